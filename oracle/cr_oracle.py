@@ -1,0 +1,518 @@
+"""numpy restatement of Commander3's constrained-realization (CR) linear system and PCG.
+TEST INFRASTRUCTURE ONLY -- never imported by the product path.
+
+Restates, for *diffuse* components with constant mixing (``F_mean`` fast path) and white per-pixel noise:
+  * ``cr_matmulA``            commander3/src/comm_cr_mod.f90:771-1024
+  * ``cr_computeRHS``         commander3/src/comm_cr_mod.f90:542-769
+  * ``cr_invM``               commander3/src/comm_cr_mod.f90:1026-1077  (diagonal preconditioner only)
+  * ``solve_cr_eqn_by_CG``    commander3/src/comm_cr_mod.f90:48-406
+  * ``cr_insert/extract_comp``commander3/src/comm_cr_utils.f90:40-113
+  * ``evalDiffuseBand`` / ``projectDiffuseBand``  commander3/src/comm_diffuse_comp_mod.f90:2027-2167
+  * diagonal preconditioner   init :1167-1252, update :1313-1557, apply :2186-2235
+  * ``matmulB``               commander3/src/comm_B_bl_mod.f90:108-127
+  * ``comm_N_rms`` invN / sqrtInvN / N   commander3/src/comm_N_rms_mod.f90:264-313
+  * ``comm_Cl`` updateS / sqrtS / sqrtInvS  commander3/src/comm_Cl_mod.f90:316-384, 550-704
+  * ``compute_invN_lm``       commander3/src/comm_N_mod.f90:127-197
+  * ``invert_matrix_with_mask`` commander3/src/math_tools.f90:406-456
+Single rank (P=1): every ring and every m is local, so the Fortran local arrays are the global ones.
+Random numbers are *inputs* (the Fortran driver owns ``planck_rng``; SURVEY.md §7 "RNG").
+
+PARITY UNPINNED vs. the reference binary (see oracle/__init__.py).
+"""
+import numpy as np
+
+from . import healpix, sht
+
+
+# ----------------------------------------------------------------------------- small objects
+class Band:
+    """``data(i)``: commander3/src/comm_data_mod.f90:33-63 (info, N, B)."""
+
+    def __init__(self, nside, lmax, siN, b_l, mb_eff=1.0, sg_mask=None, wring=None):
+        siN = np.asarray(siN, dtype=np.float64)
+        if siN.ndim == 1:
+            siN = siN[:, None]
+        self.nside, self.lmax = int(nside), int(lmax)
+        self.nmaps = siN.shape[1]
+        self.npix = 12 * nside * nside
+        assert siN.shape[0] == self.npix
+        self.siN = siN                      # 1/rms, 0 in masked pixels (comm_N_rms_mod.f90:179-193)
+        b_l = np.asarray(b_l, dtype=np.float64)
+        if b_l.ndim == 1:
+            b_l = b_l[:, None]
+        assert b_l.shape[0] == lmax + 1
+        self.b_l = b_l
+        self.mb_eff = float(mb_eff)
+        self.sg_mask = None if sg_mask is None else np.asarray(sg_mask, dtype=np.float64).reshape(self.npix, -1)
+        self.wring = wring
+        self.info = healpix.AlmInfo(lmax)
+        self.invN_diag = None
+
+    # comm_N_rms_mod.f90:264-273
+    def invN(self, m):
+        out = self.siN ** 2 * m
+        return out * self.sg_mask if self.sg_mask is not None else out
+
+    # comm_N_rms_mod.f90:304-313
+    def sqrtInvN(self, m):
+        out = self.siN * m
+        return out * self.sg_mask if self.sg_mask is not None else out
+
+    # comm_N_rms_mod.f90:288-301
+    def N(self, m):
+        with np.errstate(divide="ignore", invalid="ignore"):
+            out = np.where(self.siN > 0, m / self.siN ** 2, 0.0)
+        return out * self.sg_mask if self.sg_mask is not None else out
+
+    # comm_B_bl_mod.f90:108-127 (trans is ignored by the reference: the operator is diagonal)
+    def conv(self, alm, info):
+        out = np.zeros_like(alm)
+        ok = info.l <= self.lmax
+        nm = min(self.b_l.shape[1], alm.shape[1])
+        lc = np.minimum(info.l, self.lmax)
+        out[:, :nm] = np.where(ok[:, None], alm[:, :nm] * self.b_l[lc, :nm] * self.mb_eff, 0.0)
+        # columns beyond the beam's nmaps are left untouched for l<=lmax in the reference
+        if alm.shape[1] > nm:
+            out[:, nm:] = np.where(ok[:, None], alm[:, nm:], 0.0)
+        return out
+
+    def compute_invN_diag(self):
+        """comm_N_rms_mod.f90:214-219 + comm_N_mod.f90:127-197."""
+        out = np.zeros((self.info.nalm, self.nmaps))
+        for j in range(self.nmaps):
+            a = sht.YtW(self.nside, self.lmax, self.siN[:, j] ** 2, wring=self.wring)  # :134 YtW_scalar
+            out[:, j] = sht.invn_diag(self.nside, self.lmax, a[: self.lmax + 1])
+        self.invN_diag = out
+        return out
+
+
+def hermitian_root(A, pw):
+    """math_tools.f90:606-662 (dsyevd; returns A(1,1)=-1e30 if any eigenvalue <= 0)."""
+    W, V = np.linalg.eigh(A)
+    if np.any(W <= 0):
+        out = A.copy()
+        out[0, 0] = -1e30
+        return out
+    return (V * W ** pw) @ V.T
+
+
+class Cl:
+    """``comm_Cl``: S_mat / sqrtS_mat / sqrtInvS_mat from D_l (comm_Cl_mod.f90:316-384)."""
+
+    def __init__(self, lmax, nmaps, Dl, lmin=0, RJ2unit=None, cltype="power_law"):
+        self.lmax, self.nmaps, self.type = lmax, nmaps, cltype
+        self.lmin = lmin
+        nspec = nmaps * (nmaps + 1) // 2
+        Dl = np.asarray(Dl, dtype=np.float64).reshape(lmax + 1, nspec)
+        self.Dl = Dl
+        RJ = np.ones(nmaps) if RJ2unit is None else np.asarray(RJ2unit, dtype=np.float64)
+        self.S_mat = np.zeros((nmaps, nmaps, lmax + 1))
+        self.sqrtS_mat = np.zeros((nmaps, nmaps, lmax + 1))
+        self.sqrtInvS_mat = np.zeros((nmaps, nmaps, lmax + 1))
+        if cltype == "none":
+            return
+        for l in range(lmax + 1):
+            M = np.zeros((nmaps, nmaps))
+            ok = np.zeros(nmaps, dtype=bool)
+            k = 0
+            for i in range(nmaps):
+                for j in range(i, nmaps):
+                    if l < lmin:
+                        v = 0.0
+                    elif l == 0:
+                        v = Dl[l, k]
+                    else:
+                        v = Dl[l, k] / (l * (l + 1) / (2.0 * np.pi))
+                    v = v / (RJ[i] * RJ[j])
+                    M[i, j] = M[j, i] = v
+                    if i == j:
+                        ok[i] = Dl[l, k] > 0.0
+                    k += 1
+            for i in range(nmaps):
+                if not ok[i]:
+                    M[i, :] = 0.0
+                    M[:, i] = 0.0
+                    M[i, i] = 1.0
+            sq = hermitian_root(M, 0.5)
+            isq = hermitian_root(M, -0.5)
+            for i in range(nmaps):
+                if not ok[i]:
+                    sq[i, :] = 0.0
+                    sq[:, i] = 0.0
+                    isq[i, :] = 0.0
+                    isq[:, i] = 0.0
+            self.sqrtS_mat[:, :, l] = sq
+            self.S_mat[:, :, l] = sq @ sq
+            self.sqrtInvS_mat[:, :, l] = isq
+
+    def _apply(self, mats, alm, info, diag=False):
+        # comm_Cl_mod.f90:588-637 / 639-674; l_apod is never assigned in the reference => f_apod = 1
+        if self.type == "none":
+            return alm.copy()
+        out = np.zeros_like(alm)
+        ok = info.l <= self.lmax
+        lc = np.minimum(info.l, self.lmax)
+        if diag:
+            d = np.sqrt(np.stack([self.S_mat[j, j, :] for j in range(self.nmaps)], axis=1))  # (lmax+1, nmaps)
+            out = np.where(ok[:, None], d[lc, : alm.shape[1]] * alm, 0.0)
+        else:
+            Ml = np.moveaxis(mats, 2, 0)[lc]  # (nalm, nmaps, nmaps)
+            out = np.where(ok[:, None], np.einsum("nij,nj->ni", Ml, alm), 0.0)
+        return out
+
+    def sqrtS(self, alm, info, diag=False):
+        return self._apply(self.sqrtS_mat, alm, info, diag)
+
+    def sqrtInvS(self, alm, info):
+        return self._apply(self.sqrtInvS_mat, alm, info)
+
+
+class DiffuseComp:
+    """``comm_diffuse_comp`` reduced to what the CR system reads (constant mixing)."""
+
+    def __init__(self, lmax_amp, nmaps, cl, F_mean, active=True, mu=None, nside=None):
+        self.lmax_amp, self.nmaps, self.Cl = int(lmax_amp), int(nmaps), cl
+        self.F_mean = np.asarray(F_mean, dtype=np.float64).reshape(-1, nmaps)  # (numband, nmaps); det=0
+        self.F_null = np.all(self.F_mean == 0.0, axis=1)
+        self.active = active
+        self.info = healpix.AlmInfo(lmax_amp)
+        self.mu = mu
+        self.nside = nside
+        self.cltype = cl.type
+
+
+class CRSystem:
+    """The stacked linear system: ``ncr`` / ``ind_comp`` (comm_signal_mod.f90:113-125, comm_cr_utils.f90:25-33)."""
+
+    def __init__(self, bands, comps, only_pol=False):
+        self.bands, self.comps = list(bands), list(comps)
+        self.only_pol = only_pol
+        self.ind_comp = []
+        pos = 0
+        for c in self.comps:
+            n = c.info.nalm * c.nmaps
+            self.ind_comp.append((pos, n, c.nmaps))
+            pos += n
+        self.ncr = pos
+        self.precond = None
+
+    # comm_cr_utils.f90:92-113
+    def extract(self, k, x):
+        pos, n, nmaps = self.ind_comp[k]
+        return x[pos:pos + n].reshape(nmaps, n // nmaps).T.copy()
+
+    # comm_cr_utils.f90:57-78
+    def insert(self, k, add, alm, x):
+        pos, n, nmaps = self.ind_comp[k]
+        flat = alm.T.reshape(-1)
+        if add:
+            x[pos:pos + n] += flat
+        else:
+            x[pos:pos + n] = flat
+
+    # ---- SHT on (n, nmaps) column blocks; polarised (spin-2) columns are a later round
+    @staticmethod
+    def _Y(band, alm, lmax):
+        return np.stack([sht.Y(band.nside, lmax, alm[:, j]) for j in range(alm.shape[1])], axis=1)
+
+    @staticmethod
+    def _Yt(band, m, lmax):
+        return np.stack([sht.Yt(band.nside, lmax, m[:, j]) for j in range(m.shape[1])], axis=1)
+
+    def _lmax_all(self):
+        lm = -1
+        for c in self.comps:
+            if c.active:
+                lm = max(max(lm, c.lmax_amp), 2)  # comm_cr_mod.f90:815
+        return lm
+
+    # ------------------------------------------------------------------ evalDiffuseBand / projectDiffuseBand
+    def getBand_alm(self, c, ib, amp_in):
+        """comm_diffuse_comp_mod.f90:2027-2109 with alm_out=.true., constant mixing (:2077-2080) then beam (:2089)."""
+        b = self.bands[ib]
+        out = np.zeros((b.info.nalm, b.nmaps))
+        if c.F_null[ib]:
+            return out
+        nmaps = min(b.nmaps, c.nmaps)
+        m = amp_in[:, :nmaps] * c.F_mean[ib, :nmaps]
+        m = b.conv(m, b.info)
+        out[:, :nmaps] = m
+        return out
+
+    def projectBand_alm(self, c, ib, alm_band):
+        """comm_diffuse_comp_mod.f90:2112-2167 with alm_in=.true.: beam -> F_mean -> alm_equal to comp lmax."""
+        b = self.bands[ib]
+        if c.F_null[ib]:
+            return np.zeros((c.info.nalm, c.nmaps))
+        nmaps = min(c.nmaps, b.nmaps)
+        m = b.conv(alm_band[:, :nmaps], b.info)
+        m = m * c.F_mean[ib, :nmaps]
+        return healpix.alm_equal(m, b.info, c.info, nmaps_dst=c.nmaps)
+
+    # ------------------------------------------------------------------ cr_matmulA
+    def matmulA(self, x):
+        """commander3/src/comm_cr_mod.f90:771-1024."""
+        y = np.zeros(self.ncr)
+        sqrtS_x = x.copy()
+        for k, c in enumerate(self.comps):  # :797-836
+            if not c.active:
+                continue
+            if c.cltype != "none":
+                alm = self.extract(k, sqrtS_x)
+                self.insert(k, False, c.Cl.sqrtS(alm, c.info), sqrtS_x)
+        lmax = self._lmax_all()
+        for ib, b in enumerate(self.bands):  # :843
+            map_alm = np.zeros((b.info.nalm, b.nmaps))
+            for k, c in enumerate(self.comps):
+                if not c.active:
+                    continue
+                alm = self.extract(k, sqrtS_x)
+                alm[c.info.l > b.lmax, :] = 0.0                      # :858-860
+                pm = healpix.alm_equal(alm, c.info, b.info, nmaps_dst=b.nmaps)  # :861 set_alm (zero-filled)
+                map_alm += self.getBand_alm(c, ib, pm)               # :865-867
+            if lmax > -1:
+                info_buff = healpix.AlmInfo(lmax)                    # :888-892
+                buff = healpix.alm_equal(map_alm, b.info, info_buff, nmaps_dst=b.nmaps)
+                mp = self._Y(b, buff, lmax)
+            else:
+                mp = np.zeros((b.npix, b.nmaps))
+            mp = b.invN(mp)                                          # :905
+            if lmax > -1:
+                buff = self._Yt(b, mp, lmax)                         # :914-916
+                map_alm = healpix.alm_equal(buff, info_buff, b.info, nmaps_dst=b.nmaps)
+            for k, c in enumerate(self.comps):                       # :920-948
+                if not c.active:
+                    continue
+                alm = self.projectBand_alm(c, ib, map_alm)
+                alm[c.info.l > b.lmax, :] = 0.0                      # :931-933
+                self.insert(k, True, alm, y)
+        for k, c in enumerate(self.comps):                           # :957-1008
+            if not c.active:
+                continue
+            if c.cltype != "none":
+                alm = self.extract(k, y)
+                self.insert(k, False, c.Cl.sqrtS(alm, c.info), y)
+                self.insert(k, True, self.extract(k, x), y)
+        return y
+
+    # ------------------------------------------------------------------ cr_computeRHS
+    def computeRHS(self, residuals, operation="sample", noise_xi=None, eta=None):
+        """commander3/src/comm_cr_mod.f90:542-769.
+
+        residuals[i] : (npix, nmaps) output of compute_residual (comm_chisq_mod.f90:196-267) for band i
+        noise_xi[i]  : (npix, nmaps) unit Gaussians in the reference's draw order (Stokes outer, pixel inner :602-608)
+        eta          : (ncr,) unit Gaussians for the prior term in stacked order (:704-709)
+        """
+        rhs = np.zeros(self.ncr)
+        for ib, b in enumerate(self.bands):
+            mp = np.asarray(residuals[ib], dtype=np.float64).reshape(b.npix, b.nmaps).copy()
+            if operation == "sample":                                # :600-609
+                mp = b.sqrtInvN(mp)
+                mp = mp + np.asarray(noise_xi[ib]).reshape(b.npix, b.nmaps)
+                mp = b.sqrtInvN(mp)
+            else:
+                mp = b.invN(mp)                                      # :611
+            alm = self._Yt(b, mp, b.lmax)                            # :615
+            alm = b.conv(alm, b.info)                                # :616
+            for k, c in enumerate(self.comps):
+                if not c.active:
+                    continue
+                if c.F_null[ib]:
+                    Tm = np.zeros((c.info.nalm, c.nmaps))            # :631-632
+                else:
+                    Tm = healpix.alm_equal(alm, b.info, c.info, nmaps_dst=c.nmaps)  # :634
+                    Tm = Tm * c.F_mean[ib, :]                        # :636-639
+                Tm = c.Cl.sqrtS(Tm, c.info)                          # :652
+                Tm[c.info.l > b.lmax, :] = 0.0                       # :655-657
+                self.insert(k, True, Tm, rhs)                        # :659
+        for k, c in enumerate(self.comps):                           # :690-728
+            if not c.active or c.cltype == "none":
+                continue
+            e = np.zeros((c.info.nalm, c.nmaps))
+            if operation == "sample":
+                e = self.extract(k, np.asarray(eta, dtype=np.float64))
+                if self.only_pol:
+                    e[:, 0] = 0.0                                    # :705
+            if c.mu is not None:
+                e = e + c.Cl.sqrtInvS(c.mu, c.info)                  # :712-725
+            self.insert(k, True, e, rhs)
+        return rhs
+
+    # ------------------------------------------------------------------ diagonal preconditioner
+    def init_precond_diag(self):
+        """initDiffPrecond_diagonal: comm_diffuse_comp_mod.f90:1167-1252."""
+        comps = self.comps
+        npre = len(comps)
+        lmax_pre = max(c.lmax_amp for c in comps)                    # :212
+        nmaps_pre = max(c.nmaps for c in comps)                      # :214
+        info_pre = healpix.AlmInfo(lmax_pre)
+        M0 = np.zeros((info_pre.nalm, nmaps_pre, npre, npre))
+        for b in self.bands:
+            if b.invN_diag is None:
+                b.compute_invN_diag()
+        for j in range(nmaps_pre):
+            for q, b in enumerate(self.bands):
+                if j >= b.nmaps:
+                    continue
+                i2 = b.info.lm2i_vec(info_pre.l, info_pre.m)
+                ok = i2 >= 0
+                lc = np.minimum(info_pre.l, b.lmax)
+                base = np.where(ok, b.invN_diag[np.maximum(i2, 0), j] * b.b_l[lc, min(j, b.b_l.shape[1] - 1)] ** 2, 0.0)
+                for k1, p1 in enumerate(comps):
+                    if j >= p1.nmaps:
+                        continue
+                    for k2, p2 in enumerate(comps):
+                        if j >= p2.nmaps:
+                            continue
+                        sel = (info_pre.l <= p1.lmax_amp) & (info_pre.l <= p2.lmax_amp)
+                        M0[:, j, k1, k2] += np.where(sel, base * p1.F_mean[q, j] * p2.F_mean[q, j], 0.0)
+        self.precond = dict(info=info_pre, nmaps=nmaps_pre, M0=M0, npre=npre)
+        return self.precond
+
+    def update_precond_diag(self):
+        """updateDiffPrecond_diagonal: comm_diffuse_comp_mod.f90:1313-1557."""
+        P = self.precond
+        info_pre, nmaps_pre, npre = P["info"], P["nmaps"], P["npre"]
+        M0 = P["M0"]
+        # comp2ind: only components with mat(k,k) > 0 take part (:1232-1239)
+        present = np.stack([M0[:, :, k, k] > 0.0 for k in range(npre)], axis=2)  # (nalm, nmaps, npre)
+        M = M0.copy()
+        for k1, c in enumerate(self.comps):                          # right- and left-multiply with sqrt(S), diag form
+            if c.cltype == "none":
+                continue
+            lc = np.minimum(info_pre.l, c.Cl.lmax)
+            ok = info_pre.l <= c.Cl.lmax
+            d = np.zeros((info_pre.nalm, nmaps_pre))
+            for j in range(min(nmaps_pre, c.nmaps)):
+                d[:, j] = np.where(ok, np.sqrt(c.Cl.S_mat[j, j, lc]), 0.0)   # sqrtS(diag=.true.) :1371,1409
+            M[:, :, :, k1] *= d[:, :, None]
+            M[:, :, k1, :] *= d[:, :, None]
+        if self.only_pol:
+            M[:, 0, :, :] = 0.0                                      # :1428-1433
+        for k1, c in enumerate(self.comps):                          # add unity :1452-1470
+            if c.cltype == "none":
+                continue
+            sel = (info_pre.l <= c.lmax_amp)[:, None] & present[:, :, k1]
+            M[:, :, k1, k1] += np.where(sel, 1.0, 0.0)
+        for k1, c in enumerate(self.comps):                          # :1484-1495
+            if c.active:
+                continue
+            M[:, :, k1, :] = 0.0
+            M[:, :, :, k1] = 0.0
+        # restrict to 'present' sub-block and invert with mask (math_tools.f90:406-456)
+        invM = np.zeros_like(M)
+        nalm = info_pre.nalm
+        for j in range(nmaps_pre):
+            for i in range(nalm):
+                idx = np.nonzero(present[i, j])[0]
+                if idx.size == 0:
+                    continue
+                sub = M[i, j][np.ix_(idx, idx)]
+                if not np.any(sub != 0.0):
+                    invM[i, j][np.ix_(idx, idx)] = sub
+                    continue
+                sub = sub.copy()
+                msk = np.ones(idx.size, dtype=bool)
+                for t in range(idx.size):
+                    if abs(sub[t, t]) <= 0.0:
+                        msk[t] = False
+                        sub[t, t] = 1.0
+                inv = np.linalg.inv(sub)
+                for t in range(idx.size):
+                    if not msk[t]:
+                        inv[t, t] = 0.0
+                invM[i, j][np.ix_(idx, idx)] = inv
+        P["invM"] = invM
+        P["present"] = present
+        return invM
+
+    def invM(self, x):
+        """cr_invM (comm_cr_mod.f90:1026-1077) -> applyDiffPrecond_diagonal (comm_diffuse_comp_mod.f90:2186-2235)."""
+        P = self.precond
+        info_pre, nmaps_pre, npre = P["info"], P["nmaps"], P["npre"]
+        yv = np.zeros((npre, info_pre.nalm, nmaps_pre))
+        for k, c in enumerate(self.comps):
+            alm = self.extract(k, x)
+            kidx = info_pre.lm2i_vec(c.info.l, c.info.m)
+            yv[k][kidx, : c.nmaps] = alm
+        out = yv.copy()
+        invM, present = P["invM"], P["present"]
+        # y(ind) = M y(ind) over the present sub-block; absent entries pass through unchanged (:2211-2217)
+        mv = np.einsum("njab,bnj->anj", invM, yv)
+        anyp = present.any(axis=2)                                   # n == 0 -> cycle
+        for k in range(npre):
+            out[k] = np.where(present[:, :, k] & anyp, mv[k], yv[k])
+        res = np.zeros(self.ncr)
+        for k, c in enumerate(self.comps):
+            kidx = info_pre.lm2i_vec(c.info.l, c.info.m)
+            self.insert(k, False, out[k][kidx, : c.nmaps], res)
+        return res
+
+    # ------------------------------------------------------------------ solve_cr_eqn_by_CG
+    def solve(self, b, conv_crit="fixed_iter", tol=1e-8, miniter=5, maxiter=40, check_freq=1, x0=None,
+              history=None):
+        """commander3/src/comm_cr_mod.f90:48-406.  Returns (x, niter, stat); x already multiplied by sqrt(S)."""
+        if x0 is None:
+            x = np.zeros(self.ncr)                                   # :133-134 cg_init_zero
+        else:                                                        # :136-173
+            x = np.asarray(x0, dtype=np.float64).copy()
+            for k, c in enumerate(self.comps):
+                if c.active and c.cltype != "none":
+                    self.insert(k, False, c.Cl.sqrtInvS(self.extract(k, x), c.info), x)
+        r = b - self.matmulA(x)                                      # :201
+        d = self.invM(r)                                             # :203
+        delta_new = float(r @ d)                                     # :206
+        delta0 = float(b @ self.invM(b))                             # :208
+        lim = tol * delta0                                           # :220-222
+        val = 1e2 * lim
+        i = 1
+        stat = 0
+        niter = 0
+        while i <= maxiter:                                          # :230
+            if i % check_freq == 0:                                  # :236-247
+                val = delta_new
+                if val < lim and (i >= miniter or delta_new <= 1e-30 * delta0) and conv_crit != "fixed_iter":
+                    break
+            q = self.matmulA(d)                                      # :253
+            alpha = delta_new / float(d @ q)                         # :254
+            x = x + alpha * d                                        # :255
+            r = r - alpha * q                                        # :261
+            s = self.invM(r)                                         # :266
+            delta_old = delta_new
+            delta_new = float(r @ s)                                 # :270
+            beta = delta_new / delta_old
+            d = s + beta * d                                         # :272
+            if history is not None:
+                history.append(delta_new)
+            niter = i
+            i += 1
+        for k, c in enumerate(self.comps):                           # :350-389
+            if c.active and c.cltype != "none":
+                self.insert(k, False, c.Cl.sqrtS(self.extract(k, x), c.info), x)
+        if i >= maxiter and conv_crit != "fixed_iter":               # :392-395 (Fortran: i == maxiter+1 after a full loop)
+            stat = 1
+        return x, niter, stat
+
+
+def cg_solve_2x2_kat():
+    """The reference's only known-answer test: commander3/todscripts/wmap/cg_solver.py:30-61
+    (A=[[3,2],[2,6]], b=[2,-8], M=I => x=[2,-2]), run through the same recurrence as ``CRSystem.solve``."""
+    A = np.array([[3.0, 2.0], [2.0, 6.0]])
+    b = np.array([2.0, -8.0])
+    x = np.zeros(2)
+    r = b - A @ x
+    d = r.copy()
+    delta_new = r @ d
+    delta0 = delta_new
+    it = 0
+    while it < 1000 and delta_new > 1e-12 * delta0:
+        q = A @ d
+        alpha = delta_new / (d @ q)
+        x = x + alpha * d
+        r = r - alpha * q
+        s = r.copy()
+        delta_old = delta_new
+        delta_new = r @ s
+        d = s + (delta_new / delta_old) * d
+        it += 1
+    return x, it

@@ -1,0 +1,103 @@
+"""ctypes front-end of oracle/sht_oracle.c.  TEST INFRASTRUCTURE ONLY.
+
+Mirrors the SHT entry points of commander3/src/comm_map_mod.f90:437-579 for one scalar column:
+``Y`` (alm->map), ``Yt`` (exact transpose), ``YtW`` (analysis with ring weights * 4pi/Npix), ``WY``.
+"""
+import ctypes
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB = None
+
+JOB_YtW, JOB_Y, JOB_Yt, JOB_WY = 0, 1, 2, 3  # commander3/src/sharp.f90:8-14
+
+
+def build(force=False):
+    so = os.path.join(_HERE, "_build", "libsht_oracle.so")
+    src = os.path.join(_HERE, "sht_oracle.c")
+    if force or not os.path.exists(so) or os.path.getmtime(so) < os.path.getmtime(src):
+        subprocess.check_call(["make", "-C", _HERE, "-B" if force else "-s"], stdout=subprocess.DEVNULL)
+    return so
+
+
+def lib():
+    global _LIB
+    if _LIB is None:
+        so = os.path.join(_HERE, "_build", "libsht_oracle.so")
+        if not os.path.exists(so):
+            so = build()
+        L = ctypes.CDLL(so)
+        dp = ctypes.POINTER(ctypes.c_double)
+        L.orc_sht.argtypes = [ctypes.c_int, ctypes.c_int, ctypes.c_int, dp, dp, dp, ctypes.c_int, ctypes.c_int,
+                              ctypes.c_int]
+        L.orc_sht.restype = ctypes.c_int
+        L.orc_invn_diag.argtypes = [ctypes.c_int, ctypes.c_int, dp, dp, ctypes.c_int]
+        L.orc_invn_diag.restype = ctypes.c_int
+        L.orc_lm2i.argtypes = [ctypes.c_int, ctypes.c_int, ctypes.c_int]
+        L.orc_lm2i.restype = ctypes.c_int64
+        _LIB = L
+    return _LIB
+
+
+def _p(a):
+    return a.ctypes.data_as(ctypes.POINTER(ctypes.c_double))
+
+
+def nalm(lmax):
+    return (lmax + 1) ** 2
+
+
+def npix(nside):
+    return 12 * nside * nside
+
+
+def sht(job, nside, lmax, alm=None, map=None, wring=None, fft_mode=1, use_mlim=True, nthreads=0):
+    """Run one scalar SHT.  Returns the output array (map for Y/WY, alm for Yt/YtW)."""
+    L = lib()
+    wp = None
+    if wring is not None:
+        wring = np.ascontiguousarray(wring, dtype=np.float64)
+        assert wring.shape == (2 * nside,)
+        wp = _p(wring)
+    if job in (JOB_Y, JOB_WY):
+        a = np.ascontiguousarray(alm, dtype=np.float64)
+        assert a.shape == (nalm(lmax),), a.shape
+        out = np.zeros(npix(nside))
+        rc = L.orc_sht(job, nside, lmax, wp, _p(a), _p(out), int(fft_mode), int(use_mlim), int(nthreads))
+    else:
+        m = np.ascontiguousarray(map, dtype=np.float64)
+        assert m.shape == (npix(nside),), m.shape
+        out = np.zeros(nalm(lmax))
+        rc = L.orc_sht(job, nside, lmax, wp, _p(out), _p(m), int(fft_mode), int(use_mlim), int(nthreads))
+    if rc != 0:
+        raise RuntimeError("orc_sht failed")
+    return out
+
+
+def Y(nside, lmax, alm, **kw):
+    return sht(JOB_Y, nside, lmax, alm=alm, **kw)
+
+
+def Yt(nside, lmax, map, **kw):
+    return sht(JOB_Yt, nside, lmax, map=map, **kw)
+
+
+def YtW(nside, lmax, map, wring=None, **kw):
+    return sht(JOB_YtW, nside, lmax, map=map, wring=wring, **kw)
+
+
+def WY(nside, lmax, alm, wring=None, **kw):
+    return sht(JOB_WY, nside, lmax, alm=alm, wring=wring, **kw)
+
+
+def invn_diag(nside, lmax, al0, nthreads=0):
+    """compute_invN_lm (commander3/src/comm_N_mod.f90:127-197) by exact Gauss-Legendre quadrature."""
+    L = lib()
+    al0 = np.ascontiguousarray(al0, dtype=np.float64)
+    assert al0.shape == (lmax + 1,)
+    out = np.zeros(nalm(lmax))
+    L.orc_invn_diag(nside, lmax, _p(al0), _p(out), int(nthreads))
+    return out

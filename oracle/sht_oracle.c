@@ -1,0 +1,477 @@
+/*
+ * oracle/sht_oracle.c -- TEST INFRASTRUCTURE ONLY (CPU oracle; never linked into the product).
+ *
+ * fp64 CPU restatement of the spherical-harmonic transforms the Commander3 CR solver reaches
+ * through its libsharp2 FFI:
+ *   - job types / calling convention: commander3/src/sharp.f90:8-14 (SHARP_YtW=0, Y=1, Yt=2, WY=3),
+ *     :186-241 (sharp_execute_d: one column pointer per map, always SHARP_DP)
+ *   - which job Commander issues per Stokes column: commander3/src/comm_map_mod.f90:437-579
+ *     (exec_sharp_Y / _Yt / _YtW / _WY; T = spin 0, (Q,U) = one spin-2 call)
+ *   - a_lm storage = m-major real-packed: commander3/src/comm_map_mod.f90:228-261 (index build),
+ *     :1213-1246 (lm2i), :1497-1520 (get_alm: complex a_lm = (v(+m) + i v(-m))/sqrt(2))
+ *   - ring weights W = 1 + weight_ring, analysis weight w_ring*4pi/Npix: comm_map_mod.f90:266-283
+ *
+ * PARITY UNPINNED against libsharp2: libsharp2 (cmake/project_instructions.cmake:93, "master" tarball, or the
+ * copy in HEALPix 3.70) is not present in /root/reference nor in this image, and the reference holds no test
+ * or golden vector for this path.  This file restates the *published* algorithm (per-ring FFT + per-m
+ * Legendre recursion on HEALPix RING geometry) and is itself pinned by an independent brute-force direct sum
+ * over scipy.special.sph_harm_y (oracle/bruteforce.py, tests/golden/).
+ *
+ * Deliberately simple: scaled three-term recursion with an explicit power-of-two exponent, phases stored
+ * ring-major, ring transforms either by direct DFT (fft_mode=0, the independent check) or by radix-2 +
+ * Bluestein FFT (fft_mode=1, used for the timed CPU baseline).
+ */
+#include <complex.h>
+#include <math.h>
+#include <stddef.h>
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+#ifdef _OPENMP
+#include <omp.h>
+#endif
+
+typedef double complex cplx;
+
+#define JOB_YtW 0
+#define JOB_Y 1
+#define JOB_Yt 2
+#define JOB_WY 3
+
+static const double TWOPI = 6.283185307179586476925286766559;
+static const double PI = 3.141592653589793238462643383279;
+
+/* ---------------------------------------------------------------- HEALPix RING geometry */
+/* ring = 1..4*nside-1, north to south (in_ring ordering of comm_map_mod.f90:198-226). */
+typedef struct {
+    int nphi;       /* pixels in ring */
+    double z;       /* cos(theta) */
+    double sth;     /* sin(theta) */
+    double phi0;    /* azimuth of first pixel */
+    int64_t start;  /* RING index of first pixel */
+} ringinfo;
+
+static ringinfo ring_info(int nside, int ring) {
+    ringinfo r;
+    int64_t N = nside, npix = 12 * N * N;
+    int northring = ring > 2 * nside ? 4 * nside - ring : ring;
+    double fN = (double)N;
+    if (northring < nside) { /* polar cap */
+        double i = (double)northring;
+        double omz = i * i / (3.0 * fN * fN); /* 1 - z */
+        r.z = 1.0 - omz;
+        r.sth = sqrt(omz * (2.0 - omz));
+        r.nphi = 4 * northring;
+        r.phi0 = PI / (4.0 * i);
+        r.start = 2 * (int64_t)northring * (northring - 1);
+    } else { /* equatorial belt */
+        r.z = 4.0 / 3.0 - 2.0 * (double)northring / (3.0 * fN);
+        r.sth = sqrt((1.0 - r.z) * (1.0 + r.z));
+        r.nphi = 4 * nside;
+        r.phi0 = ((northring - nside) & 1) ? 0.0 : PI / (4.0 * fN);
+        r.start = 2 * N * (N - 1) + 4 * N * (int64_t)(northring - nside);
+    }
+    if (ring != northring) { /* southern mirror */
+        r.z = -r.z;
+        r.start = npix - r.start - r.nphi;
+    }
+    return r;
+}
+
+void orc_ring_info(int nside, int ring, int* nphi, double* z, double* sth, double* phi0, int64_t* start) {
+    ringinfo r = ring_info(nside, ring);
+    *nphi = r.nphi; *z = r.z; *sth = r.sth; *phi0 = r.phi0; *start = r.start;
+}
+
+/* ---------------------------------------------------------------- a_lm layout (P=1: all m on this rank) */
+/* comm_map_mod.f90:228-261: m=0 block of lmax+1 reals, then per m>0 (l=m..lmax) interleaved (+m,-m). */
+static inline int64_t mind(int lmax, int m) {
+    if (m == 0) return 0;
+    /* (lmax+1) + sum_{k=1}^{m-1} 2(lmax-k+1) */
+    return (int64_t)(lmax + 1) + 2 * ((int64_t)(m - 1) * (lmax + 1) - (int64_t)(m - 1) * m / 2);
+}
+int64_t orc_lm2i(int lmax, int l, int m) { /* comm_map_mod.f90:1213-1246 */
+    int am = m < 0 ? -m : m;
+    if (l > lmax || am > l) return -1;
+    if (m == 0) return l;
+    return mind(lmax, am) + 2 * (l - am) + (m < 0 ? 1 : 0);
+}
+
+/* ---------------------------------------------------------------- FFT (radix-2 + Bluestein), fft_mode=1 */
+static void fft_pow2(cplx* a, int n, int sign) { /* in place, unnormalised, exp(sign*2*pi*i*jk/n) */
+    for (int i = 1, j = 0; i < n; ++i) {
+        int bit = n >> 1;
+        for (; j & bit; bit >>= 1) j ^= bit;
+        j ^= bit;
+        if (i < j) { cplx t = a[i]; a[i] = a[j]; a[j] = t; }
+    }
+    for (int len = 2; len <= n; len <<= 1) {
+        int half = len >> 1;
+        for (int k = 0; k < half; ++k) {
+            double ang = sign * TWOPI * (double)k / (double)len;
+            cplx w = cos(ang) + I * sin(ang);
+            for (int i = k; i < n; i += len) {
+                cplx u = a[i], v = a[i + half] * w;
+                a[i] = u + v;
+                a[i + half] = u - v;
+            }
+        }
+    }
+}
+
+typedef struct {
+    int n, M;      /* M = 0: n is a power of two, plain FFT */
+    cplx* w;       /* chirp w_j = exp(+i*pi*j^2/n), j<n */
+    cplx* chat;    /* FFT_M of conj chirp (sign +1 transform); the sign -1 one is its conjugate-symmetric twin */
+} fftplan;
+
+static int is_pow2(int n) { return (n & (n - 1)) == 0; }
+
+static void plan_init(fftplan* p, int n) {
+    p->n = n; p->M = 0; p->w = NULL; p->chat = NULL;
+    if (is_pow2(n)) return;
+    int M = 1;
+    while (M < 2 * n - 1) M <<= 1;
+    p->M = M;
+    p->w = (cplx*)malloc(sizeof(cplx) * n);
+    p->chat = (cplx*)calloc(M, sizeof(cplx));
+    for (int j = 0; j < n; ++j) {
+        int64_t q = ((int64_t)j * j) % (2 * (int64_t)n); /* exact phase reduction */
+        double ang = PI * (double)q / (double)n;
+        p->w[j] = cos(ang) + I * sin(ang);
+    }
+    p->chat[0] = conj(p->w[0]);
+    for (int j = 1; j < n; ++j) { p->chat[j] = conj(p->w[j]); p->chat[M - j] = conj(p->w[j]); }
+    fft_pow2(p->chat, M, -1);
+}
+static void plan_free(fftplan* p) { free(p->w); free(p->chat); }
+
+/* y_k = sum_j x_j exp(sign*2*pi*i*jk/n); x,y length n; work length >= max(n,M) */
+static void fft_any(const fftplan* p, const cplx* x, cplx* y, cplx* work, int sign) {
+    int n = p->n;
+    if (p->M == 0) {
+        memcpy(y, x, sizeof(cplx) * n);
+        fft_pow2(y, n, sign);
+        return;
+    }
+    int M = p->M;
+    /* sign=+1: exp(2 pi i jk/n) = w_j w_k conj(w_{k-j}).  sign=-1: conjugate everything. */
+    for (int j = 0; j < n; ++j) work[j] = x[j] * (sign > 0 ? p->w[j] : conj(p->w[j]));
+    for (int j = n; j < M; ++j) work[j] = 0;
+    fft_pow2(work, M, -1);
+    if (sign > 0) for (int j = 0; j < M; ++j) work[j] *= p->chat[j];
+    else          for (int j = 0; j < M; ++j) work[j] *= conj(p->chat[(M - j) & (M - 1)]);
+    fft_pow2(work, M, +1);
+    double inv = 1.0 / (double)M;
+    for (int k = 0; k < n; ++k) y[k] = work[k] * inv * (sign > 0 ? p->w[k] : conj(p->w[k]));
+}
+
+/* ---------------------------------------------------------------- Legendre helpers */
+/* eps_lm = sqrt((l^2-m^2)/(4l^2-1)) */
+static inline double eps_lm(int l, int m) {
+    double dl = (double)l, dm = (double)m;
+    return sqrt((dl * dl - dm * dm) / (4.0 * dl * dl - 1.0));
+}
+
+/* libsharp's (ring,m) cut: all lambda_lm(theta), l<=lmax, are negligible for m above this. */
+static int mlim_of(int lmax, int spin, double sth, double cth) {
+    double ofs = lmax * 0.01;
+    if (ofs < 100.) ofs = 100.;
+    double b = -2 * spin * fabs(cth);
+    double t1 = lmax * sth + ofs;
+    double c = (double)spin * spin - t1 * t1;
+    double discr = b * b - 4 * c;
+    if (discr <= 0) return lmax;
+    double res = (-b + sqrt(discr)) / 2.;
+    if (res > lmax) res = lmax;
+    return (int)(res + 0.5);
+}
+
+#define RESCALE_BIG 0x1p+300
+#define RESCALE_INV 0x1p-300
+
+/*
+ * Scalar (spin-0) SHT on the full HEALPix sphere, one map.
+ *   job      : JOB_Y / JOB_WY (alm -> map), JOB_Yt / JOB_YtW (map -> alm)
+ *   wring    : [2*nside] ring weights W (comm_map_mod.f90:266-283 passes 1+weight_ring); NULL = 1
+ *   alm      : real-packed m-major, (lmax+1)^2 doubles
+ *   map      : RING-ordered, 12*nside^2 doubles
+ *   fft_mode : 0 direct DFT per ring (independent check), 1 FFT
+ *   use_mlim : 1 = skip (ring,m) pairs beyond libsharp's mlim
+ * Returns 0.
+ */
+int orc_sht(int job, int nside, int lmax, const double* wring, double* alm, double* map, int fft_mode,
+            int use_mlim, int nthreads) {
+    const int nring = 4 * nside - 1, npair = 2 * nside, mmax = lmax, nm = mmax + 1;
+    const int64_t npix = 12 * (int64_t)nside * nside;
+    const int synth = (job == JOB_Y || job == JOB_WY);
+    const int weighted = (job == JOB_YtW || job == JOB_WY);
+    const double sqrt2 = sqrt(2.0);
+#ifdef _OPENMP
+    if (nthreads > 0) omp_set_num_threads(nthreads);
+#endif
+    (void)nthreads;
+    cplx* ph = (cplx*)calloc((size_t)nring * nm, sizeof(cplx)); /* ph[(ring-1)*nm + m] */
+    if (!ph) return -1;
+    ringinfo* ri = (ringinfo*)malloc(sizeof(ringinfo) * (nring + 1));
+    for (int r = 1; r <= nring; ++r) ri[r] = ring_info(nside, r);
+    /* log lambda_mm prefactors: lambda_mm = (-1)^m sqrt((2m+1)!!/(4 pi (2m)!!)) sin^m */
+    double* logpref = (double*)malloc(sizeof(double) * nm);
+    logpref[0] = -0.5 * log(4.0 * PI);
+    for (int m = 1; m <= mmax; ++m) logpref[m] = logpref[m - 1] + 0.5 * log((2.0 * m + 1.0) / (2.0 * m));
+
+    /* ---------------- analysis: pixels -> phases (per ring) */
+    fftplan* plans = NULL;
+    if (fft_mode) {
+        plans = (fftplan*)malloc(sizeof(fftplan) * (nside + 1));
+        for (int i = 1; i <= nside; ++i) plan_init(&plans[i], 4 * i);
+    }
+    if (!synth) {
+#pragma omp parallel
+        {
+            cplx* x = (cplx*)malloc(sizeof(cplx) * 4 * nside);
+            cplx* y = (cplx*)malloc(sizeof(cplx) * 4 * nside);
+            cplx* work = (cplx*)malloc(sizeof(cplx) * 16 * nside);
+            double* ct = (double*)malloc(sizeof(double) * 4 * nside);
+            double* st = (double*)malloc(sizeof(double) * 4 * nside);
+#pragma omp for schedule(dynamic, 4)
+            for (int r = 1; r <= nring; ++r) {
+                const ringinfo R = ri[r];
+                const int n = R.nphi;
+                const int northring = r > 2 * nside ? 4 * nside - r : r;
+                double wgt = 1.0;
+                if (weighted) wgt = (wring ? wring[northring - 1] : 1.0) * 4.0 * PI / (double)npix;
+                const double* pm = map + R.start;
+                cplx* out = ph + (size_t)(r - 1) * nm;
+                if (fft_mode) {
+                    for (int k = 0; k < n; ++k) x[k] = pm[k] * wgt;
+                    fft_any(&plans[n / 4], x, y, work, -1);
+                    for (int m = 0; m <= mmax; ++m) {
+                        double ang = -(double)m * R.phi0;
+                        out[m] = y[m % n] * (cos(ang) + I * sin(ang));
+                    }
+                } else {
+                    for (int j = 0; j < n; ++j) { ct[j] = cos(TWOPI * j / n); st[j] = sin(TWOPI * j / n); }
+                    for (int m = 0; m <= mmax; ++m) {
+                        double sr = 0, si = 0;
+                        int64_t idx = 0, step = m % n;
+                        for (int k = 0; k < n; ++k) {
+                            sr += pm[k] * ct[idx];
+                            si -= pm[k] * st[idx];
+                            idx += step; if (idx >= n) idx -= n;
+                        }
+                        double ang = -(double)m * R.phi0;
+                        out[m] = (sr + I * si) * wgt * (cos(ang) + I * sin(ang));
+                    }
+                }
+            }
+            free(x); free(y); free(work); free(ct); free(st);
+        }
+    }
+
+    /* ---------------- Legendre stage, parallel over m */
+#pragma omp parallel
+    {
+        double* ieps = (double*)malloc(sizeof(double) * (lmax + 2));
+        double* epsv = (double*)malloc(sizeof(double) * (lmax + 2));
+        cplx* a = (cplx*)malloc(sizeof(cplx) * (lmax + 1));
+#pragma omp for schedule(dynamic, 1)
+        for (int mi = 0; mi <= mmax; ++mi) {
+            /* interleave long (small m) and short (large m) columns */
+            const int m = (mi & 1) ? mmax - mi / 2 : mi / 2;
+            for (int l = m; l <= lmax; ++l) { epsv[l] = eps_lm(l, m); ieps[l] = l > m ? 1.0 / epsv[l] : 0.0; }
+            const int64_t base = mind(lmax, m);
+            const double mfac = m > 0 ? sqrt2 : 1.0;
+            if (synth) {
+                for (int l = m; l <= lmax; ++l)
+                    a[l] = m == 0 ? alm[base + l] + 0 * I
+                                  : (alm[base + 2 * (l - m)] + I * alm[base + 2 * (l - m) + 1]) * mfac;
+            } else {
+                for (int l = m; l <= lmax; ++l) a[l] = 0;
+            }
+            for (int rp = 1; rp <= npair; ++rp) {
+                const ringinfo R = ri[rp];
+                const double x = R.z, sth = R.sth;
+                if (use_mlim && m > mlim_of(lmax, 0, sth, x)) continue;
+                const int has_south = rp < npair;
+                /* lambda_mm as mantissa * 2^e */
+                double l2 = (logpref[m] + (m > 0 ? (double)m * log(sth) : 0.0)) / M_LN2;
+                double fl = floor(l2);
+                long e = (long)fl;
+                double lc = exp2(l2 - fl);
+                if (m & 1) lc = -lc;
+                double lp = 0.0;
+                double sf = (e < -900) ? 0.0 : ldexp(1.0, (int)e);
+                cplx Gn = 0, Gs = 0, Ge = 0, Go = 0;
+                if (!synth) {
+                    Gn = ph[(size_t)(rp - 1) * nm + m];
+                    Gs = has_south ? ph[(size_t)(4 * nside - rp - 1) * nm + m] : 0;
+                    Ge = Gn + Gs; Go = Gn - Gs; /* parity-even / parity-odd ring combinations */
+                }
+                cplx Fe = 0, Fo = 0;
+                for (int l = m;; ++l) {
+                    if (sf != 0.0) {
+                        double lam = lc * sf;
+                        if (synth) { if ((l - m) & 1) Fo += a[l] * lam; else Fe += a[l] * lam; }
+                        else       { a[l] += (((l - m) & 1) ? Go : Ge) * lam; }
+                    }
+                    if (l == lmax) break;
+                    double ln = (x * lc - epsv[l] * lp) * ieps[l + 1];
+                    lp = lc; lc = ln;
+                    if (fabs(lc) > RESCALE_BIG) {
+                        lc *= RESCALE_INV; lp *= RESCALE_INV; e += 300;
+                        sf = (e < -900) ? 0.0 : ldexp(1.0, (int)e);
+                    }
+                }
+                if (synth) {
+                    ph[(size_t)(rp - 1) * nm + m] = Fe + Fo;
+                    if (has_south) ph[(size_t)(4 * nside - rp - 1) * nm + m] = Fe - Fo;
+                }
+            }
+            if (!synth) {
+                if (m == 0) for (int l = 0; l <= lmax; ++l) alm[base + l] = creal(a[l]);
+                else for (int l = m; l <= lmax; ++l) {
+                    alm[base + 2 * (l - m)] = creal(a[l]) * mfac;
+                    alm[base + 2 * (l - m) + 1] = cimag(a[l]) * mfac;
+                }
+            }
+        }
+        free(ieps); free(epsv); free(a);
+    }
+
+    /* ---------------- synthesis: phases -> pixels (per ring) */
+    if (synth) {
+#pragma omp parallel
+        {
+            cplx* x = (cplx*)malloc(sizeof(cplx) * 4 * nside);
+            cplx* y = (cplx*)malloc(sizeof(cplx) * 4 * nside);
+            cplx* work = (cplx*)malloc(sizeof(cplx) * 16 * nside);
+            double* ct = (double*)malloc(sizeof(double) * 4 * nside);
+            double* st = (double*)malloc(sizeof(double) * 4 * nside);
+#pragma omp for schedule(dynamic, 4)
+            for (int r = 1; r <= nring; ++r) {
+                const ringinfo R = ri[r];
+                const int n = R.nphi;
+                const int northring = r > 2 * nside ? 4 * nside - r : r;
+                double wgt = 1.0;
+                if (weighted) wgt = (wring ? wring[northring - 1] : 1.0) * 4.0 * PI / (double)npix;
+                double* pm = map + R.start;
+                const cplx* in = ph + (size_t)(r - 1) * nm;
+                if (fft_mode) {
+                    for (int k = 0; k < n; ++k) x[k] = 0;
+                    for (int m = 0; m <= mmax; ++m) {
+                        double ang = (double)m * R.phi0;
+                        x[m % n] += in[m] * (cos(ang) + I * sin(ang));
+                    }
+                    fft_any(&plans[n / 4], x, y, work, +1);
+                    for (int k = 0; k < n; ++k) pm[k] = creal(y[k]) * wgt;
+                } else {
+                    for (int j = 0; j < n; ++j) { ct[j] = cos(TWOPI * j / n); st[j] = sin(TWOPI * j / n); }
+                    for (int k = 0; k < n; ++k) pm[k] = 0;
+                    for (int m = 0; m <= mmax; ++m) {
+                        double ang = (double)m * R.phi0;
+                        cplx g = in[m] * (cos(ang) + I * sin(ang));
+                        double gr = creal(g), gi = cimag(g);
+                        int64_t idx = 0, step = m % n;
+                        for (int k = 0; k < n; ++k) {
+                            pm[k] += gr * ct[idx] - gi * st[idx];
+                            idx += step; if (idx >= n) idx -= n;
+                        }
+                    }
+                    if (wgt != 1.0) for (int k = 0; k < n; ++k) pm[k] *= wgt;
+                }
+            }
+            free(x); free(y); free(work); free(ct); free(st);
+        }
+    }
+    if (plans) { for (int i = 1; i <= nside; ++i) plan_free(&plans[i]); free(plans); }
+    free(logpref); free(ri); free(ph);
+    return 0;
+}
+
+/*
+ * Harmonic-space diagonal of Y^T N^-1 Y as Commander's compute_invN_lm defines it
+ * (commander3/src/comm_N_mod.f90:127-197):
+ *   N_lm = (-1)^m (2l+1)/sqrt(4pi) * Npix/4pi * sum_{l'<=lmax} a_l'0 sqrt(2l'+1) (l l l'; -m m 0)(l l l'; 0 0 0)
+ * with a_l'0 the m=0 coefficients of YtW(siN^2) (":134 call invN_diag%YtW_scalar").  By the Gaunt integral
+ * this equals  Npix/4pi * Int |Y_lm|^2 g dOmega  with  g(theta) = sum_{l'<=lmax} a_l'0 Y_l'0(theta),  which is
+ * evaluated here exactly by Gauss-Legendre quadrature (integrand is a polynomial of degree <= 3*lmax in cos theta).
+ * oracle/wigner.py evaluates the 3j form literally for small lmax and tests/ pin the two against each other.
+ *   al0 : [lmax+1] the a_l0 of YtW(siN^2);  out : real-packed (lmax+1)^2, both (+m,-m) slots get the same value
+ */
+static void gauss_legendre(int n, double* x, double* w) {
+    for (int i = 0; i < (n + 1) / 2; ++i) {
+        double z = cos(PI * (i + 0.75) / (n + 0.5)), pp = 0;
+        for (int it = 0; it < 100; ++it) {
+            double p1 = 1.0, p2 = 0.0;
+            for (int j = 1; j <= n; ++j) { double p3 = p2; p2 = p1; p1 = ((2.0 * j - 1.0) * z * p2 - (j - 1.0) * p3) / j; }
+            pp = n * (z * p1 - p2) / (z * z - 1.0);
+            double z1 = z; z = z1 - p1 / pp;
+            if (fabs(z - z1) < 1e-16) break;
+        }
+        x[i] = z; x[n - 1 - i] = -z;
+        w[i] = w[n - 1 - i] = 2.0 / ((1.0 - z * z) * pp * pp);
+    }
+}
+
+int orc_invn_diag(int nside, int lmax, const double* al0, double* out, int nthreads) {
+#ifdef _OPENMP
+    if (nthreads > 0) omp_set_num_threads(nthreads);
+#endif
+    (void)nthreads;
+    const int ng = (3 * lmax) / 2 + 2;
+    const double npix = 12.0 * nside * nside;
+    double* gx = (double*)malloc(sizeof(double) * ng);
+    double* gw = (double*)malloc(sizeof(double) * ng);
+    double* g = (double*)malloc(sizeof(double) * ng);
+    gauss_legendre(ng, gx, gw);
+    /* g(theta_k) = sum_l' a_l'0 Y_l'0 */
+    for (int k = 0; k < ng; ++k) {
+        double x = gx[k], lp = 0.0, lc = sqrt(1.0 / (4.0 * PI)), s = 0;
+        for (int l = 0;; ++l) {
+            s += al0[l] * lc;
+            if (l == lmax) break;
+            double ln = (x * lc - eps_lm(l, 0) * lp) / eps_lm(l + 1, 0);
+            lp = lc; lc = ln;
+        }
+        g[k] = s;
+    }
+    double* logpref = (double*)malloc(sizeof(double) * (lmax + 1));
+    logpref[0] = -0.5 * log(4.0 * PI);
+    for (int m = 1; m <= lmax; ++m) logpref[m] = logpref[m - 1] + 0.5 * log((2.0 * m + 1.0) / (2.0 * m));
+#pragma omp parallel
+    {
+        double* acc = (double*)malloc(sizeof(double) * (lmax + 1));
+        double* epsv = (double*)malloc(sizeof(double) * (lmax + 2));
+#pragma omp for schedule(dynamic, 1)
+        for (int m = 0; m <= lmax; ++m) {
+            for (int l = m; l <= lmax + 1; ++l) epsv[l] = eps_lm(l, m);
+            for (int l = m; l <= lmax; ++l) acc[l] = 0;
+            for (int k = 0; k < ng; ++k) {
+                double x = gx[k], sth = sqrt((1.0 - x) * (1.0 + x));
+                double l2 = (logpref[m] + (m > 0 ? (double)m * log(sth) : 0.0)) / M_LN2;
+                double fl = floor(l2);
+                long e = (long)fl;
+                double lc = exp2(l2 - fl), lp = 0.0;
+                double sf = (e < -900) ? 0.0 : ldexp(1.0, (int)e);
+                double wk = gw[k] * g[k] * TWOPI * npix / (4.0 * PI);
+                for (int l = m;; ++l) {
+                    if (sf != 0.0) { double lam = lc * sf; acc[l] += wk * lam * lam; }
+                    if (l == lmax) break;
+                    double ln = (x * lc - epsv[l] * lp) / epsv[l + 1];
+                    lp = lc; lc = ln;
+                    if (fabs(lc) > RESCALE_BIG) {
+                        lc *= RESCALE_INV; lp *= RESCALE_INV; e += 300;
+                        sf = (e < -900) ? 0.0 : ldexp(1.0, (int)e);
+                    }
+                }
+            }
+            int64_t base = mind(lmax, m);
+            if (m == 0) for (int l = 0; l <= lmax; ++l) out[base + l] = acc[l];
+            else for (int l = m; l <= lmax; ++l) { out[base + 2 * (l - m)] = acc[l]; out[base + 2 * (l - m) + 1] = acc[l]; }
+        }
+        free(acc); free(epsv);
+    }
+    free(logpref); free(gx); free(gw); free(g);
+    return 0;
+}
