@@ -1,0 +1,8 @@
+"""commander_amd -- MI355X-native Gibbs amplitude-sampling path for Commander3.
+
+The product is ``libcmdr_hip.so`` (hand-written gfx950 HIP kernels behind the C ABI of ``include/cmdr_hip.h``);
+this package is the thin Python host mirror used by the tests and ``bench.py``.  There is no CPU fallback: every
+compute call raises ``CmdrError`` when the HIP library or a GPU is missing.
+"""
+from .lib import CmdrError, lib, build_library, device_count  # noqa: F401
+from .sht import ShtPlan, JOB_Y, JOB_Yt, JOB_YtW, JOB_WY  # noqa: F401

@@ -1,0 +1,281 @@
+// Host-side SHT plan tables (no HIP calls here; also compiled into the host-emulation test library).
+#include "plan_tables.hpp"
+
+#include <algorithm>
+#include <cmath>
+#include <complex>
+#include <map>
+
+#include "common_host.hpp"
+
+namespace cmdr {
+
+static inline double eps_lm(int l, int m) {
+    const double dl = (double)l, dm = (double)m;
+    return std::sqrt((dl * dl - dm * dm) / (4.0 * dl * dl - 1.0));
+}
+
+// |mu| must reach 2^kStartExp before a (m, pair) column is switched on; everything below is dropped (1e-84).
+static constexpr int kStartExp = -280;
+
+void LegendreTables::build(int lmax_, const std::vector<double>& x_, const std::vector<double>& sth_, int R_,
+                           int nthreads) {
+    lmax = lmax_;
+    npair = (int)x_.size();
+    R = R_;
+    const int per = kWave * R;
+    nchunk = (npair + per - 1) / per;
+    npair_pad = nchunk * per;
+    x.assign(npair_pad, 0.0);
+    sth.assign(npair_pad, 1.0);
+    mlim.assign(npair_pad, -1);
+    for (int p = 0; p < npair; ++p) {
+        x[p] = x_[p];
+        sth[p] = sth_[p];
+        mlim[p] = mlim_spin0(lmax, sth_[p]);
+    }
+    const int nm = lmax + 1;
+    alpha.assign(ntrip(lmax), 0.0);
+    cnorm.assign(ntrip(lmax), 0.0);
+    ls.assign((size_t)nm * npair_pad, kLsNever);
+    seedc.assign((size_t)nm * npair_pad, 0.0);
+    seedp.assign((size_t)nm * npair_pad, 0.0);
+
+    std::vector<double> logpref(nm);
+    logpref[0] = -0.5 * std::log(4.0 * kPi);
+    for (int m = 1; m <= lmax; ++m) logpref[m] = logpref[m - 1] + 0.5 * std::log((2.0 * m + 1.0) / (2.0 * m));
+
+    std::vector<std::vector<WaveTask>> tasks_m(nm);
+    host_parallel_for(nm, [&](int mi) {
+        // interleave long and short columns for balance
+        const int m = (mi & 1) ? lmax - mi / 2 : mi / 2;
+        const int64_t mo = moffp(lmax, m);
+        double* al = alpha.data() + mo - m;   // al[l], l = m..lmax+1
+        double* cn = cnorm.data() + mo - m;
+        // lambda_l = c_l mu_l ; mu_l = alpha_l x mu_{l-1} - mu_{l-2}
+        cn[m] = 1.0;
+        al[m] = 0.0;
+        double c2 = 1.0, c1 = 1.0;  // c_{l-2}, c_{l-1}
+        if (m + 1 <= lmax + 1) {
+            al[m + 1] = 1.0 / eps_lm(m + 1, m);
+            cn[m + 1] = 1.0;
+        }
+        for (int l = m + 2; l <= lmax + 1; ++l) {
+            const double el = eps_lm(l, m), el1 = eps_lm(l - 1, m);
+            const double c = c2 * el1 / el;
+            al[l] = c1 / (el * c);
+            cn[l] = c;
+            c2 = c1;
+            c1 = c;
+        }
+        cn[lmax + 1] = 0.0;  // pad entry carries no signal
+        int* lsm = ls.data() + (size_t)m * npair_pad;
+        double* scm = seedc.data() + (size_t)m * npair_pad;
+        double* spm = seedp.data() + (size_t)m * npair_pad;
+        for (int p = 0; p < npair; ++p) {
+            if (m > mlim[p]) continue;
+            const double xx = x[p];
+            const double l2 = (logpref[m] + (m > 0 ? (double)m * std::log(sth[p]) : 0.0)) / M_LN2;
+            const double fl = std::floor(l2);
+            long e = (long)fl;
+            double lc = std::exp2(l2 - fl), lp = 0.0;
+            if (m & 1) lc = -lc;
+            int l = m;
+            for (;;) {
+                int ex;
+                (void)std::frexp(std::max(std::fabs(lc), std::fabs(lp)), &ex);
+                if (e + ex >= kStartExp) {
+                    lsm[p] = l;
+                    scm[p] = std::ldexp(lc, (int)e);
+                    spm[p] = std::ldexp(lp, (int)e);
+                    break;
+                }
+                if (l == lmax) break;
+                const double ln = al[l + 1] * xx * lc - lp;
+                lp = lc;
+                lc = ln;
+                ++l;
+                if (std::fabs(lc) > 0x1p+300) {
+                    lc *= 0x1p-300;
+                    lp *= 0x1p-300;
+                    e += 300;
+                }
+            }
+        }
+        for (int ch = 0; ch < nchunk; ++ch) {
+            int lo = kLsNever, hi = -1;
+            for (int p = ch * per; p < (ch + 1) * per; ++p) {
+                const int v = lsm[p];
+                if (v == kLsNever) continue;
+                lo = std::min(lo, v);
+                hi = std::max(hi, v);
+            }
+            if (hi < 0) continue;
+            WaveTask t;
+            t.m = m;
+            t.chunk = ch;
+            t.lw = lo - ((lo - m) & 1);
+            int a = hi + 1;
+            a += (a - m) & 1;
+            t.lAend = a;
+            tasks_m[m].push_back(t);
+        }
+    }, nthreads);
+    tasks.clear();
+    for (int m = 0; m < nm; ++m) tasks.insert(tasks.end(), tasks_m[m].begin(), tasks_m[m].end());
+    // longest first == smallest lw first (all columns end at lmax)
+    std::stable_sort(tasks.begin(), tasks.end(), [](const WaveTask& a, const WaveTask& b) { return a.lw < b.lw; });
+}
+
+static int bitrev(int v, int bits) {
+    int r = 0;
+    for (int i = 0; i < bits; ++i) { r = (r << 1) | (v & 1); v >>= 1; }
+    return r;
+}
+
+static void host_fft_pow2(std::vector<std::complex<double>>& a, int sign) {
+    const int n = (int)a.size();
+    for (int i = 1, j = 0; i < n; ++i) {
+        int bit = n >> 1;
+        for (; j & bit; bit >>= 1) j ^= bit;
+        j ^= bit;
+        if (i < j) std::swap(a[i], a[j]);
+    }
+    for (int len = 2; len <= n; len <<= 1) {
+        const int half = len >> 1;
+        for (int k = 0; k < half; ++k) {
+            const double ang = sign * 2.0 * kPi * (double)k / (double)len;
+            const std::complex<double> w(std::cos(ang), std::sin(ang));
+            for (int i = k; i < n; i += len) {
+                const auto u = a[i], v = a[i + half] * w;
+                a[i] = u + v;
+                a[i + half] = u - v;
+            }
+        }
+    }
+}
+
+void RingTables::build(int nside_, int lmax_, const std::vector<int>& rings, const double* wring,
+                       const std::vector<int>& mlim) {
+    nside = nside_;
+    lmax = lmax_;
+    npair = (int)rings.size();
+    pairs.assign(npair, RingPairDesc{});
+    const double npix_full = 12.0 * nside * (double)nside;
+    // local map = owned rings in ascending ring order: northern members ascending, then southern ascending
+    int64_t off = 0;
+    for (int p = 0; p < npair; ++p) {
+        const RingInfo r = healpix_ring(nside, rings[p]);
+        pairs[p].startN = off;
+        off += r.nphi;
+    }
+    for (int p = npair - 1; p >= 0; --p) {
+        if (rings[p] == 2 * nside) { pairs[p].startS = -1; continue; }
+        const RingInfo r = healpix_ring(nside, rings[p]);
+        pairs[p].startS = off;
+        off += r.nphi;
+    }
+    npix_local = off;
+    log2Mmax = 1;
+    std::map<int, int64_t> chirp_of;  // nphi -> offset (in complex units)
+    chirp.clear();
+    for (int p = 0; p < npair; ++p) {
+        const RingInfo r = healpix_ring(nside, rings[p]);
+        RingPairDesc& d = pairs[p];
+        d.ring = rings[p];
+        d.nphi = r.nphi;
+        d.phi0 = r.phi0;
+        d.mmax_eff = std::min(mlim[p], lmax);
+        d.wgt = (wring ? wring[rings[p] - 1] : 1.0) * 4.0 * kPi / npix_full;
+        const int n = r.nphi;
+        if ((n & (n - 1)) == 0) {
+            d.bluestein = 0;
+            int lg = 0;
+            while ((1 << lg) < n) ++lg;
+            d.log2M = lg;
+            d.chirp_off = -1;
+        } else {
+            d.bluestein = 1;
+            int lg = 0;
+            while ((1 << lg) < 2 * n - 1) ++lg;
+            d.log2M = lg;
+            auto it = chirp_of.find(n);
+            if (it == chirp_of.end()) {
+                const int M = 1 << lg;
+                const int64_t o = (int64_t)chirp.size() / 2;
+                chirp_of[n] = o;
+                std::vector<std::complex<double>> w(n), c(M, 0.0);
+                for (int j = 0; j < n; ++j) {
+                    const int64_t q = ((int64_t)j * j) % (2 * (int64_t)n);
+                    const double ang = kPi * (double)q / (double)n;
+                    w[j] = {std::cos(ang), std::sin(ang)};
+                }
+                c[0] = std::conj(w[0]);
+                for (int j = 1; j < n; ++j) { c[j] = std::conj(w[j]); c[M - j] = std::conj(w[j]); }
+                host_fft_pow2(c, -1);
+                for (int j = 0; j < n; ++j) { chirp.push_back(w[j].real()); chirp.push_back(w[j].imag()); }
+                for (int q = 0; q < M; ++q) {
+                    const auto v = c[bitrev(q, lg)];
+                    chirp.push_back(v.real());
+                    chirp.push_back(v.imag());
+                }
+                d.chirp_off = o;
+            } else {
+                d.chirp_off = it->second;
+            }
+        }
+        log2Mmax = std::max(log2Mmax, d.log2M);
+    }
+    classes.assign(log2Mmax + 1, {});
+    for (int p = 0; p < npair; ++p) classes[pairs[p].log2M].push_back(p);
+    const int Mmax = 1 << log2Mmax;
+    twiddle.resize(Mmax);  // Mmax/2 complex
+    for (int k = 0; k < Mmax / 2; ++k) {
+        const double ang = 2.0 * kPi * (double)k / (double)Mmax;
+        twiddle[2 * k] = std::cos(ang);
+        twiddle[2 * k + 1] = std::sin(ang);
+    }
+}
+
+void ShtTables::build(int nside_, int lmax_, const std::vector<int>& rings_in, const double* wring, int nthreads) {
+    nside = nside_;
+    lmax = lmax_;
+    std::vector<int> rings = rings_in;
+    if (rings.empty()) for (int i = 1; i <= 2 * nside; ++i) rings.push_back(i);
+    std::sort(rings.begin(), rings.end());
+    std::vector<double> x(rings.size()), sth(rings.size());
+    for (size_t p = 0; p < rings.size(); ++p) {
+        const RingInfo r = healpix_ring(nside, rings[p]);
+        x[p] = r.z;
+        sth[p] = r.sth;
+    }
+    const int np = (int)rings.size();
+    const int R = np >= 1024 ? 4 : (np >= 256 ? 2 : 1);
+    leg.build(lmax, x, sth, R, nthreads);
+    ring.build(nside, lmax, rings, wring, leg.mlim);
+}
+
+void gauss_legendre(int n, std::vector<double>& x, std::vector<double>& w) {
+    x.assign(n, 0.0);
+    w.assign(n, 0.0);
+    for (int i = 0; i < (n + 1) / 2; ++i) {
+        double z = std::cos(kPi * (i + 0.75) / (n + 0.5)), pp = 0;
+        for (int it = 0; it < 100; ++it) {
+            double p1 = 1.0, p2 = 0.0;
+            for (int j = 1; j <= n; ++j) {
+                const double p3 = p2;
+                p2 = p1;
+                p1 = ((2.0 * j - 1.0) * z * p2 - (j - 1.0) * p3) / j;
+            }
+            pp = n * (z * p1 - p2) / (z * z - 1.0);
+            const double z1 = z;
+            z = z1 - p1 / pp;
+            if (std::fabs(z - z1) < 1e-16) break;
+        }
+        x[i] = z;
+        x[n - 1 - i] = -z;
+        w[i] = w[n - 1 - i] = 2.0 / ((1.0 - z * z) * pp * pp);
+    }
+}
+
+}  // namespace cmdr

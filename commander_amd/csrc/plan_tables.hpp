@@ -1,0 +1,75 @@
+// Host-side (HIP-free) tables of an SHT plan: Legendre recursion coefficients, per-(m, ring-pair) start seeds,
+// wave task list, ring/FFT descriptors and Bluestein chirps.  Built once per (nside, lmax, ring subset).
+//
+// Replaces the libsharp2 info objects Commander creates in commander3/src/comm_map_mod.f90:264-283
+// (sharp_make_mmajor_real_packed_alm_info / sharp_make_healpix_geom_info).
+#pragma once
+#include <cstdint>
+#include <vector>
+
+#include "geom.hpp"
+
+namespace cmdr {
+
+constexpr int kWave = 64;
+constexpr int kLsNever = 0x3fffffff;  // "this (m, pair) never starts"
+constexpr int kAdjL = 8;              // l per transpose-reduce group in the adjoint Legendre kernel
+
+// Padded triangle: column m holds l = m..lmax+1 (one zero pad entry), so kernels may run l in (even, odd) pairs.
+inline int64_t moffp(int lmax, int m) { return (int64_t)m * (lmax + 2) - (int64_t)m * (m - 1) / 2; }
+inline int64_t ntrip(int lmax) { return moffp(lmax, lmax + 1) + 16; }  // + slack for look-ahead reads
+
+struct WaveTask {  // one wavefront's work item: 64*R colatitude pairs of one m
+    int m, chunk, lw, lAend;
+};
+
+// Legendre stage over north/south-symmetric colatitude pairs (HEALPix ring pairs, or Gauss-Legendre nodes).
+struct LegendreTables {
+    int lmax = -1, npair = 0, R = 1, npair_pad = 0, nchunk = 0;
+    std::vector<double> x, sth;         // [npair_pad] cos/sin(theta) of the northern member (x >= 0)
+    std::vector<int> mlim;              // [npair_pad] largest m with non-negligible lambda (-1 for padding)
+    std::vector<double> alpha;          // [ntrip] mu_l = alpha_l x mu_{l-1} - mu_{l-2}
+    std::vector<double> cnorm;          // [ntrip] lambda_lm = cnorm * mu_l  (pad entries 0)
+    std::vector<int> ls;                // [(lmax+1) * npair_pad] first l with |mu| above threshold
+    std::vector<double> seedc, seedp;   // mu_{ls}, mu_{ls-1}
+    std::vector<WaveTask> tasks;        // sorted by decreasing length
+    void build(int lmax, const std::vector<double>& x, const std::vector<double>& sth, int R, int nthreads = 0);
+};
+
+struct RingPairDesc {   // one north/south ring pair (or the equator alone: startS = -1)
+    int nphi;           // pixels per ring
+    int log2M;          // FFT size class: nphi if power of two, else Bluestein M >= 2 nphi - 1
+    int bluestein;      // 0/1
+    int mmax_eff;       // = mlim of the pair
+    int64_t startN, startS;  // offsets of the two rings in the *local* map (startS = -1: no southern ring)
+    double phi0;
+    double wgt;         // analysis weight W_ring * 4 pi / Npix
+    int64_t chirp_off;  // offset into chirp table (Bluestein only)
+    int ring;           // northern ring number 1..2*nside
+};
+
+struct RingTables {
+    int nside = 0, lmax = -1, npair = 0;
+    int64_t npix_local = 0;
+    std::vector<RingPairDesc> pairs;          // [npair]
+    std::vector<std::vector<int>> classes;    // classes[log2M] = pair indices
+    int log2Mmax = 0;
+    std::vector<double> twiddle;              // [2 * Mmax/2]  exp(2 pi i k / Mmax), k < Mmax/2 (re,im)
+    // Bluestein tables, per distinct nphi: w_j = exp(i pi j^2 / n) (j<n), then chat in bit-reversed order (M)
+    std::vector<double> chirp;                // (re,im) pairs
+    void build(int nside, int lmax, const std::vector<int>& rings /*northern ring numbers, ascending*/,
+               const double* wring /*[2*nside] or nullptr*/, const std::vector<int>& mlim);
+};
+
+struct ShtTables {
+    int nside = 0, lmax = -1;
+    LegendreTables leg;
+    RingTables ring;
+    // rings: northern ring numbers (1..2*nside) this plan owns; empty = all (single GPU)
+    void build(int nside, int lmax, const std::vector<int>& rings, const double* wring, int nthreads = 0);
+};
+
+// Gauss-Legendre nodes/weights on (-1,1), descending x (north first).
+void gauss_legendre(int n, std::vector<double>& x, std::vector<double>& w);
+
+}  // namespace cmdr

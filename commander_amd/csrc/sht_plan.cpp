@@ -1,0 +1,119 @@
+#include "sht_plan.hpp"
+
+namespace cmdr {
+
+void LegendreDev::upload(const LegendreTables& T) {
+    lmax = T.lmax;
+    npair_pad = T.npair_pad;
+    R = T.R;
+    nchunk = T.nchunk;
+    ntasks = (int)T.tasks.size();
+    x.upload(T.x);
+    ls.upload(T.ls);
+    seedc.upload(T.seedc);
+    seedp.upload(T.seedp);
+    alpha.upload(T.alpha);
+    cnorm.upload(T.cnorm);
+    tasks.upload(T.tasks);
+}
+
+LegArgs LegendreDev::args() const {
+    LegArgs A;
+    A.lmax = lmax;
+    A.npair_pad = npair_pad;
+    A.R = R;
+    A.x = x.get();
+    A.ls = ls.get();
+    A.seedc = seedc.get();
+    A.seedp = seedp.get();
+    A.alpha = alpha.get();
+    return A;
+}
+
+ShtPlan::ShtPlan(int nside, int lmax, const std::vector<int>& rings, const double* wring, int max_maps)
+    : max_maps_(max_maps) {
+    CMDR_REQUIRE(nside >= 1 && (nside & (nside - 1)) == 0, "nside must be a power of two");
+    CMDR_REQUIRE(lmax >= 0, "lmax must be >= 0");
+    CMDR_REQUIRE(max_maps >= 1, "max_maps must be >= 1");
+    T_.build(nside, lmax, rings, wring);
+    CMDR_REQUIRE(T_.ring.log2Mmax <= 13, "ring FFT larger than 8192 points (nside > 1024) is not supported yet");
+    leg_.upload(T_.leg);
+    std::vector<RingDev> rd(T_.ring.npair);
+    for (int p = 0; p < T_.ring.npair; ++p) {
+        const RingPairDesc& d = T_.ring.pairs[p];
+        RingDev& r = rd[p];
+        r.nphi = d.nphi;
+        r.log2M = d.log2M;
+        r.bluestein = d.bluestein;
+        r.mmax_eff = d.mmax_eff;
+        r.startN = d.startN;
+        r.startS = d.startS;
+        r.phi0 = d.phi0;
+        r.wgt = d.wgt;
+        r.chirp_off = d.chirp_off;
+        r.ring = d.ring;
+        r.pad = 0;
+    }
+    rings_.upload(rd);
+    cls_.resize(T_.ring.classes.size());
+    ncls_.resize(T_.ring.classes.size());
+    for (size_t c = 0; c < T_.ring.classes.size(); ++c) {
+        ncls_[c] = (int)T_.ring.classes[c].size();
+        if (ncls_[c]) cls_[c].upload(T_.ring.classes[c]);
+    }
+    tw_.upload(T_.ring.twiddle);
+    if (!T_.ring.chirp.empty()) chirp_.upload(T_.ring.chirp);
+    ast_.alloc((size_t)max_maps * leg_.tri_elems());
+    ph_.alloc((size_t)max_maps * leg_.ph_elems());
+    part_.alloc((size_t)max_maps * part_map_stride());
+    // never-written entries ((m, pair) beyond mlim, l below a task's start) must read as zero forever
+    ast_.zero();
+    ph_.zero();
+    part_.zero();
+    CMDR_HIP_CHECK(hipDeviceSynchronize());
+}
+
+void ShtPlan::synth_from_stream(int nmaps, hipStream_t s) {
+    launch_leg_synth(leg_.args(), leg_.tasks.get(), leg_.ntasks, ast_.get(), leg_.tri_elems(), ph_.get(),
+                     leg_.ph_elems(), nmaps, s);
+}
+
+void ShtPlan::rings(int mode, double* d_map, int64_t map_stride, const double* const* d_mul, bool weighted,
+                    int nmaps, hipStream_t s) {
+    for (size_t c = 0; c < cls_.size(); ++c) {
+        if (!ncls_[c]) continue;
+        launch_ring(mode, rings_.get(), cls_[c].get(), ncls_[c], (int)c, ph_.get(), leg_.ph_elems(),
+                    leg_.npair_pad, d_map, map_stride, d_mul, weighted ? 1 : 0,
+                    reinterpret_cast<const cd*>(tw_.get()), T_.ring.log2Mmax,
+                    reinterpret_cast<const cd*>(chirp_.get()), nmaps, s);
+    }
+}
+
+void ShtPlan::adjoint_to_partials(int nmaps, bool square, hipStream_t s) {
+    launch_leg_adj(leg_.args(), leg_.tasks.get(), leg_.ntasks, ph_.get(), leg_.ph_elems(), part_.get(),
+                   part_map_stride(), leg_.tri_elems(), nmaps, square, s);
+}
+
+void ShtPlan::alm2map(const double* d_alm, int64_t alm_stride, double* d_map, int64_t map_stride, int nmaps,
+                      bool weighted, hipStream_t s) {
+    for (int i0 = 0; i0 < nmaps; i0 += max_maps_) {
+        const int nb = std::min(max_maps_, nmaps - i0);
+        launch_alm_to_stream(d_alm + i0 * alm_stride, alm_stride, ast_.get(), leg_.tri_elems(), leg_.cnorm.get(),
+                             T_.lmax, nb, s);
+        synth_from_stream(nb, s);
+        rings(0, d_map + i0 * map_stride, map_stride, nullptr, weighted, nb, s);
+    }
+}
+
+void ShtPlan::map2alm(const double* d_map, int64_t map_stride, double* d_alm, int64_t alm_stride, int nmaps,
+                      bool weighted, hipStream_t s) {
+    for (int i0 = 0; i0 < nmaps; i0 += max_maps_) {
+        const int nb = std::min(max_maps_, nmaps - i0);
+        rings(1, const_cast<double*>(d_map) + i0 * map_stride, map_stride, nullptr, weighted, nb, s);
+        adjoint_to_partials(nb, false, s);
+        launch_part_to_alm(part_.get(), part_map_stride(), leg_.tri_elems(), leg_.nchunk, d_alm + i0 * alm_stride,
+                           alm_stride, leg_.cnorm.get(), T_.lmax, nb, s);
+    }
+}
+
+}  // namespace cmdr

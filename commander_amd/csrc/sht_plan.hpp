@@ -1,0 +1,65 @@
+// Device-resident SHT plan: uploads ShtTables and owns the per-plan workspaces (coefficient streams, phases,
+// adjoint partial columns).  One plan per distinct (nside, lmax, ring subset); Commander keeps the equivalent
+// libsharp handles in its comm_mapinfo cache (commander3/src/comm_map_mod.f90:126-127,157-169).
+#pragma once
+#include <memory>
+#include <vector>
+
+#include "common.hpp"
+#include "kernels.hpp"
+#include "plan_tables.hpp"
+
+namespace cmdr {
+
+class LegendreDev {  // device mirror of LegendreTables
+  public:
+    void upload(const LegendreTables& T);
+    LegArgs args() const;
+    int lmax = -1, npair_pad = 0, R = 1, nchunk = 0, ntasks = 0;
+    DevBuf<double> x, seedc, seedp, alpha, cnorm;
+    DevBuf<int> ls;
+    DevBuf<WaveTask> tasks;
+    int64_t ph_elems() const { return (int64_t)(lmax + 1) * npair_pad * 4; }       // doubles per map
+    int64_t tri_elems() const { return 2 * ntrip(lmax); }                          // doubles per map
+};
+
+class ShtPlan {
+  public:
+    ShtPlan(int nside, int lmax, const std::vector<int>& rings, const double* wring, int max_maps);
+    int nside() const { return T_.nside; }
+    int lmax() const { return T_.lmax; }
+    int64_t npix_local() const { return T_.ring.npix_local; }
+    int64_t nalm() const { return nalm_packed(T_.lmax); }
+    int max_maps() const { return max_maps_; }
+    const ShtTables& tables() const { return T_; }
+
+    // Commander entry points (comm_map_mod.f90:437-579), device pointers, column-major [n][nmaps] with the given
+    // column strides.  weighted=false: Y / Yt ; weighted=true: WY / YtW.
+    void alm2map(const double* d_alm, int64_t alm_stride, double* d_map, int64_t map_stride, int nmaps,
+                 bool weighted, hipStream_t s);
+    void map2alm(const double* d_map, int64_t map_stride, double* d_alm, int64_t alm_stride, int nmaps,
+                 bool weighted, hipStream_t s);
+
+    // Building blocks used by the fused CR matvec.
+    double* stream() { return ast_.get(); }                // [max_maps][tri_elems]
+    double* phases() { return ph_.get(); }                 // [max_maps][ph_elems]
+    double* partials() { return part_.get(); }             // [max_maps][nchunk][tri_elems]
+    int64_t part_map_stride() const { return (int64_t)leg_.nchunk * leg_.tri_elems(); }
+    void synth_from_stream(int nmaps, hipStream_t s);                                // stream -> phases
+    void rings(int mode, double* d_map, int64_t map_stride, const double* const* d_mul, bool weighted, int nmaps,
+               hipStream_t s);                                                       // see launch_ring
+    void adjoint_to_partials(int nmaps, bool square, hipStream_t s);                 // phases -> partials
+    const LegendreDev& leg() const { return leg_; }
+
+  private:
+    ShtTables T_;
+    LegendreDev leg_;
+    int max_maps_;
+    DevBuf<RingDev> rings_;
+    std::vector<DevBuf<int>> cls_;
+    std::vector<int> ncls_;
+    DevBuf<double> tw_, chirp_;
+    DevBuf<double> ast_, ph_, part_;
+};
+
+}  // namespace cmdr

@@ -1,0 +1,65 @@
+"""ctypes loader of libcmdr_hip.so (the C ABI in include/cmdr_hip.h)."""
+import ctypes
+import os
+import subprocess
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_SO = os.path.join(_HERE, "libcmdr_hip.so")
+_LIB = None
+
+
+class CmdrError(RuntimeError):
+    pass
+
+
+def build_library(force=False):
+    """Compile every HIP source for gfx950 (hipcc cross-compiles without a GPU)."""
+    args = ["make", "-C", os.path.join(_HERE, "csrc"), "-j8"]
+    if force:
+        args.append("-B")
+    subprocess.check_call(args, stdout=subprocess.DEVNULL)
+    return _SO
+
+
+def _sig(L):
+    c_int, c_i64, c_sz, c_vp = ctypes.c_int, ctypes.c_int64, ctypes.c_size_t, ctypes.c_void_p
+    dp = ctypes.POINTER(ctypes.c_double)
+    ip = ctypes.POINTER(ctypes.c_int)
+    pdp = ctypes.POINTER(dp)
+    L.cmdr_last_error.restype = ctypes.c_char_p
+    L.cmdr_device_count.restype = c_int
+    L.cmdr_set_device.argtypes = [c_int]
+    L.cmdr_dev_alloc.argtypes = [c_sz, ctypes.POINTER(c_vp)]
+    L.cmdr_dev_free.argtypes = [c_vp]
+    L.cmdr_memcpy_h2d.argtypes = [c_vp, c_vp, c_sz]
+    L.cmdr_memcpy_d2h.argtypes = [c_vp, c_vp, c_sz]
+    L.cmdr_sht_plan_create.argtypes = [c_int, c_int, c_int, ip, dp, c_int, ctypes.POINTER(c_vp)]
+    L.cmdr_sht_plan_destroy.argtypes = [c_vp]
+    L.cmdr_sht_nalm.argtypes = [c_vp]
+    L.cmdr_sht_nalm.restype = c_i64
+    L.cmdr_sht_npix.argtypes = [c_vp]
+    L.cmdr_sht_npix.restype = c_i64
+    L.cmdr_sht_execute.argtypes = [c_vp, c_int, c_int, pdp, pdp]
+    L.cmdr_sht_execute_dev.argtypes = [c_vp, c_int, c_int, c_vp, c_i64, c_vp, c_i64]
+
+
+def lib():
+    """Load the library; raise loudly if it was not built (no silent fallback)."""
+    global _LIB
+    if _LIB is None:
+        if not os.path.exists(_SO):
+            raise CmdrError("libcmdr_hip.so is not built: run `python -c 'import __graft_entry__ as g; g.build()'` "
+                            "(there is no CPU path)")
+        L = ctypes.CDLL(_SO)
+        _sig(L)
+        _LIB = L
+    return _LIB
+
+
+def check(rc):
+    if rc != 0:
+        raise CmdrError(lib().cmdr_last_error().decode())
+
+
+def device_count():
+    return lib().cmdr_device_count()
