@@ -1,0 +1,248 @@
+"""Python host mirror of Commander3's CR module on top of the ``cmdr_*`` C ABI.
+
+Names and argument meaning follow ``commander3/src/comm_cr_mod.f90`` (public list at :36):
+``cr_matmulA``, ``cr_invM``, ``cr_computeRHS``, ``solve_cr_eqn_by_CG``; component / band registration mirrors
+what ``initialize_signal_mod`` / ``initialize_data_mod`` hand to the solver.  Everything numeric runs in
+libcmdr_hip.so; this file only marshals arrays.  No CPU fallback: a missing library or GPU raises ``CmdrError``.
+"""
+import ctypes
+
+import numpy as np
+
+from . import lib as _libmod
+from .lib import CmdrError, check
+
+_dp = ctypes.POINTER(ctypes.c_double)
+_vp = ctypes.c_void_p
+ALLREDUCE_CB = ctypes.CFUNCTYPE(None, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64)
+
+CRIT = {"residual": 0, "fixed_iter": 1}  # cpar%cg_conv_crit (comm_cr_mod.f90:220-229); 'chisq' is not on this path
+
+
+def _f(a):
+    return np.asfortranarray(np.asarray(a, dtype=np.float64))
+
+
+def _p(a):
+    return a.ctypes.data_as(_dp)
+
+
+class DeviceArray:
+    """fp64 buffer in HBM allocated through ``cmdr_dev_alloc`` (so callers can keep vectors resident)."""
+
+    def __init__(self, L, n, src=None):
+        self.L, self.n = L, int(n)
+        p = _vp()
+        check(L.cmdr_dev_alloc(max(self.n, 1) * 8, ctypes.byref(p)), L)
+        self.ptr = p
+        if src is not None:
+            self.upload(src)
+
+    def upload(self, src):
+        a = np.ascontiguousarray(src, dtype=np.float64).reshape(-1)
+        assert a.size == self.n, (a.size, self.n)
+        check(self.L.cmdr_memcpy_h2d(self.ptr, a.ctypes.data_as(_vp), a.nbytes), self.L)
+
+    def download(self):
+        out = np.empty(self.n)
+        check(self.L.cmdr_memcpy_d2h(out.ctypes.data_as(_vp), self.ptr, out.nbytes), self.L)
+        return out
+
+    def free(self):
+        if self.ptr:
+            self.L.cmdr_dev_free(self.ptr)
+            self.ptr = None
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass
+
+
+class CRContext:
+    """One CR linear system on one GPU (``cmdr_ctx``)."""
+
+    def __init__(self, device=0, _lib=None):
+        self.L = _lib if _lib is not None else _libmod.lib()
+        h = _vp()
+        check(self.L.cmdr_ctx_create(int(device), ctypes.byref(h)), self.L)
+        self._h = h
+        self.nband = 0
+        self.ncomp = 0
+        self.band_shape = []  # (npix_local, nmaps)
+        self.band_meta = []   # (nside, lmax)
+        self.ncr = None
+        self._keep = []
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self.L.cmdr_ctx_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # ---- setup ------------------------------------------------------------------------------------------
+    def set_rings(self, nside, rings):
+        r = np.ascontiguousarray(rings, dtype=np.int32)
+        check(self.L.cmdr_ctx_set_rings(self._h, int(nside), r.size, r.ctypes.data_as(ctypes.POINTER(ctypes.c_int))),
+              self.L)
+
+    def set_allreduce(self, fn):
+        """fn(dev_ptr: int, n: int) sums n doubles at device address dev_ptr over all ranks, in place."""
+        def _cb(user, ptr, n):
+            fn(ptr, n)
+        cb = ALLREDUCE_CB(_cb)
+        self._keep.append(cb)
+        check(self.L.cmdr_ctx_set_allreduce(self._h, ctypes.cast(cb, _vp), None), self.L)
+
+    def set_only_pol(self, flag):
+        check(self.L.cmdr_ctx_set_only_pol(self._h, int(bool(flag))), self.L)
+
+    def add_band(self, nside, lmax, siN, b_l, mb_eff=1.0, sg_mask=None, wring=None):
+        """``data(i)``: siN (npix_local[, nmaps]) = 1/rms with 0 in masked pixels; b_l (lmax+1[, nmaps])."""
+        siN = _f(np.asarray(siN, dtype=np.float64).reshape(np.shape(siN)[0], -1))
+        nmaps = siN.shape[1]
+        b_l = _f(np.asarray(b_l, dtype=np.float64).reshape(lmax + 1, -1))
+        assert b_l.shape[1] == nmaps
+        mk = None if sg_mask is None else _f(np.asarray(sg_mask, dtype=np.float64).reshape(siN.shape))
+        w = None if wring is None else np.ascontiguousarray(wring, dtype=np.float64)
+        idx = check(self.L.cmdr_band_add(self._h, int(nside), int(lmax), nmaps, _p(siN), _p(b_l), float(mb_eff),
+                                         None if mk is None else _p(mk), None if w is None else _p(w)), self.L)
+        self.nband += 1
+        self.band_shape.append((siN.shape[0], nmaps))
+        self.band_meta.append((int(nside), int(lmax)))
+        return idx
+
+    def add_comp(self, lmax_amp, nmaps, F_mean, sqrtS_mat=None, sqrtInvS_mat=None, S_mat=None, active=True):
+        """One diffuse component; ``sqrtS_mat is None`` means cltype == 'none'.  F_mean: (numband[, nmaps])."""
+        F = _f(np.asarray(F_mean, dtype=np.float64).reshape(self.nband, -1))
+        assert F.shape[1] == nmaps
+        if sqrtS_mat is None:
+            idx = check(self.L.cmdr_comp_add(self._h, int(lmax_amp), int(nmaps), -1, None, None, None, _p(F),
+                                             int(bool(active))), self.L)
+        else:
+            a, b, c = _f(sqrtS_mat), _f(sqrtInvS_mat), _f(S_mat)
+            lmax_cl = a.shape[2] - 1
+            assert a.shape == b.shape == c.shape == (nmaps, nmaps, lmax_cl + 1)
+            idx = check(self.L.cmdr_comp_add(self._h, int(lmax_amp), int(nmaps), lmax_cl, _p(a), _p(b), _p(c), _p(F),
+                                             int(bool(active))), self.L)
+        self.ncomp += 1
+        return idx
+
+    def finalize(self):
+        check(self.L.cmdr_finalize(self._h), self.L)
+        self.ncr = int(self.L.cmdr_ncr(self._h))
+
+    def band_npix(self, b):
+        return int(self.L.cmdr_band_npix(self._h, b))
+
+    # ---- preconditioner (initPrecond / update_precond: comm_signal_mod.f90:179, comm_cr_mod.f90:76) -------
+    def initPrecond(self):
+        check(self.L.cmdr_precond_init_diag(self._h), self.L)
+
+    def update_precond(self):
+        check(self.L.cmdr_precond_update_diag(self._h), self.L)
+
+    def invN_diag(self, band):
+        """``data(band)%N%invN_diag%alm`` (nalm, nmaps) after initPrecond (comm_N_mod.f90:127-197)."""
+        lmax, nmaps = self.band_meta[band][1], self.band_shape[band][1]
+        out = np.zeros(((lmax + 1) ** 2, nmaps), order="F")
+        check(self.L.cmdr_get_invN_diag(self._h, int(band), _p(out)), self.L)
+        return out
+
+    # ---- operators on host vectors ---------------------------------------------------------------------------
+    def cr_matmulA(self, x):
+        x = np.ascontiguousarray(x, dtype=np.float64)
+        assert x.shape == (self.ncr,)
+        y = np.empty(self.ncr)
+        check(self.L.cmdr_matmulA(self._h, _p(x), _p(y)), self.L)
+        return y
+
+    def cr_invM(self, x):
+        x = np.ascontiguousarray(x, dtype=np.float64)
+        assert x.shape == (self.ncr,)
+        y = np.empty(self.ncr)
+        check(self.L.cmdr_invM(self._h, _p(x), _p(y)), self.L)
+        return y
+
+    def cr_computeRHS(self, operation, resid, xi=None, eta=None, mu=None):
+        """resid[i], xi[i]: (npix_local[, nmaps]) per band; eta, mu: (ncr,)."""
+        sample = operation == "sample"
+        arr = _dp * self.nband
+        keep = []
+
+        def cols(lst):
+            ptrs = []
+            for b, m in enumerate(lst):
+                a = _f(np.asarray(m, dtype=np.float64).reshape(self.band_shape[b]))
+                keep.append(a)
+                ptrs.append(_p(a))
+            return arr(*ptrs)
+        r = cols(resid)
+        x = cols(xi) if sample else None
+        e = np.ascontiguousarray(eta, dtype=np.float64) if sample else None
+        mm = None if mu is None else np.ascontiguousarray(mu, dtype=np.float64)
+        rhs = np.empty(self.ncr)
+        check(self.L.cmdr_compute_rhs(self._h, int(sample), r, x, None if e is None else _p(e),
+                                      None if mm is None else _p(mm), _p(rhs)), self.L)
+        return rhs
+
+    def solve_cr_eqn_by_CG(self, b, conv_crit="fixed_iter", tol=1e-8, miniter=5, maxiter=40, check_freq=1, x0=None):
+        """Returns (x, niter, stat, (delta_new, delta0)); x already multiplied by sqrt(S)."""
+        b = np.ascontiguousarray(b, dtype=np.float64)
+        assert b.shape == (self.ncr,)
+        x = np.empty(self.ncr)
+        x0a = None if x0 is None else np.ascontiguousarray(x0, dtype=np.float64)
+        niter, stat = ctypes.c_int(0), ctypes.c_int(0)
+        res = np.zeros(2)
+        check(self.L.cmdr_solve(self._h, _p(b), _p(x), CRIT[conv_crit], float(tol), int(miniter), int(maxiter),
+                                int(check_freq), None if x0a is None else _p(x0a), ctypes.byref(niter), _p(res),
+                                ctypes.byref(stat)), self.L)
+        return x, niter.value, stat.value, (res[0], res[1])
+
+    # ---- device-resident variants (bench.py) ----------------------------------------------------------------
+    def dev(self, n, src=None):
+        return DeviceArray(self.L, n, src)
+
+    def cr_matmulA_dev(self, x, y):
+        check(self.L.cmdr_matmulA_dev(self._h, x.ptr, y.ptr), self.L)
+
+    def cr_invM_dev(self, x, y):
+        check(self.L.cmdr_invM_dev(self._h, x.ptr, y.ptr), self.L)
+
+    def cr_computeRHS_dev(self, operation, resid, xi, eta, mu, rhs):
+        sample = operation == "sample"
+        arr = _vp * self.nband
+        r = arr(*[a.ptr for a in resid])
+        x = arr(*[a.ptr for a in xi]) if sample else None
+        check(self.L.cmdr_compute_rhs_dev(self._h, int(sample), r, x, eta.ptr if sample else None,
+                                          None if mu is None else mu.ptr, rhs.ptr), self.L)
+
+    def solve_dev(self, b, x, conv_crit="fixed_iter", tol=1e-8, miniter=5, maxiter=40, check_freq=1, x0=None):
+        niter, stat = ctypes.c_int(0), ctypes.c_int(0)
+        res = np.zeros(2)
+        check(self.L.cmdr_solve_dev(self._h, b.ptr, x.ptr, CRIT[conv_crit], float(tol), int(miniter), int(maxiter),
+                                    int(check_freq), None if x0 is None else x0.ptr, ctypes.byref(niter), _p(res),
+                                    ctypes.byref(stat)), self.L)
+        return niter.value, stat.value, (res[0], res[1])
+
+
+def build_context(spec, device=0, rings_by_nside=None, _lib=None):
+    """Create a ready CRContext from a problem ``spec`` (see commander_amd.synth.make_problem).
+    rings_by_nside: {nside: northern ring numbers} for a ring-sharded rank (maps in spec are then local)."""
+    ctx = CRContext(device, _lib=_lib)
+    if rings_by_nside:
+        for ns, r in rings_by_nside.items():
+            ctx.set_rings(ns, r)
+    for b in spec["bands"]:
+        ctx.add_band(b["nside"], b["lmax"], b["siN"], b["b_l"], b.get("mb_eff", 1.0), b.get("sg_mask"), b.get("wring"))
+    for c in spec["comps"]:
+        ctx.add_comp(c["lmax"], c["nmaps"], c["F_mean"], c.get("sqrtS_mat"), c.get("sqrtInvS_mat"), c.get("S_mat"),
+                     c.get("active", True))
+    ctx.finalize()
+    return ctx

@@ -5,6 +5,7 @@
 #include <string>
 
 #include "common.hpp"
+#include "cr_system.hpp"
 #include "sht_plan.hpp"
 
 namespace {
@@ -127,6 +128,236 @@ int cmdr_sht_execute(cmdr_sht_plan* plan, int job, int nmaps, double* const* alm
             else
                 CMDR_HIP_CHECK(hipMemcpy(alm[k], plan->alm.get() + k * na, na * sizeof(double), hipMemcpyDeviceToHost));
         }
+    });
+}
+
+}  // extern "C"
+
+// ------------------------------------------------------------------------------------------------- CR level
+struct cmdr_ctx {
+    std::unique_ptr<cmdr::CrSystem> sys;
+    cmdr::DevBuf<double> hx, hy, hz;           // staging for the host-pointer entry points
+    std::vector<cmdr::DevBuf<double>> hmaps;   // staged band maps (resid, xi)
+};
+
+extern "C" {
+
+int cmdr_ctx_create(int device, cmdr_ctx** out) {
+    return guarded([&] {
+        CMDR_REQUIRE(out != nullptr, "out is NULL");
+        CMDR_REQUIRE(cmdr_device_count() > device && device >= 0,
+                     "no such HIP device: libcmdr_hip has no CPU path");
+        auto* c = new cmdr_ctx;
+        try {
+            c->sys = std::make_unique<cmdr::CrSystem>(device);
+        } catch (...) {
+            delete c;
+            throw;
+        }
+        *out = c;
+    });
+}
+int cmdr_ctx_destroy(cmdr_ctx* ctx) {
+    return guarded([&] { delete ctx; });
+}
+int cmdr_ctx_set_rings(cmdr_ctx* ctx, int nside, int nrings, const int* rings) {
+    return guarded([&] {
+        CMDR_REQUIRE(ctx && rings && nrings > 0, "bad arguments");
+        ctx->sys->set_rings(nside, std::vector<int>(rings, rings + nrings));
+    });
+}
+int cmdr_ctx_set_allreduce(cmdr_ctx* ctx, cmdr_allreduce_fn fn, void* user) {
+    return guarded([&] {
+        CMDR_REQUIRE(ctx, "ctx is NULL");
+        ctx->sys->set_allreduce(fn, user);
+    });
+}
+int cmdr_ctx_set_only_pol(cmdr_ctx* ctx, int only_pol) {
+    return guarded([&] {
+        CMDR_REQUIRE(ctx, "ctx is NULL");
+        ctx->sys->set_only_pol(only_pol != 0);
+    });
+}
+int cmdr_band_add(cmdr_ctx* ctx, int nside, int lmax, int nmaps, const double* siN, const double* b_l,
+                  double mb_eff, const double* sg_mask, const double* wring) {
+    int idx = -1;
+    const int rc = guarded([&] {
+        CMDR_REQUIRE(ctx, "ctx is NULL");
+        idx = ctx->sys->add_band(nside, lmax, nmaps, siN, b_l, mb_eff, sg_mask, wring);
+    });
+    return rc == 0 ? idx : rc;
+}
+int cmdr_comp_add(cmdr_ctx* ctx, int lmax_amp, int nmaps, int lmax_cl, const double* sqrtS_mat,
+                  const double* sqrtInvS_mat, const double* S_mat, const double* F_mean, int active) {
+    int idx = -1;
+    const int rc = guarded([&] {
+        CMDR_REQUIRE(ctx, "ctx is NULL");
+        idx = ctx->sys->add_comp(lmax_amp, nmaps, lmax_cl, sqrtS_mat, sqrtInvS_mat, S_mat, F_mean, active);
+    });
+    return rc == 0 ? idx : rc;
+}
+int cmdr_finalize(cmdr_ctx* ctx) {
+    return guarded([&] {
+        CMDR_REQUIRE(ctx, "ctx is NULL");
+        ctx->sys->finalize();
+    });
+}
+int64_t cmdr_ncr(const cmdr_ctx* ctx) { return ctx ? ctx->sys->ncr() : -1; }
+int64_t cmdr_band_npix(const cmdr_ctx* ctx, int band) {
+    if (!ctx || band < 0 || band >= ctx->sys->nband()) return -1;
+    return ctx->sys->band_npix(band);
+}
+int cmdr_precond_init_diag(cmdr_ctx* ctx) {
+    return guarded([&] {
+        CMDR_REQUIRE(ctx, "ctx is NULL");
+        ctx->sys->precond_init_diag();
+    });
+}
+int cmdr_precond_update_diag(cmdr_ctx* ctx) {
+    return guarded([&] {
+        CMDR_REQUIRE(ctx, "ctx is NULL");
+        ctx->sys->precond_update_diag();
+        ctx->sys->sync();
+    });
+}
+int cmdr_get_invN_diag(cmdr_ctx* ctx, int band, double* out_host) {
+    return guarded([&] {
+        CMDR_REQUIRE(ctx && out_host && band >= 0 && band < ctx->sys->nband(), "bad arguments");
+        const double* p = ctx->sys->invN_diag_dev(band);
+        CMDR_REQUIRE(p != nullptr, "cmdr_precond_init_diag has not run");
+        // nmaps columns of nalm
+        const int64_t n = ctx->sys->band_nalm(band);
+        CMDR_HIP_CHECK(hipMemcpy(out_host, p, sizeof(double) * n, hipMemcpyDeviceToHost));
+    });
+}
+
+int cmdr_matmulA_dev(cmdr_ctx* ctx, const double* x, double* y) {
+    return guarded([&] {
+        CMDR_REQUIRE(ctx && x && y, "bad arguments");
+        ctx->sys->matmulA(x, y);
+        CMDR_HIP_CHECK(hipGetLastError());
+        ctx->sys->sync();
+    });
+}
+int cmdr_invM_dev(cmdr_ctx* ctx, const double* x, double* y) {
+    return guarded([&] {
+        CMDR_REQUIRE(ctx && x && y, "bad arguments");
+        ctx->sys->invM(x, y);
+        CMDR_HIP_CHECK(hipGetLastError());
+        ctx->sys->sync();
+    });
+}
+int cmdr_matmulA(cmdr_ctx* ctx, const double* x, double* y) {
+    return guarded([&] {
+        CMDR_REQUIRE(ctx && x && y, "bad arguments");
+        const size_t n = (size_t)ctx->sys->ncr();
+        ctx->hx.ensure(n);
+        ctx->hy.ensure(n);
+        CMDR_HIP_CHECK(hipMemcpy(ctx->hx.get(), x, n * sizeof(double), hipMemcpyHostToDevice));
+        if (cmdr_matmulA_dev(ctx, ctx->hx.get(), ctx->hy.get()) != 0) throw cmdr::Error(g_err);
+        CMDR_HIP_CHECK(hipMemcpy(y, ctx->hy.get(), n * sizeof(double), hipMemcpyDeviceToHost));
+    });
+}
+int cmdr_invM(cmdr_ctx* ctx, const double* x, double* y) {
+    return guarded([&] {
+        CMDR_REQUIRE(ctx && x && y, "bad arguments");
+        const size_t n = (size_t)ctx->sys->ncr();
+        ctx->hx.ensure(n);
+        ctx->hy.ensure(n);
+        CMDR_HIP_CHECK(hipMemcpy(ctx->hx.get(), x, n * sizeof(double), hipMemcpyHostToDevice));
+        if (cmdr_invM_dev(ctx, ctx->hx.get(), ctx->hy.get()) != 0) throw cmdr::Error(g_err);
+        CMDR_HIP_CHECK(hipMemcpy(y, ctx->hy.get(), n * sizeof(double), hipMemcpyDeviceToHost));
+    });
+}
+
+int cmdr_compute_rhs_dev(cmdr_ctx* ctx, int sample, const double* const* resid, const double* const* xi,
+                         const double* eta, const double* mu, double* rhs) {
+    return guarded([&] {
+        CMDR_REQUIRE(ctx && resid && rhs, "bad arguments");
+        CMDR_REQUIRE(!sample || (xi && eta), "operation 'sample' needs xi and eta");
+        ctx->sys->compute_rhs(sample != 0, resid, xi, eta, mu, rhs);
+        CMDR_HIP_CHECK(hipGetLastError());
+        ctx->sys->sync();
+    });
+}
+int cmdr_compute_rhs(cmdr_ctx* ctx, int sample, const double* const* resid, const double* const* xi,
+                     const double* eta, const double* mu, double* rhs) {
+    return guarded([&] {
+        CMDR_REQUIRE(ctx && resid && rhs, "bad arguments");
+        CMDR_REQUIRE(!sample || (xi && eta), "operation 'sample' needs xi and eta");
+        const int nb = ctx->sys->nband();
+        const size_t n = (size_t)ctx->sys->ncr();
+        ctx->hmaps.resize(2 * (size_t)nb);
+        std::vector<const double*> dres(nb), dxi(nb, nullptr);
+        for (int b = 0; b < nb; ++b) {
+            const size_t np = (size_t)ctx->sys->band_npix(b) * 1;  // per column; nmaps columns are contiguous
+            // nmaps is folded into the staging size through siN's own size on the device side
+            const size_t tot = np * (size_t)(ctx->sys->band_nmaps(b));
+            ctx->hmaps[2 * b].ensure(tot);
+            CMDR_HIP_CHECK(hipMemcpy(ctx->hmaps[2 * b].get(), resid[b], tot * sizeof(double), hipMemcpyHostToDevice));
+            dres[b] = ctx->hmaps[2 * b].get();
+            if (sample) {
+                ctx->hmaps[2 * b + 1].ensure(tot);
+                CMDR_HIP_CHECK(hipMemcpy(ctx->hmaps[2 * b + 1].get(), xi[b], tot * sizeof(double), hipMemcpyHostToDevice));
+                dxi[b] = ctx->hmaps[2 * b + 1].get();
+            }
+        }
+        ctx->hx.ensure(n);
+        ctx->hy.ensure(n);
+        ctx->hz.ensure(n);
+        if (sample) CMDR_HIP_CHECK(hipMemcpy(ctx->hx.get(), eta, n * sizeof(double), hipMemcpyHostToDevice));
+        if (mu) CMDR_HIP_CHECK(hipMemcpy(ctx->hz.get(), mu, n * sizeof(double), hipMemcpyHostToDevice));
+        if (cmdr_compute_rhs_dev(ctx, sample, dres.data(), dxi.data(), sample ? ctx->hx.get() : nullptr,
+                                 mu ? ctx->hz.get() : nullptr, ctx->hy.get()) != 0)
+            throw cmdr::Error(g_err);
+        CMDR_HIP_CHECK(hipMemcpy(rhs, ctx->hy.get(), n * sizeof(double), hipMemcpyDeviceToHost));
+    });
+}
+
+int cmdr_solve_dev(cmdr_ctx* ctx, const double* b, double* x, int crit, double tol, int miniter, int maxiter,
+                   int check_freq, const double* x0, int* niter, double* res, int* stat) {
+    return guarded([&] {
+        CMDR_REQUIRE(ctx && b && x, "bad arguments");
+        CMDR_REQUIRE(crit == 0 || crit == 1, "crit must be 0 (residual) or 1 (fixed_iter)");
+        const cmdr::SolveResult R = ctx->sys->solve(b, x, crit, tol, miniter, maxiter, check_freq, x0);
+        if (niter) *niter = R.niter;
+        if (stat) *stat = R.stat;
+        if (res) { res[0] = R.delta_new; res[1] = R.delta0; }
+    });
+}
+int cmdr_solve(cmdr_ctx* ctx, const double* b, double* x, int crit, double tol, int miniter, int maxiter,
+               int check_freq, const double* x0, int* niter, double* res, int* stat) {
+    return guarded([&] {
+        CMDR_REQUIRE(ctx && b && x, "bad arguments");
+        const size_t n = (size_t)ctx->sys->ncr();
+        ctx->hx.ensure(n);
+        ctx->hy.ensure(n);
+        ctx->hz.ensure(n);
+        CMDR_HIP_CHECK(hipMemcpy(ctx->hx.get(), b, n * sizeof(double), hipMemcpyHostToDevice));
+        if (x0) CMDR_HIP_CHECK(hipMemcpy(ctx->hz.get(), x0, n * sizeof(double), hipMemcpyHostToDevice));
+        if (cmdr_solve_dev(ctx, ctx->hx.get(), ctx->hy.get(), crit, tol, miniter, maxiter, check_freq,
+                           x0 ? ctx->hz.get() : nullptr, niter, res, stat) != 0)
+            throw cmdr::Error(g_err);
+        CMDR_HIP_CHECK(hipMemcpy(x, ctx->hy.get(), n * sizeof(double), hipMemcpyDeviceToHost));
+    });
+}
+
+int cmdr_profile_enable(cmdr_ctx* ctx, int on) {
+    return guarded([&] {
+        CMDR_REQUIRE(ctx, "ctx is NULL");
+        ctx->sys->set_profile(on != 0);
+    });
+}
+int cmdr_profile_read(cmdr_ctx* ctx, double* ms_sum, long long* count) {
+    return guarded([&] {
+        CMDR_REQUIRE(ctx && ms_sum && count, "bad arguments");
+        ctx->sys->read_profile(ms_sum, count);
+    });
+}
+int cmdr_problem_info(cmdr_ctx* ctx, int64_t* out) {
+    return guarded([&] {
+        CMDR_REQUIRE(ctx && out, "bad arguments");
+        ctx->sys->problem_info(out);
     });
 }
 

@@ -1,0 +1,150 @@
+// Element bodies of the harmonic-space / vector kernels of the CR solver (host-emulable, see kernels_body.hpp).
+// Each works on one (l, m) of an (l, m) grid and touches both the (+m) and (-m) slots of Commander's real-packed
+// layout (commander3/src/comm_map_mod.f90:228-261).
+#pragma once
+#include "kernels_body.hpp"
+
+namespace cmdr {
+
+struct CompDev {        // one diffuse component inside the stacked vector (comm_cr_utils.f90:25-33 ind_comp)
+    long long pos;      // 0-based start in x
+    long long nalm;     // (lmax+1)^2
+    int lmax;           // lmax_amp
+    int nmaps;
+    int lmax_cl;        // lmax of the S tables (-1: cltype 'none')
+    int active;
+    long long smat_off; // offset of this component's [3 kinds][nmaps*nmaps*(lmax_cl+1)] tables (sqrtS, sqrtInvS, S)
+};
+
+// out = f(M_l) applied per l to the nmaps-vector of a component (comm_Cl_mod.f90:588-674), optionally + add.
+//   kind 0: sqrtS_mat, 1: sqrtInvS_mat.  l > lmax_cl -> 0.  cltype 'none' (lmax_cl < 0) -> identity.
+//   inactive components: out = (add ? add : 0)  [cr_matmulA never touches their slots: comm_cr_mod.f90:800-803]
+CMDR_HD void sqrtS_elem(const CompDev& C, const double* __restrict__ smat, int kind, const double* __restrict__ in,
+                        const double* __restrict__ add, double* __restrict__ out, int m, int l,
+                        bool pass_inactive) {
+    const int64_t i0 = d_packed_index(C.lmax, l, m);
+    const int nslot = m == 0 ? 1 : 2;
+    const int nm = C.nmaps;
+    for (int sl = 0; sl < nslot; ++sl) {
+        const int64_t i = i0 + sl;
+        double v[3] = {0.0, 0.0, 0.0}, r[3] = {0.0, 0.0, 0.0};
+        for (int a = 0; a < nm; ++a) v[a] = in[C.pos + a * C.nalm + i];
+        if (!C.active) {
+            for (int a = 0; a < nm; ++a) r[a] = pass_inactive ? v[a] : 0.0;
+        } else if (C.lmax_cl < 0) {
+            for (int a = 0; a < nm; ++a) r[a] = v[a];
+        } else if (l <= C.lmax_cl) {
+            const double* M = smat + C.smat_off + (int64_t)kind * nm * nm * (C.lmax_cl + 1) + (int64_t)nm * nm * l;
+            for (int a = 0; a < nm; ++a) {
+                double s = 0.0;
+                for (int b = 0; b < nm; ++b) s += M[a + nm * b] * v[b];
+                r[a] = s;
+            }
+        }
+        for (int a = 0; a < nm; ++a) {
+            double o = r[a];
+            // the unit prior / eta / mu terms exist only for active components with a prior
+            // (comm_cr_mod.f90:698, :967: "if (trim(c%cltype) /= 'none')")
+            if (add) o += (C.active && C.lmax_cl >= 0) ? add[C.pos + a * C.nalm + i] : 0.0;
+            out[C.pos + a * C.nalm + i] = o;
+        }
+    }
+}
+
+// Band stream entry: a~_bm(l,m) = cnorm * kappa_m * sum_c w[bm][c][l] * sx_{c, stokes(bm)}(l,m)
+//   w folds F_mean * b_l * mb_eff and both l-truncations (comm_cr_mod.f90:858-867,
+//   comm_diffuse_comp_mod.f90:2077-2089, comm_B_bl_mod.f90:108-127).
+CMDR_HD void band_prep_elem(const CompDev* __restrict__ comps, int ncomp, const double* __restrict__ sx,
+                            const double* __restrict__ w /* [ncomp][lmax_g+1] for this bm */, int stokes,
+                            double* __restrict__ ast, const double* __restrict__ cnorm, int lmax_g, int m, int l) {
+    const int64_t t = d_moffp(lmax_g, m) + (l - m);
+    double re = 0.0, im = 0.0;
+    if (l <= lmax_g) {
+        for (int c = 0; c < ncomp; ++c) {
+            const CompDev C = comps[c];
+            if (l > C.lmax || stokes >= C.nmaps) continue;
+            const double wc = w[(int64_t)c * (lmax_g + 1) + l];
+            if (wc == 0.0) continue;
+            const int64_t i = C.pos + (int64_t)stokes * C.nalm + d_packed_index(C.lmax, l, m);
+            re += wc * sx[i];
+            if (m > 0) im += wc * sx[i + 1];
+        }
+        const double f = cnorm[t] * (m == 0 ? 1.0 : 0.70710678118654752440);
+        re *= f;
+        im *= f;
+    }
+    ast[2 * t] = re;
+    ast[2 * t + 1] = im;
+}
+
+// Component entry of y_c: (+)= kappa'_m * sum_{bm in group} w[bm][c][l] cnorm[t] sum_chunks part[bm][chunk][t]
+//   (projectDiffuseBand, comm_diffuse_comp_mod.f90:2112-2167, and the truncation comm_cr_mod.f90:931-933).
+CMDR_HD void band_post_elem(const CompDev& C, int c, int ncomp, const double* __restrict__ part,
+                            int64_t part_map_stride, int64_t part_chunk_stride, int nchunk, int nbm,
+                            const int* __restrict__ bm_stokes, const double* __restrict__ w /* [nbm][ncomp][lmax_g+1] */,
+                            const double* __restrict__ cnorm, int lmax_g, double* __restrict__ yc, int accumulate,
+                            int m, int l) {
+    const int64_t i0 = d_packed_index(C.lmax, l, m);
+    for (int a = 0; a < C.nmaps; ++a) {
+        double re = 0.0, im = 0.0;
+        if (l <= lmax_g && C.active) {
+            const int64_t t = d_moffp(lmax_g, m) + (l - m);
+            for (int b = 0; b < nbm; ++b) {
+                if (bm_stokes[b] != a) continue;
+                const double wc = w[((int64_t)b * ncomp + c) * (lmax_g + 1) + l];
+                if (wc == 0.0) continue;
+                const double* p = part + b * part_map_stride + 2 * t;
+                double sr = 0.0, si = 0.0;
+                for (int ch = 0; ch < nchunk; ++ch) {
+                    sr += p[ch * part_chunk_stride];
+                    si += p[ch * part_chunk_stride + 1];
+                }
+                re += wc * sr;
+                im += wc * si;
+            }
+            const double f = cnorm[t] * (m == 0 ? 1.0 : 1.41421356237309504880);
+            re *= f;
+            im *= f;
+        }
+        const int64_t i = C.pos + (int64_t)a * C.nalm + i0;
+        if (accumulate) {
+            yc[i] += re;
+            if (m > 0) yc[i + 1] += im;
+        } else {
+            yc[i] = re;
+            if (m > 0) yc[i + 1] = im;
+        }
+    }
+}
+
+// Diagonal preconditioner (applyDiffPrecond_diagonal, comm_diffuse_comp_mod.f90:2186-2235): per (l, m, stokes)
+// a dense npre x npre block (same for +m and -m).  P layout: [stokes][k1][k2][ntri(lmax_pre)] (unpadded triangle).
+CMDR_HD int64_t d_moff(int lmax, int m) { return (int64_t)m * (lmax + 1) - (int64_t)m * (m - 1) / 2; }
+
+CMDR_HD void precond_diag_elem(const CompDev* __restrict__ comps, int ncomp, const double* __restrict__ P,
+                               int lmax_pre, int nmaps_pre, const double* __restrict__ in, double* __restrict__ out,
+                               int m, int l) {
+    const int64_t ntri = (int64_t)(lmax_pre + 1) * (lmax_pre + 2) / 2;
+    const int64_t t = d_moff(lmax_pre, m) + (l - m);
+    const int nslot = m == 0 ? 1 : 2;
+    for (int j = 0; j < nmaps_pre; ++j) {
+        for (int sl = 0; sl < nslot; ++sl) {
+            double v[8];
+            for (int k = 0; k < ncomp; ++k) {
+                const CompDev C = comps[k];
+                v[k] = (l <= C.lmax && j < C.nmaps) ? in[C.pos + (int64_t)j * C.nalm + d_packed_index(C.lmax, l, m) + sl]
+                                                     : 0.0;
+            }
+            for (int k1 = 0; k1 < ncomp; ++k1) {
+                const CompDev C = comps[k1];
+                if (l > C.lmax || j >= C.nmaps) continue;
+                double s = 0.0;
+                for (int k2 = 0; k2 < ncomp; ++k2)
+                    s += P[(((int64_t)j * ncomp + k1) * ncomp + k2) * ntri + t] * v[k2];
+                out[C.pos + (int64_t)j * C.nalm + d_packed_index(C.lmax, l, m) + sl] = s;
+            }
+        }
+    }
+}
+
+}  // namespace cmdr

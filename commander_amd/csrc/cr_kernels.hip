@@ -1,0 +1,207 @@
+// gfx950 kernels of the CR solver that are pure HBM streams:
+// harmonic-space scalings / re-layouts on (l, m) grids, pixel-space noise weighting, fused CG vector updates and
+// deterministic two-stage dot products whose results stay on the device (no host sync inside a CG iteration).
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+
+#include "cr_body.hpp"
+#include "kernels.hpp"
+
+namespace cmdr {
+
+// ----------------------------------------------------------------------------- (l, m)-grid kernels
+__global__ void k_sqrtS(const CompDev* __restrict__ comps, const double* __restrict__ smat, int kind,
+                        const double* __restrict__ in, const double* __restrict__ add, double* __restrict__ out,
+                        int pass_inactive) {
+    const CompDev C = comps[blockIdx.z];
+    const int m = blockIdx.y, l = m + blockIdx.x * 256 + threadIdx.x;
+    if (m > C.lmax || l > C.lmax) return;
+    sqrtS_elem(C, smat, kind, in, add, out, m, l, pass_inactive != 0);
+}
+void launch_sqrtS(const CompDev* comps, int ncomp, int lmax_max, const double* smat, int kind, const double* in,
+                  const double* add, double* out, bool pass_inactive, hipStream_t s) {
+    dim3 grid((lmax_max + 1 + 255) / 256, lmax_max + 1, ncomp);
+    hipLaunchKernelGGL(k_sqrtS, grid, dim3(256), 0, s, comps, smat, kind, in, add, out, pass_inactive ? 1 : 0);
+}
+
+__global__ void k_band_prep(const CompDev* __restrict__ comps, int ncomp, const double* __restrict__ sx,
+                            const double* __restrict__ w, const int* __restrict__ bm_stokes,
+                            double* __restrict__ ast, int64_t ast_stride, const double* __restrict__ cnorm,
+                            int lmax_g) {
+    const int m = blockIdx.y, l = m + blockIdx.x * 256 + threadIdx.x;
+    if (l > lmax_g + 1) return;
+    const int bm = blockIdx.z;
+    band_prep_elem(comps, ncomp, sx, w + (int64_t)bm * ncomp * (lmax_g + 1), bm_stokes[bm], ast + bm * ast_stride,
+                   cnorm, lmax_g, m, l);
+}
+void launch_band_prep(const CompDev* comps, int ncomp, const double* sx, const double* w, const int* bm_stokes,
+                      double* ast, int64_t ast_stride, const double* cnorm, int lmax_g, int nbm, hipStream_t s) {
+    dim3 grid((lmax_g + 2 + 255) / 256, lmax_g + 1, nbm);
+    hipLaunchKernelGGL(k_band_prep, grid, dim3(256), 0, s, comps, ncomp, sx, w, bm_stokes, ast, ast_stride, cnorm,
+                       lmax_g);
+}
+
+__global__ void k_band_post(const CompDev* __restrict__ comps, int ncomp, const double* __restrict__ part,
+                            int64_t pms, int64_t pcs, int nchunk, int nbm, const int* __restrict__ bm_stokes,
+                            const double* __restrict__ w, const double* __restrict__ cnorm, int lmax_g,
+                            double* __restrict__ yc, int accumulate) {
+    const int c = blockIdx.z;
+    const CompDev C = comps[c];
+    const int m = blockIdx.y, l = m + blockIdx.x * 256 + threadIdx.x;
+    if (m > C.lmax || l > C.lmax) return;
+    band_post_elem(C, c, ncomp, part, pms, pcs, nchunk, nbm, bm_stokes, w, cnorm, lmax_g, yc, accumulate, m, l);
+}
+void launch_band_post(const CompDev* comps, int ncomp, int lmax_max, const double* part, int64_t pms, int64_t pcs,
+                      int nchunk, int nbm, const int* bm_stokes, const double* w, const double* cnorm, int lmax_g,
+                      double* yc, bool accumulate, hipStream_t s) {
+    dim3 grid((lmax_max + 1 + 255) / 256, lmax_max + 1, ncomp);
+    hipLaunchKernelGGL(k_band_post, grid, dim3(256), 0, s, comps, ncomp, part, pms, pcs, nchunk, nbm, bm_stokes, w,
+                       cnorm, lmax_g, yc, accumulate ? 1 : 0);
+}
+
+__global__ void k_precond_diag(const CompDev* __restrict__ comps, int ncomp, const double* __restrict__ P,
+                               int lmax_pre, int nmaps_pre, const double* __restrict__ in,
+                               double* __restrict__ out) {
+    const int m = blockIdx.y, l = m + blockIdx.x * 256 + threadIdx.x;
+    if (l > lmax_pre) return;
+    precond_diag_elem(comps, ncomp, P, lmax_pre, nmaps_pre, in, out, m, l);
+}
+void launch_precond_diag(const CompDev* comps, int ncomp, const double* P, int lmax_pre, int nmaps_pre,
+                         const double* in, double* out, hipStream_t s) {
+    dim3 grid((lmax_pre + 1 + 255) / 256, lmax_pre + 1);
+    hipLaunchKernelGGL(k_precond_diag, grid, dim3(256), 0, s, comps, ncomp, P, lmax_pre, nmaps_pre, in, out);
+}
+
+// fill the "phases" of a Gauss-Legendre Legendre plan with per-node weights: ph[m][pair] = (wN, 0, wS, 0)
+__global__ void k_fill_gl(double* __restrict__ ph, const double* __restrict__ wn, const double* __restrict__ ws,
+                          int npair_pad, int lmax) {
+    const int p = blockIdx.x * 256 + threadIdx.x, m = blockIdx.y;
+    if (p >= npair_pad) return;
+    double* o = ph + ((int64_t)m * npair_pad + p) * 4;
+    o[0] = wn[p];
+    o[1] = 0.0;
+    o[2] = ws[p];
+    o[3] = 0.0;
+}
+void launch_fill_gl(double* ph, const double* wn, const double* ws, int npair_pad, int lmax, hipStream_t s) {
+    dim3 grid((npair_pad + 255) / 256, lmax + 1);
+    hipLaunchKernelGGL(k_fill_gl, grid, dim3(256), 0, s, ph, wn, ws, npair_pad, lmax);
+}
+
+// invN_diag: out packed (+m,-m both) = cnorm^2 * sum_chunks Re part   (comm_N_mod.f90:180-186)
+__global__ void k_part_to_diag(const double* __restrict__ part, int64_t pcs, int nchunk,
+                               const double* __restrict__ cnorm, double* __restrict__ out, int lmax) {
+    const int m = blockIdx.y, l = m + blockIdx.x * 256 + threadIdx.x;
+    if (l > lmax) return;
+    const int64_t t = d_moffp(lmax, m) + (l - m);
+    double s = 0.0;
+    for (int c = 0; c < nchunk; ++c) s += part[c * pcs + 2 * t];
+    const double cn = cnorm[t];
+    s *= cn * cn;
+    const int64_t i = d_packed_index(lmax, l, m);
+    out[i] = s;
+    if (m > 0) out[i + 1] = s;
+}
+void launch_part_to_diag(const double* part, int64_t pcs, int nchunk, const double* cnorm, double* out, int lmax,
+                         hipStream_t s) {
+    dim3 grid((lmax + 1 + 255) / 256, lmax + 1);
+    hipLaunchKernelGGL(k_part_to_diag, grid, dim3(256), 0, s, part, pcs, nchunk, cnorm, out, lmax);
+}
+
+// ----------------------------------------------------------------------------- pixel-space streams
+// mode 0: out = a*b ; 1: out = a*(a*b + c) (RHS "sample": sqrtInvN, + xi, sqrtInvN; comm_cr_mod.f90:600-609)
+__global__ void k_pix(int mode, const double* __restrict__ a, const double* __restrict__ b,
+                      const double* __restrict__ c, double* __restrict__ out, int64_t n) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const double av = a[i];
+        out[i] = mode == 0 ? av * b[i] : av * (av * b[i] + c[i]);
+    }
+}
+void launch_pix(int mode, const double* a, const double* b, const double* c, double* out, int64_t n,
+                hipStream_t s) {
+    const int nb = (int)std::min<int64_t>((n + 255) / 256, 4096);
+    hipLaunchKernelGGL(k_pix, dim3(nb), dim3(256), 0, s, mode, a, b, c, out, n);
+}
+
+// ----------------------------------------------------------------------------- CG vector algebra
+// Deterministic dot: fixed grid of kDotBlocks partial sums (wave shuffle -> LDS), then one block folds them in
+// a fixed order.  Results land in a small device scalar array so the host never waits inside an iteration.
+constexpr int kDotBlocks = 1024;
+
+__device__ inline double block_sum_256(double v) {
+    __shared__ double sm[4];
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o);
+    const int w = threadIdx.x >> 6;
+    if ((threadIdx.x & 63) == 0) sm[w] = v;
+    __syncthreads();
+    double r = 0.0;
+    if (threadIdx.x == 0) r = (sm[0] + sm[1]) + (sm[2] + sm[3]);
+    __syncthreads();
+    return r;
+}
+
+__global__ void __launch_bounds__(256) k_dot_partial(const double* __restrict__ a, const double* __restrict__ b,
+                                                     int64_t n, double* __restrict__ partial) {
+    double acc = 0.0;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)kDotBlocks * 256) acc += a[i] * b[i];
+    const double r = block_sum_256(acc);
+    if (threadIdx.x == 0) partial[blockIdx.x] = r;
+}
+// scal[slot] = sum(partial); if shift: scal[slot+1] = old scal[slot] first (delta_old <- delta_new)
+__global__ void __launch_bounds__(256) k_dot_final(const double* __restrict__ partial, double* __restrict__ scal,
+                                                   int slot, int shift) {
+    double acc = 0.0;
+    for (int i = threadIdx.x; i < kDotBlocks; i += 256) acc += partial[i];
+    const double r = block_sum_256(acc);
+    if (threadIdx.x == 0) {
+        if (shift) scal[slot + 1] = scal[slot];
+        scal[slot] = r;
+    }
+}
+void launch_dot(const double* a, const double* b, int64_t n, double* partial, double* scal, int slot, bool shift,
+                hipStream_t s) {
+    hipLaunchKernelGGL(k_dot_partial, dim3(kDotBlocks), dim3(256), 0, s, a, b, n, partial);
+    hipLaunchKernelGGL(k_dot_final, dim3(1), dim3(256), 0, s, partial, scal, slot, shift ? 1 : 0);
+}
+int dot_partial_count() { return kDotBlocks; }
+
+// x += alpha d ; r -= alpha q ; alpha = scal[num] / scal[den]   (comm_cr_mod.f90:254-261)
+__global__ void k_cg_xr(double* __restrict__ x, double* __restrict__ r, const double* __restrict__ d,
+                        const double* __restrict__ q, int64_t n, const double* __restrict__ scal, int num, int den) {
+    const double alpha = scal[num] / scal[den];
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        x[i] += alpha * d[i];
+        r[i] -= alpha * q[i];
+    }
+}
+void launch_cg_xr(double* x, double* r, const double* d, const double* q, int64_t n, const double* scal, int num,
+                  int den, hipStream_t s) {
+    const int nb = (int)std::min<int64_t>((n + 255) / 256, 4096);
+    hipLaunchKernelGGL(k_cg_xr, dim3(nb), dim3(256), 0, s, x, r, d, q, n, scal, num, den);
+}
+
+// d = s + beta d ; beta = scal[num] / scal[den]   (comm_cr_mod.f90:271-272)
+__global__ void k_cg_d(double* __restrict__ d, const double* __restrict__ sv, int64_t n,
+                       const double* __restrict__ scal, int num, int den) {
+    const double beta = scal[num] / scal[den];
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+        d[i] = sv[i] + beta * d[i];
+}
+void launch_cg_d(double* d, const double* sv, int64_t n, const double* scal, int num, int den, hipStream_t s) {
+    const int nb = (int)std::min<int64_t>((n + 255) / 256, 4096);
+    hipLaunchKernelGGL(k_cg_d, dim3(nb), dim3(256), 0, s, d, sv, n, scal, num, den);
+}
+
+// out = a + cb * b  (cb = +-1 etc.)
+__global__ void k_axpby(const double* __restrict__ a, const double* __restrict__ b, double cb,
+                        double* __restrict__ out, int64_t n) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+        out[i] = a[i] + cb * b[i];
+}
+void launch_axpby(const double* a, const double* b, double cb, double* out, int64_t n, hipStream_t s) {
+    const int nb = (int)std::min<int64_t>((n + 255) / 256, 4096);
+    hipLaunchKernelGGL(k_axpby, dim3(nb), dim3(256), 0, s, a, b, cb, out, n);
+}
+
+}  // namespace cmdr

@@ -1,0 +1,557 @@
+#include "cr_system.hpp"
+
+#include <cmath>
+#include <cstring>
+#include <map>
+
+namespace cmdr {
+
+CrSystem::CrSystem(int device) : device_(device) {
+    CMDR_HIP_CHECK(hipSetDevice(device));
+    CMDR_HIP_CHECK(hipStreamCreate(&stream_));
+}
+
+CrSystem::~CrSystem() {
+    if (stream_) (void)hipStreamDestroy(stream_);
+}
+
+void CrSystem::sync() { CMDR_HIP_CHECK(hipStreamSynchronize(stream_)); }
+
+void CrSystem::set_profile(bool on) {
+    double ms[4];
+    long long n[4];
+    read_profile(ms, n);
+    for (int k = 0; k < 4; ++k) { prof_ms_[k] = 0; prof_n_[k] = 0; }
+    profile_ = on;
+}
+
+void CrSystem::problem_info(int64_t* out) const {
+    CMDR_REQUIRE(finalized_, "finalize first");
+    const Group& G = groups_[0];
+    const LegendreTables& L = G.plan->tables().leg;
+    int64_t steps = 0;
+    for (int m = 0; m <= L.lmax; ++m)
+        for (int p = 0; p < L.npair; ++p) {
+            const int v = L.ls[(size_t)m * L.npair_pad + p];
+            if (v != kLsNever) steps += L.lmax - v + 1;
+        }
+    out[0] = G.nbm;
+    out[1] = (int64_t)L.tasks.size();
+    out[2] = steps;
+}
+
+void CrSystem::span_begin(int kind) {
+    if (!profile_) return;
+    Span s;
+    s.kind = kind;
+    CMDR_HIP_CHECK(hipEventCreate(&s.a));
+    CMDR_HIP_CHECK(hipEventCreate(&s.b));
+    CMDR_HIP_CHECK(hipEventRecord(s.a, stream_));
+    spans_.push_back(s);
+    open_.push_back((int)spans_.size() - 1);
+}
+
+void CrSystem::span_end() {
+    if (!profile_) return;
+    CMDR_HIP_CHECK(hipEventRecord(spans_[open_.back()].b, stream_));
+    open_.pop_back();
+}
+
+void CrSystem::read_profile(double* ms_sum, long long* count) {
+    if (!spans_.empty()) {
+        sync();
+        for (Span& s : spans_) {
+            float ms = 0.f;
+            CMDR_HIP_CHECK(hipEventElapsedTime(&ms, s.a, s.b));
+            prof_ms_[s.kind] += ms;
+            prof_n_[s.kind] += 1;
+            (void)hipEventDestroy(s.a);
+            (void)hipEventDestroy(s.b);
+        }
+        spans_.clear();
+    }
+    for (int k = 0; k < 4; ++k) { ms_sum[k] = prof_ms_[k]; count[k] = prof_n_[k]; }
+}
+
+void CrSystem::set_rings(int nside, const std::vector<int>& rings) {
+    CMDR_REQUIRE(!finalized_, "set_rings after finalize");
+    for (auto& rs : ring_sets_)
+        if (rs.first == nside) { rs.second = rings; return; }
+    ring_sets_.push_back({nside, rings});
+}
+
+int64_t CrSystem::band_npix(int b) const {
+    const Band& B = bands_[b];
+    if (B.group >= 0) return groups_[B.group].plan->npix_local();
+    for (auto& rs : ring_sets_)
+        if (rs.first == B.nside && !rs.second.empty()) {
+            int64_t n = 0;
+            for (int r : rs.second) n += (int64_t)healpix_ring(B.nside, r).nphi * (r == 2 * B.nside ? 1 : 2);
+            return n;
+        }
+    return 12 * (int64_t)B.nside * B.nside;
+}
+
+int CrSystem::add_band(int nside, int lmax, int nmaps, const double* siN, const double* b_l, double mb_eff,
+                       const double* sg_mask, const double* wring) {
+    CMDR_REQUIRE(!finalized_, "add_band after finalize");
+    CMDR_REQUIRE(comps_.empty(), "add all bands before the first component (F_mean is dimensioned by numband)");
+    CMDR_REQUIRE(nmaps >= 1 && nmaps <= 3, "nmaps must be 1..3");
+    CMDR_REQUIRE(siN && b_l, "siN / b_l is NULL");
+    bands_.emplace_back();
+    Band& B = bands_.back();
+    B.nside = nside;
+    B.lmax = lmax;
+    B.nmaps = nmaps;
+    B.mb_eff = mb_eff;
+    B.b_l.assign(b_l, b_l + (size_t)(lmax + 1) * nmaps);
+    if (wring) { B.wring.assign(wring, wring + 2 * nside); B.has_wring = true; }
+    const int64_t np = band_npix((int)bands_.size() - 1) * nmaps;
+    std::vector<double> mul(np);
+    for (int64_t i = 0; i < np; ++i) mul[i] = siN[i] * siN[i] * (sg_mask ? sg_mask[i] : 1.0);  // comm_N_rms_mod.f90:264-273
+    std::vector<double> s1(siN, siN + np);
+    if (sg_mask) for (int64_t i = 0; i < np; ++i) s1[i] *= sg_mask[i];                         // :304-313 (applied twice = once, mask is 0/1)
+    if (sg_mask) B.siN_raw.upload(siN, (size_t)np);
+    B.siN.upload(s1);
+    B.mul.upload(mul);
+    return (int)bands_.size() - 1;
+}
+
+int CrSystem::add_comp(int lmax_amp, int nmaps, int lmax_cl, const double* sqrtS, const double* sqrtInvS,
+                       const double* S, const double* F_mean, int active) {
+    CMDR_REQUIRE(!finalized_, "add_comp after finalize");
+    CMDR_REQUIRE(!bands_.empty(), "add bands first");
+    CMDR_REQUIRE(nmaps >= 1 && nmaps <= 3, "nmaps must be 1..3");
+    CMDR_REQUIRE(comps_.size() < 8, "at most 8 diffuse components");
+    CMDR_REQUIRE(F_mean, "F_mean is NULL");
+    comps_.emplace_back();
+    Comp& C = comps_.back();
+    C.d.lmax = lmax_amp;
+    C.d.nmaps = nmaps;
+    C.d.nalm = nalm_packed(lmax_amp);
+    C.d.lmax_cl = lmax_cl;
+    C.d.active = active ? 1 : 0;
+    C.d.pos = 0;
+    C.d.smat_off = 0;
+    if (lmax_cl >= 0) {
+        CMDR_REQUIRE(sqrtS && sqrtInvS && S, "S tables are NULL");
+        const size_t n = (size_t)nmaps * nmaps * (lmax_cl + 1);
+        C.sqrtS.assign(sqrtS, sqrtS + n);
+        C.sqrtInvS.assign(sqrtInvS, sqrtInvS + n);
+        C.S.assign(S, S + n);
+    }
+    C.F_mean.assign(F_mean, F_mean + (size_t)bands_.size() * nmaps);
+    return (int)comps_.size() - 1;
+}
+
+void CrSystem::finalize() {
+    CMDR_REQUIRE(!finalized_, "finalize called twice");
+    CMDR_REQUIRE(!bands_.empty() && !comps_.empty(), "need at least one band and one component");
+    // stacked vector: comm_signal_mod.f90:113-125, comm_cr_mod.f90:467-501
+    int64_t pos = 0;
+    std::vector<double> smat;
+    lmax_max_ = -1;
+    for (Comp& C : comps_) {
+        C.d.pos = pos;
+        pos += C.d.nalm * C.d.nmaps;
+        C.d.smat_off = (long long)smat.size();
+        smat.insert(smat.end(), C.sqrtS.begin(), C.sqrtS.end());
+        smat.insert(smat.end(), C.sqrtInvS.begin(), C.sqrtInvS.end());
+        smat.insert(smat.end(), C.S.begin(), C.S.end());
+        lmax_max_ = std::max(lmax_max_, C.d.lmax);
+    }
+    ncr_ = pos;
+    std::vector<CompDev> cd;
+    for (Comp& C : comps_) cd.push_back(C.d);
+    comps_dev_.upload(cd);
+    if (smat.empty()) smat.push_back(0.0);
+    smat_.upload(smat);
+    // groups of bands sharing one SHT plan
+    const int ncomp = (int)comps_.size();
+    for (int b = 0; b < (int)bands_.size(); ++b) {
+        Band& B = bands_[b];
+        int g = -1;
+        for (int k = 0; k < (int)groups_.size(); ++k)
+            if (groups_[k].nside == B.nside && groups_[k].lmax == B.lmax) {
+                const Band& B0 = bands_[groups_[k].bands[0]];
+                if (B0.has_wring == B.has_wring && B0.wring == B.wring) g = k;
+            }
+        if (g < 0) {
+            groups_.emplace_back();
+            g = (int)groups_.size() - 1;
+            groups_[g].nside = B.nside;
+            groups_[g].lmax = B.lmax;
+        }
+        Group& G = groups_[g];
+        B.group = -1;  // assigned after the plan exists (band_npix uses it)
+        B.bm0 = G.nbm;
+        G.bands.push_back(b);
+        for (int j = 0; j < B.nmaps; ++j) { G.bm_band.push_back(b); G.bm_stokes.push_back(j); }
+        G.nbm += B.nmaps;
+    }
+    for (int g = 0; g < (int)groups_.size(); ++g) {
+        Group& G = groups_[g];
+        std::vector<int> rings;
+        for (auto& rs : ring_sets_) if (rs.first == G.nside) rings = rs.second;
+        const Band& B0 = bands_[G.bands[0]];
+        G.plan = std::make_unique<ShtPlan>(G.nside, G.lmax, rings, B0.has_wring ? B0.wring.data() : nullptr, G.nbm);
+        const int64_t np = G.plan->npix_local();
+        std::vector<double> w((size_t)G.nbm * ncomp * (G.lmax + 1), 0.0);
+        std::vector<const double*> mp(G.nbm);
+        for (int bm = 0; bm < G.nbm; ++bm) {
+            const int b = G.bm_band[bm], j = G.bm_stokes[bm];
+            Band& B = bands_[b];
+            CMDR_REQUIRE((int64_t)B.siN.size() == np * B.nmaps, "siN size does not match the plan's local map");
+            mp[bm] = B.mul.get() + (int64_t)j * np;
+            for (int c = 0; c < ncomp; ++c) {
+                const Comp& C = comps_[c];
+                if (!C.d.active || j >= C.d.nmaps) continue;
+                const double F = C.F_mean[b + (size_t)bands_.size() * j];
+                for (int l = 0; l <= std::min(G.lmax, C.d.lmax); ++l)
+                    w[((size_t)bm * ncomp + c) * (G.lmax + 1) + l] = F * B.b_l[l + (size_t)(B.lmax + 1) * j] * B.mb_eff;
+            }
+        }
+        G.w.upload(w);
+        G.bm_stokes_dev.upload(G.bm_stokes);
+        G.mul_ptrs.upload(mp);
+        for (int b : G.bands) bands_[b].group = g;
+    }
+    sx_.alloc(ncr_); yc_.alloc(ncr_); r_.alloc(ncr_); d_.alloc(ncr_); q_.alloc(ncr_); s_.alloc(ncr_); tmp_.alloc(ncr_);
+    dot_partial_.alloc(dot_partial_count());
+    scal_.alloc(16);
+    scal_.zero(stream_);
+    sync();
+    finalized_ = true;
+}
+
+void CrSystem::reduce(double* v, int64_t n) {
+    if (!allreduce_) return;
+    sync();
+    allreduce_(allreduce_user_, v, n);
+}
+
+// ------------------------------------------------------------------------------------------------- matvec
+void CrSystem::adjoint_groups_to_yc(bool /*from_maps*/) {
+    const int ncomp = (int)comps_.size();
+    for (int g = 0; g < (int)groups_.size(); ++g) {
+        Group& G = groups_[g];
+        ShtPlan& P = *G.plan;
+        span_begin(2);
+        P.adjoint_to_partials(G.nbm, false, stream_);
+        span_end();
+        launch_band_post(comps_dev_.get(), ncomp, lmax_max_, P.partials(), P.part_map_stride(), P.leg().tri_elems(),
+                         P.leg().nchunk, G.nbm, G.bm_stokes_dev.get(), G.w.get(), P.leg().cnorm.get(), G.lmax,
+                         yc_.get(), g > 0, stream_);
+    }
+    reduce(yc_.get(), ncr_);
+}
+
+void CrSystem::matmulA(const double* x, double* y) {
+    CMDR_REQUIRE(finalized_, "finalize first");
+    const int ncomp = (int)comps_.size();
+    span_begin(3);
+    // sqrtS_x = S^1/2 x  (comm_cr_mod.f90:792-836)
+    launch_sqrtS(comps_dev_.get(), ncomp, lmax_max_, smat_.get(), 0, x, nullptr, sx_.get(), false, stream_);
+    for (Group& G : groups_) {   // per-band loop :843-954, all bands of a geometry batched
+        ShtPlan& P = *G.plan;
+        launch_band_prep(comps_dev_.get(), ncomp, sx_.get(), G.w.get(), G.bm_stokes_dev.get(), P.stream(),
+                         P.leg().tri_elems(), P.leg().cnorm.get(), G.lmax, G.nbm, stream_);
+        span_begin(0);
+        P.synth_from_stream(G.nbm, stream_);                                         // Y        :891
+        span_end();
+        span_begin(1);
+        P.rings(2, nullptr, 0, G.mul_ptrs.get(), false, G.nbm, stream_);             // N^-1 :905 fused with both FFTs
+        span_end();
+    }
+    adjoint_groups_to_yc(false);                                                     // Yt :915, projectBand :920-948
+    // y = S^1/2 yc + x  (:957-1008)
+    launch_sqrtS(comps_dev_.get(), ncomp, lmax_max_, smat_.get(), 0, yc_.get(), x, y, false, stream_);
+    span_end();
+}
+
+// ------------------------------------------------------------------------------------------------- RHS
+void CrSystem::compute_rhs(bool sample, const double* const* resid, const double* const* xi, const double* eta,
+                           const double* mu, double* rhs) {
+    CMDR_REQUIRE(finalized_, "finalize first");
+    const int ncomp = (int)comps_.size();
+    for (Group& G : groups_) {
+        ShtPlan& P = *G.plan;
+        const int64_t np = P.npix_local();
+        G.tmpmap.ensure((size_t)G.nbm * np);
+        for (int bm = 0; bm < G.nbm; ++bm) {
+            const int b = G.bm_band[bm], j = G.bm_stokes[bm];
+            const Band& B = bands_[b];
+            const double* dmap = resid[b] + (int64_t)j * np;
+            double* out = G.tmpmap.get() + (int64_t)bm * np;
+            if (sample)  // sqrtInvN, + xi, sqrtInvN  (comm_cr_mod.f90:600-609)
+                launch_pix(1, B.siN.get() + (int64_t)j * np, dmap, xi[b] + (int64_t)j * np, out, np, stream_);
+            else         // invN (:611)
+                launch_pix(0, B.mul.get() + (int64_t)j * np, dmap, nullptr, out, np, stream_);
+        }
+        P.rings(1, G.tmpmap.get(), np, nullptr, false, G.nbm, stream_);              // Yt :615
+    }
+    adjoint_groups_to_yc(true);                                                      // beam, F_mean :616-639
+    // rhs = S^1/2 yc + eta + S^-1/2 mu   (:652-659, :690-728)
+    const double* add = nullptr;
+    if (mu) {
+        launch_sqrtS(comps_dev_.get(), ncomp, lmax_max_, smat_.get(), 1, mu, sample ? eta : nullptr, tmp_.get(), false,
+                     stream_);
+        add = tmp_.get();
+    } else if (sample) {
+        add = eta;
+    }
+    launch_sqrtS(comps_dev_.get(), ncomp, lmax_max_, smat_.get(), 0, yc_.get(), add, rhs, false, stream_);
+}
+
+// ------------------------------------------------------------------------------------------------- preconditioner
+namespace {
+// invert_matrix_with_mask (math_tools.f90:406-456) for a small dense block, Gauss-Jordan with partial pivoting
+void invert_with_mask(std::vector<double>& A, int n) {
+    std::vector<char> mask(n, 1);
+    for (int i = 0; i < n; ++i)
+        if (std::fabs(A[i * n + i]) <= 0.0) { mask[i] = 0; A[i * n + i] = 1.0; }
+    std::vector<double> I(n * n, 0.0);
+    for (int i = 0; i < n; ++i) I[i * n + i] = 1.0;
+    for (int c = 0; c < n; ++c) {
+        int piv = c;
+        for (int r = c + 1; r < n; ++r) if (std::fabs(A[r * n + c]) > std::fabs(A[piv * n + c])) piv = r;
+        if (A[piv * n + c] == 0.0) throw Error("singular preconditioner block");
+        if (piv != c) for (int k = 0; k < n; ++k) { std::swap(A[c * n + k], A[piv * n + k]); std::swap(I[c * n + k], I[piv * n + k]); }
+        const double inv = 1.0 / A[c * n + c];
+        for (int k = 0; k < n; ++k) { A[c * n + k] *= inv; I[c * n + k] *= inv; }
+        for (int r = 0; r < n; ++r) {
+            if (r == c) continue;
+            const double f = A[r * n + c];
+            if (f == 0.0) continue;
+            for (int k = 0; k < n; ++k) { A[r * n + k] -= f * A[c * n + k]; I[r * n + k] -= f * I[c * n + k]; }
+        }
+    }
+    A = I;
+    for (int i = 0; i < n; ++i) if (!mask[i]) A[i * n + i] = 0.0;
+}
+}  // namespace
+
+void CrSystem::precond_init_diag() {
+    CMDR_REQUIRE(finalized_, "finalize first");
+    const int nband = (int)bands_.size(), npre = (int)comps_.size();
+    // ---- invN_diag per band: compute_invN_lm (comm_N_mod.f90:127-197) as an exact Gauss-Legendre quadrature of
+    //      Npix/4pi * Int |Y_lm|^2 g dOmega, g = sum_{l'<=lmax} a_l'0 Y_l'0, a = YtW(siN^2)  (:134)
+    std::map<int, std::unique_ptr<LegendreDev>> glplans;
+    std::map<int, std::pair<std::vector<double>, std::vector<double>>> glnodes;
+    for (int b = 0; b < nband; ++b) {
+        Band& B = bands_[b];
+        Group& G = groups_[B.group];
+        ShtPlan& P = *G.plan;
+        const int lmax = B.lmax;
+        const int64_t np = P.npix_local(), na = nalm_packed(lmax);
+        const int ng = (3 * lmax) / 2 + 2, nhalf = (ng + 1) / 2;
+        if (!glplans.count(lmax)) {
+            std::vector<double> gx, gw;
+            gauss_legendre(ng, gx, gw);
+            std::vector<double> x(nhalf), sth(nhalf);
+            for (int k = 0; k < nhalf; ++k) { x[k] = std::max(gx[k], 0.0); sth[k] = std::sqrt((1.0 - x[k]) * (1.0 + x[k])); }
+            LegendreTables T;
+            T.build(lmax, x, sth, nhalf >= 1024 ? 4 : (nhalf >= 256 ? 2 : 1));
+            auto L = std::make_unique<LegendreDev>();
+            L->upload(T);
+            glplans[lmax] = std::move(L);
+            glnodes[lmax] = {gx, gw};
+        }
+        LegendreDev& L = *glplans[lmax];
+        const auto& gx = glnodes[lmax].first;
+        const auto& gw = glnodes[lmax].second;
+        DevBuf<double> siN2(np), alm(na), ph((size_t)L.ph_elems()), part((size_t)L.nchunk * L.tri_elems());
+        DevBuf<double> wn(L.npair_pad), ws(L.npair_pad);
+        part.zero(stream_);
+        B.invN_diag.alloc((size_t)na * B.nmaps);
+        B.invN_diag_h.assign((size_t)na * B.nmaps, 0.0);
+        for (int j = 0; j < B.nmaps; ++j) {
+            const double* sraw = (B.siN_raw.size() ? B.siN_raw.get() : B.siN.get()) + (int64_t)j * np;
+            launch_pix(0, sraw, sraw, nullptr, siN2.get(), np, stream_);   // invN_diag%map = siN**2 (comm_N_rms_mod.f90:217)
+            P.map2alm(siN2.get(), np, alm.get(), na, 1, true, stream_);
+            reduce(alm.get(), na);
+            std::vector<double> al0(lmax + 1);
+            sync();
+            CMDR_HIP_CHECK(hipMemcpy(al0.data(), alm.get(), sizeof(double) * (lmax + 1), hipMemcpyDeviceToHost));
+            // g(theta_k) and node weights
+            std::vector<double> g(ng);
+            for (int k = 0; k < ng; ++k) {
+                const double x = gx[k];
+                double lp = 0.0, lc = std::sqrt(1.0 / (4.0 * kPi)), sacc = 0.0;
+                for (int l = 0;; ++l) {
+                    sacc += al0[l] * lc;
+                    if (l == lmax) break;
+                    const double dl = l, dl1 = l + 1;
+                    const double e0 = std::sqrt(dl * dl / (4.0 * dl * dl - 1.0));
+                    const double e1 = std::sqrt(dl1 * dl1 / (4.0 * dl1 * dl1 - 1.0));
+                    const double ln = (x * lc - e0 * lp) / e1;
+                    lp = lc;
+                    lc = ln;
+                }
+                g[k] = sacc;
+            }
+            const double npix_full = 12.0 * B.nside * (double)B.nside;
+            std::vector<double> hwn(L.npair_pad, 0.0), hws(L.npair_pad, 0.0);
+            for (int k = 0; k < nhalf; ++k) {
+                const int ks = ng - 1 - k;
+                const double f = 2.0 * kPi * npix_full / (4.0 * kPi);
+                hwn[k] = gw[k] * g[k] * f;
+                hws[k] = (ks != k) ? gw[ks] * g[ks] * f : 0.0;
+            }
+            wn.upload(hwn, stream_);
+            ws.upload(hws, stream_);
+            launch_fill_gl(ph.get(), wn.get(), ws.get(), L.npair_pad, lmax, stream_);
+            launch_leg_adj(L.args(), L.tasks.get(), L.ntasks, ph.get(), L.ph_elems(), part.get(),
+                           (int64_t)L.nchunk * L.tri_elems(), L.tri_elems(), 1, true, stream_);
+            launch_part_to_diag(part.get(), L.tri_elems(), L.nchunk, L.cnorm.get(), B.invN_diag.get() + (int64_t)j * na,
+                                lmax, stream_);
+        }
+        sync();
+        CMDR_HIP_CHECK(hipMemcpy(B.invN_diag_h.data(), B.invN_diag.get(), sizeof(double) * na * B.nmaps,
+                                 hipMemcpyDeviceToHost));
+    }
+    // ---- M0 = sum_bands invN_diag * b_l^2 * F F   (initDiffPrecond_diagonal, comm_diffuse_comp_mod.f90:1199-1230)
+    lmax_pre_ = -1;
+    nmaps_pre_ = 0;
+    for (const Comp& C : comps_) { lmax_pre_ = std::max(lmax_pre_, C.d.lmax); nmaps_pre_ = std::max(nmaps_pre_, C.d.nmaps); }
+    const int64_t nt = ntri(lmax_pre_);
+    M0_.assign((size_t)nmaps_pre_ * npre * npre * nt, 0.0);
+    for (int j = 0; j < nmaps_pre_; ++j)
+        for (int q = 0; q < nband; ++q) {
+            const Band& B = bands_[q];
+            if (j >= B.nmaps) continue;
+            const int64_t na = nalm_packed(B.lmax);
+            for (int m = 0; m <= std::min(lmax_pre_, B.lmax); ++m)
+                for (int l = m; l <= std::min(lmax_pre_, B.lmax); ++l) {
+                    const int64_t t = moff(lmax_pre_, m) + (l - m);
+                    const int64_t i2 = mind(B.lmax, m) + (m == 0 ? l : 2 * (l - m));
+                    const double bl = B.b_l[l + (size_t)(B.lmax + 1) * j];
+                    const double base = B.invN_diag_h[i2 + (size_t)na * j] * bl * bl;
+                    for (int k1 = 0; k1 < npre; ++k1) {
+                        const Comp& p1 = comps_[k1];
+                        if (l > p1.d.lmax || j >= p1.d.nmaps) continue;
+                        for (int k2 = 0; k2 < npre; ++k2) {
+                            const Comp& p2 = comps_[k2];
+                            if (l > p2.d.lmax || j >= p2.d.nmaps) continue;
+                            M0_[(((size_t)j * npre + k1) * npre + k2) * nt + t] +=
+                                base * p1.F_mean[q + (size_t)nband * j] * p2.F_mean[q + (size_t)nband * j];
+                        }
+                    }
+                }
+        }
+    precond_ready_ = false;
+}
+
+void CrSystem::precond_update_diag() {
+    CMDR_REQUIRE(!M0_.empty(), "precond_init_diag first");
+    const int npre = (int)comps_.size();
+    const int64_t nt = ntri(lmax_pre_);
+    std::vector<double> P((size_t)nmaps_pre_ * npre * npre * nt, 0.0);
+    host_parallel_for(lmax_pre_ + 1, [&](int m) {
+        std::vector<double> M;
+        std::vector<int> idx;
+        for (int j = 0; j < nmaps_pre_; ++j)
+            for (int l = m; l <= lmax_pre_; ++l) {
+                const int64_t t = moff(lmax_pre_, m) + (l - m);
+                auto at = [&](std::vector<double>& V, int k1, int k2) -> double& {
+                    return V[(((size_t)j * npre + k1) * npre + k2) * nt + t];
+                };
+                idx.clear();
+                for (int k = 0; k < npre; ++k) if (at(M0_, k, k) > 0.0) idx.push_back(k);   // comp2ind :1232-1239
+                for (int k = 0; k < npre; ++k) at(P, k, k) = 1.0;                             // absent: pass through
+                const int n = (int)idx.size();
+                if (n == 0) continue;
+                M.assign((size_t)n * n, 0.0);
+                for (int a = 0; a < n; ++a) for (int b = 0; b < n; ++b) M[a * n + b] = at(M0_, idx[a], idx[b]);
+                for (int a = 0; a < n; ++a) {                                                 // S^1/2 (diag) both sides :1352-1424
+                    const Comp& C = comps_[idx[a]];
+                    if (C.d.lmax_cl < 0) continue;
+                    double dsc = 0.0;
+                    if (l <= C.d.lmax_cl && j < C.d.nmaps)
+                        dsc = std::sqrt(C.S[j + (size_t)C.d.nmaps * (j + (size_t)C.d.nmaps * l)]);
+                    for (int b = 0; b < n; ++b) { M[a * n + b] *= dsc; M[b * n + a] *= dsc; }
+                }
+                if (only_pol_ && j == 0) std::fill(M.begin(), M.end(), 0.0);                  // :1428-1433
+                for (int a = 0; a < n; ++a) {                                                 // add unity :1452-1470
+                    const Comp& C = comps_[idx[a]];
+                    if (C.d.lmax_cl < 0) continue;
+                    if (l <= C.d.lmax) M[a * n + a] += 1.0;
+                }
+                for (int a = 0; a < n; ++a) {                                                 // inactive comps :1484-1495
+                    if (comps_[idx[a]].d.active) continue;
+                    for (int b = 0; b < n; ++b) { M[a * n + b] = 0.0; M[b * n + a] = 0.0; }
+                }
+                bool any = false;
+                for (double v : M) if (v != 0.0) { any = true; break; }
+                if (any) invert_with_mask(M, n);                                              // :1539-1551
+                for (int a = 0; a < n; ++a) {
+                    at(P, idx[a], idx[a]) = 0.0;
+                    for (int b = 0; b < n; ++b) at(P, idx[a], idx[b]) = M[a * n + b];
+                }
+            }
+    });
+    P_.upload(P, stream_);
+    precond_ready_ = true;
+}
+
+void CrSystem::invM(const double* x, double* y) {
+    CMDR_REQUIRE(precond_ready_, "preconditioner not initialised (precond_init_diag + precond_update_diag)");
+    launch_precond_diag(comps_dev_.get(), (int)comps_.size(), P_.get(), lmax_pre_, nmaps_pre_, x, y, stream_);
+}
+
+// ------------------------------------------------------------------------------------------------- PCG
+SolveResult CrSystem::solve(const double* b, double* x, int crit, double tol, int miniter, int maxiter,
+                            int check_freq, const double* x0) {
+    CMDR_REQUIRE(finalized_ && precond_ready_, "system / preconditioner not ready");
+    CMDR_REQUIRE(check_freq >= 1, "check_freq must be >= 1");
+    const bool fixed_iter = (crit == 1);
+    const int ncomp = (int)comps_.size();
+    const int64_t n = ncr_;
+    double* scal = scal_.get();      // [0] delta_new [1] delta_old [2] d.q [3] delta0
+    SolveResult R;
+    if (!x0) {                                                                          // :133-134
+        CMDR_HIP_CHECK(hipMemsetAsync(x, 0, n * sizeof(double), stream_));
+        CMDR_HIP_CHECK(hipMemcpyAsync(r_.get(), b, n * sizeof(double), hipMemcpyDeviceToDevice, stream_));  // r = b - A 0
+    } else {                                                                            // :136-173
+        launch_sqrtS(comps_dev_.get(), ncomp, lmax_max_, smat_.get(), 1, x0, nullptr, x, true, stream_);
+        matmulA(x, q_.get());
+        launch_axpby(b, q_.get(), -1.0, r_.get(), n, stream_);                           // :201
+    }
+    invM(r_.get(), d_.get());                                                           // :203
+    launch_dot(r_.get(), d_.get(), n, dot_partial_.get(), scal, 0, false, stream_);     // :206
+    invM(b, tmp_.get());
+    launch_dot(b, tmp_.get(), n, dot_partial_.get(), scal, 3, false, stream_);          // :208
+    double h[4];
+    auto fetch = [&]() {
+        sync();
+        CMDR_HIP_CHECK(hipMemcpy(h, scal, sizeof(h), hipMemcpyDeviceToHost));
+    };
+    fetch();
+    R.delta0 = h[3];
+    const double lim = tol * h[3];                                                      // :220-222
+    int i = 1;
+    for (; i <= maxiter; ++i) {                                                         // :230
+        if (i % check_freq == 0 && !fixed_iter) {                                       // :236-247
+            fetch();
+            const double val = h[0];
+            if (val < lim && (i >= miniter || h[0] <= 1e-30 * h[3])) break;
+        }
+        matmulA(d_.get(), q_.get());                                                    // :253
+        launch_dot(d_.get(), q_.get(), n, dot_partial_.get(), scal, 2, false, stream_); // :254
+        launch_cg_xr(x, r_.get(), d_.get(), q_.get(), n, scal, 0, 2, stream_);          // :255,:261
+        invM(r_.get(), s_.get());                                                       // :266
+        launch_dot(r_.get(), s_.get(), n, dot_partial_.get(), scal, 0, true, stream_);  // :269-270
+        launch_cg_d(d_.get(), s_.get(), n, scal, 0, 1, stream_);                        // :271-272
+        R.niter = i;
+    }
+    // x <- S^1/2 x  (:350-389)
+    launch_sqrtS(comps_dev_.get(), ncomp, lmax_max_, smat_.get(), 0, x, nullptr, tmp_.get(), true, stream_);
+    CMDR_HIP_CHECK(hipMemcpyAsync(x, tmp_.get(), n * sizeof(double), hipMemcpyDeviceToDevice, stream_));
+    fetch();
+    R.delta_new = h[0];
+    if (i >= maxiter && !fixed_iter) R.stat = 1;                                        // :392-395
+    CMDR_HIP_CHECK(hipGetLastError());
+    return R;
+}
+
+}  // namespace cmdr

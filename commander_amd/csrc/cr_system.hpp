@@ -1,0 +1,130 @@
+// The constrained-realization linear system on the device: what commander3/src/comm_cr_mod.f90 does per Gibbs
+// amplitude sample, with every vector resident in HBM (persistent workspaces; the reference allocates and frees
+// its temporaries on every call, comm_cr_mod.f90:847-848,952-953).
+//
+//   A = 1 + S^1/2 [ sum_bands F^T B^T Y^T N^-1 Y B F ] S^1/2        cr_matmulA        comm_cr_mod.f90:771-1024
+//   b = S^1/2 sum_bands F^T B^T Y^T (N^-1 d | N^-1/2 (N^-1/2 d + xi)) + eta (+ S^-1/2 mu)   cr_computeRHS :542-769
+//   M^-1 = block-diagonal in (l, m, stokes) over components        cr_invM :1026-1077, diagonal type
+//   PCG (Shewchuk form)                                            solve_cr_eqn_by_CG :48-406
+//
+// Scope: diffuse components with constant mixing (F_mean fast path, comm_diffuse_comp_mod.f90:2077-2080), white
+// per-pixel noise (comm_N_rms), spin-0 columns.
+#pragma once
+#include <memory>
+#include <vector>
+
+#include "common.hpp"
+#include "kernels.hpp"
+#include "sht_plan.hpp"
+
+namespace cmdr {
+
+// In-place sum over ranks of a device vector (ring / band sharding across GPUs).  Called on the host thread with
+// the library stream idle; must return with the result complete.  The host language supplies it
+// (torch.distributed / RCCL in bench.py, MPI in the Fortran driver).
+using AllreduceFn = void (*)(void* user, double* dev_ptr, int64_t n);
+
+struct SolveResult {
+    int niter = 0;
+    int stat = 0;
+    double delta_new = 0.0, delta0 = 0.0;
+};
+
+class CrSystem {
+  public:
+    explicit CrSystem(int device);
+    ~CrSystem();
+
+    void set_rings(int nside, const std::vector<int>& rings);  // multi-GPU ring subset for bands of this nside
+    int add_band(int nside, int lmax, int nmaps, const double* siN, const double* b_l, double mb_eff,
+                 const double* sg_mask, const double* wring);
+    int add_comp(int lmax_amp, int nmaps, int lmax_cl, const double* sqrtS, const double* sqrtInvS,
+                 const double* S, const double* F_mean, int active);
+    void finalize();
+    void set_allreduce(AllreduceFn fn, void* user) { allreduce_ = fn; allreduce_user_ = user; }
+    void set_only_pol(bool v) { only_pol_ = v; }
+
+    int64_t ncr() const { return ncr_; }
+    int nband() const { return (int)bands_.size(); }
+    int64_t band_npix(int b) const;
+    int64_t band_nalm(int b) const { return nalm_packed(bands_[b].lmax) * bands_[b].nmaps; }
+    int band_nmaps(int b) const { return bands_[b].nmaps; }
+
+    void precond_init_diag();     // initDiffPrecond_diagonal + compute_invN_lm
+    void precond_update_diag();   // updateDiffPrecond_diagonal
+    const double* invN_diag_dev(int band) const { return bands_[band].invN_diag.get(); }
+
+    // all pointers below are device pointers
+    void matmulA(const double* x, double* y);
+    void invM(const double* x, double* y);
+    void compute_rhs(bool sample, const double* const* resid, const double* const* xi, const double* eta,
+                     const double* mu, double* rhs);
+    SolveResult solve(const double* b, double* x, int crit, double tol, int miniter, int maxiter, int check_freq,
+                      const double* x0);
+    void sync();
+    hipStream_t stream() const { return stream_; }
+    // HIP-event timing of the dominant kernels on the library stream (bench.py roofline leg).
+    // kinds: 0 Legendre synthesis, 1 fused ring stage, 2 Legendre adjoint, 3 whole matvec
+    void set_profile(bool on);
+    void read_profile(double* ms_sum, long long* count);   // [4] each; drains pending events
+    void problem_info(int64_t* out) const;
+
+  private:
+    struct Band {
+        int nside, lmax, nmaps, group = -1, bm0 = 0;
+        double mb_eff;
+        std::vector<double> b_l;            // (lmax+1) x nmaps, column-major
+        DevBuf<double> siN, mul;            // npix_local x nmaps: 1/rms (* samp-group mask), and siN^2 * mask
+        DevBuf<double> siN_raw;             // bare 1/rms, only kept when a samp-group mask was given
+        DevBuf<double> invN_diag;           // nalm x nmaps (device)
+        std::vector<double> invN_diag_h;
+        std::vector<double> wring;
+        bool has_wring = false;
+    };
+    struct Comp {
+        CompDev d;
+        std::vector<double> sqrtS, sqrtInvS, S;  // nmaps x nmaps x (lmax_cl+1), Fortran order
+        std::vector<double> F_mean;              // nband x nmaps, column-major (F_mean(band,0,stokes))
+    };
+    struct Group {
+        int nside, lmax, nbm = 0;
+        std::vector<int> bands, bm_band, bm_stokes;
+        std::unique_ptr<ShtPlan> plan;
+        DevBuf<double> w;                   // [nbm][ncomp][lmax+1]
+        DevBuf<int> bm_stokes_dev;
+        DevBuf<const double*> mul_ptrs;     // [nbm]
+        DevBuf<double> tmpmap;              // [nbm][npix_local] (RHS only; allocated lazily)
+    };
+    void adjoint_groups_to_yc(bool from_maps);
+    struct Span { hipEvent_t a, b; int kind; };
+    void span_begin(int kind);
+    void span_end();
+    std::vector<Span> spans_;
+    std::vector<int> open_;
+    double prof_ms_[4] = {0, 0, 0, 0};
+    long long prof_n_[4] = {0, 0, 0, 0};
+    void reduce(double* v, int64_t n);
+
+    int device_;
+    hipStream_t stream_ = nullptr;
+    std::vector<Band> bands_;
+    std::vector<Comp> comps_;
+    std::vector<Group> groups_;
+    std::vector<std::pair<int, std::vector<int>>> ring_sets_;
+    bool finalized_ = false, only_pol_ = false, profile_ = false;
+    int64_t ncr_ = 0;
+    int lmax_max_ = -1;
+    DevBuf<CompDev> comps_dev_;
+    DevBuf<double> smat_;
+    DevBuf<double> sx_, yc_, r_, d_, q_, s_, tmp_;
+    DevBuf<double> dot_partial_, scal_;
+    // diagonal preconditioner
+    int lmax_pre_ = -1, nmaps_pre_ = 0;
+    std::vector<double> M0_;                // [nmaps_pre][npre][npre][ntri(lmax_pre)]
+    DevBuf<double> P_;
+    bool precond_ready_ = false;
+    AllreduceFn allreduce_ = nullptr;
+    void* allreduce_user_ = nullptr;
+};
+
+}  // namespace cmdr

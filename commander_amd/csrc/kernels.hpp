@@ -4,6 +4,7 @@
 
 #include <cstdint>
 
+#include "cr_body.hpp"
 #include "kernels_body.hpp"
 #include "plan_tables.hpp"
 
@@ -22,5 +23,27 @@ void launch_alm_to_stream(const double* alm, int64_t alm_stride, double* ast, in
                           const double* cnorm, int lmax, int nmaps, hipStream_t s);
 void launch_part_to_alm(const double* part, int64_t pms, int64_t pcs, int nchunk, double* alm, int64_t alm_stride,
                         const double* cnorm, int lmax, int nmaps, hipStream_t s);
+
+// ---- CR solver streams (cr_kernels.hip)
+void launch_sqrtS(const CompDev* comps, int ncomp, int lmax_max, const double* smat, int kind, const double* in,
+                  const double* add, double* out, bool pass_inactive, hipStream_t s);
+void launch_band_prep(const CompDev* comps, int ncomp, const double* sx, const double* w, const int* bm_stokes,
+                      double* ast, int64_t ast_stride, const double* cnorm, int lmax_g, int nbm, hipStream_t s);
+void launch_band_post(const CompDev* comps, int ncomp, int lmax_max, const double* part, int64_t pms, int64_t pcs,
+                      int nchunk, int nbm, const int* bm_stokes, const double* w, const double* cnorm, int lmax_g,
+                      double* yc, bool accumulate, hipStream_t s);
+void launch_precond_diag(const CompDev* comps, int ncomp, const double* P, int lmax_pre, int nmaps_pre,
+                         const double* in, double* out, hipStream_t s);
+void launch_fill_gl(double* ph, const double* wn, const double* ws, int npair_pad, int lmax, hipStream_t s);
+void launch_part_to_diag(const double* part, int64_t pcs, int nchunk, const double* cnorm, double* out, int lmax,
+                         hipStream_t s);
+void launch_pix(int mode, const double* a, const double* b, const double* c, double* out, int64_t n, hipStream_t s);
+int dot_partial_count();
+void launch_dot(const double* a, const double* b, int64_t n, double* partial, double* scal, int slot, bool shift,
+                hipStream_t s);
+void launch_cg_xr(double* x, double* r, const double* d, const double* q, int64_t n, const double* scal, int num,
+                  int den, hipStream_t s);
+void launch_cg_d(double* d, const double* sv, int64_t n, const double* scal, int num, int den, hipStream_t s);
+void launch_axpby(const double* a, const double* b, double cb, double* out, int64_t n, hipStream_t s);
 
 }  // namespace cmdr

@@ -41,6 +41,35 @@ def _sig(L):
     L.cmdr_sht_npix.restype = c_i64
     L.cmdr_sht_execute.argtypes = [c_vp, c_int, c_int, pdp, pdp]
     L.cmdr_sht_execute_dev.argtypes = [c_vp, c_int, c_int, c_vp, c_i64, c_vp, c_i64]
+    pvp = ctypes.POINTER(c_vp)
+    c_dbl = ctypes.c_double
+    L.cmdr_ctx_create.argtypes = [c_int, pvp]
+    L.cmdr_ctx_destroy.argtypes = [c_vp]
+    L.cmdr_ctx_set_rings.argtypes = [c_vp, c_int, c_int, ip]
+    L.cmdr_ctx_set_allreduce.argtypes = [c_vp, c_vp, c_vp]
+    L.cmdr_ctx_set_only_pol.argtypes = [c_vp, c_int]
+    L.cmdr_band_add.argtypes = [c_vp, c_int, c_int, c_int, dp, dp, c_dbl, dp, dp]
+    L.cmdr_comp_add.argtypes = [c_vp, c_int, c_int, c_int, dp, dp, dp, dp, c_int]
+    L.cmdr_finalize.argtypes = [c_vp]
+    L.cmdr_ncr.argtypes = [c_vp]
+    L.cmdr_ncr.restype = c_i64
+    L.cmdr_band_npix.argtypes = [c_vp, c_int]
+    L.cmdr_band_npix.restype = c_i64
+    L.cmdr_precond_init_diag.argtypes = [c_vp]
+    L.cmdr_precond_update_diag.argtypes = [c_vp]
+    L.cmdr_get_invN_diag.argtypes = [c_vp, c_int, dp]
+    L.cmdr_matmulA.argtypes = [c_vp, dp, dp]
+    L.cmdr_invM.argtypes = [c_vp, dp, dp]
+    L.cmdr_matmulA_dev.argtypes = [c_vp, c_vp, c_vp]
+    L.cmdr_invM_dev.argtypes = [c_vp, c_vp, c_vp]
+    L.cmdr_compute_rhs.argtypes = [c_vp, c_int, pdp, pdp, dp, dp, dp]
+    L.cmdr_compute_rhs_dev.argtypes = [c_vp, c_int, pvp, pvp, c_vp, c_vp, c_vp]
+    pint = ctypes.POINTER(c_int)
+    L.cmdr_profile_enable.argtypes = [c_vp, c_int]
+    L.cmdr_profile_read.argtypes = [c_vp, dp, ctypes.POINTER(ctypes.c_longlong)]
+    L.cmdr_problem_info.argtypes = [c_vp, ctypes.POINTER(c_i64)]
+    L.cmdr_solve.argtypes = [c_vp, dp, dp, c_int, c_dbl, c_int, c_int, c_int, dp, pint, dp, pint]
+    L.cmdr_solve_dev.argtypes = [c_vp, c_vp, c_vp, c_int, c_dbl, c_int, c_int, c_int, c_vp, pint, dp, pint]
 
 
 def lib():
@@ -56,9 +85,17 @@ def lib():
     return _LIB
 
 
-def check(rc):
-    if rc != 0:
-        raise CmdrError(lib().cmdr_last_error().decode())
+def load(path):
+    """Load a library exporting the cmdr_* C ABI from an explicit path (tests use this for the host emulation)."""
+    L = ctypes.CDLL(path)
+    _sig(L)
+    return L
+
+
+def check(rc, L=None):
+    if rc < 0:
+        raise CmdrError((L or lib()).cmdr_last_error().decode())
+    return rc
 
 
 def device_count():

@@ -1,0 +1,111 @@
+"""Synthetic workloads for the CR solver (no real Planck data is available offline).
+
+Every value here is this build's own fixed choice so all sessions / ranks use identical inputs:
+  * CMB prior   D_l^TT = 1000 uK^2 flat (l >= 1), D_0 = D_1         (power_law type, comm_Cl_mod.f90:226-246)
+  * synchrotron D_l = 100 (l/80)^-2.5, constant beta = -3.1, nu_ref = 30 GHz  =>  F_mean = (nu/30)^-3.1
+  * Gaussian beams b_l = exp(-l(l+1) sigma^2/2)  (gaussbeam path, comm_utils.f90:91-92), no pixel window
+  * noise rms_p = sigma_0 (1 + 0.5 cos theta_p), sigma_0 from S/N = 1 at the beam scale; mask |cos theta| < sin 12 deg
+  * random numbers: counter-based Philox, master seed 163425 (tutorial/param_tutorial.txt:15), one sub-stream per
+    (kind, band|component), drawn in global RING / stacked order so results do not depend on the GPU count.
+"""
+import numpy as np
+
+from . import cl as _cl
+from . import healpix
+
+BASE_SEED = 163425
+
+PLANCK_NU = [30.0, 44.0, 70.0, 100.0, 143.0, 217.0, 353.0, 545.0, 857.0]
+PLANCK_FWHM = [32.3, 27.0, 13.2, 9.7, 7.3, 5.0, 4.9, 4.8, 4.6]
+
+CONFIGS = {
+    # BASELINE.json configs[0..2] (spin-0 / temperature)
+    "cfg1": dict(nside=64, lmax=128, nu=[70.0], fwhm=[60.0], comps=["cmb"]),
+    "cfg2": dict(nside=256, lmax=512, nu=[30.0, 70.0, 143.0], fwhm=[32.3, 13.2, 7.3], comps=["cmb", "synch"]),
+    "cfg3": dict(nside=1024, lmax=2000, nu=PLANCK_NU, fwhm=PLANCK_FWHM, comps=["cmb"]),
+}
+
+
+def gaussbeam(fwhm_arcmin, lmax):
+    sigma = np.radians(fwhm_arcmin / 60.0) / np.sqrt(8.0 * np.log(2.0))
+    l = np.arange(lmax + 1, dtype=np.float64)
+    return np.exp(-0.5 * l * (l + 1.0) * sigma * sigma)
+
+
+def rng(kind, index):
+    return np.random.Generator(np.random.Philox(key=BASE_SEED, counter=[0, 0, int(kind), int(index)]))
+
+
+def comp_Dl(name, lmax):
+    l = np.arange(lmax + 1, dtype=np.float64)
+    if name == "cmb":
+        D = np.full(lmax + 1, 1000.0)
+    elif name == "synch":
+        D = 100.0 * (np.maximum(l, 1.0) / 80.0) ** -2.5
+    else:
+        raise ValueError(name)
+    D[0] = D[1] if lmax >= 1 else D[0]
+    return D
+
+
+def make_problem(cfg, nside=None, lmax=None, comp_lmax=None, pixels=None):
+    """Problem spec dict consumed by ``commander_amd.cr.build_context`` (and by the tests' oracle builder).
+
+    pixels: optional full-sky RING indices of a rank's local map (ring sharding); maps are then local."""
+    c = dict(CONFIGS[cfg]) if isinstance(cfg, str) else dict(cfg)
+    nside = int(nside or c["nside"])
+    lmax = int(lmax or c["lmax"])
+    npix = 12 * nside * nside
+    z = healpix.pix_z(nside)
+    Dl_cmb = comp_Dl("cmb", lmax)
+    l = np.arange(lmax + 1, dtype=np.float64)
+    Cl_cmb = np.where(l > 0, Dl_cmb * 2.0 * np.pi / np.maximum(l * (l + 1.0), 1.0), Dl_cmb)
+    bands = []
+    for nu, fwhm in zip(c["nu"], c["fwhm"]):
+        b_l = gaussbeam(fwhm, lmax)
+        below = np.nonzero(b_l ** 2 < 0.5)[0]
+        l_half = int(below[0]) if below.size else lmax
+        l_star = max(1, min(l_half, int(0.75 * lmax)))
+        sigma0 = np.sqrt(Cl_cmb[l_star] * b_l[l_star] ** 2 * npix / (4.0 * np.pi))
+        rms = sigma0 * (1.0 + 0.5 * z)
+        siN = 1.0 / rms
+        siN[np.abs(z) < np.sin(np.radians(12.0))] = 0.0
+        if pixels is not None:
+            siN = siN[pixels]
+        bands.append(dict(nside=nside, lmax=lmax, nu=nu, fwhm=fwhm, siN=siN, b_l=b_l, mb_eff=1.0, sigma0=sigma0))
+    comps = []
+    for k, name in enumerate(c["comps"]):
+        cl_lmax = lmax if comp_lmax is None else int(comp_lmax[k])
+        sq, isq, S = _cl.update_S(comp_Dl(name, cl_lmax)[:, None], 1)
+        if name == "cmb":
+            F = np.ones(len(bands))
+        else:
+            F = np.array([(b["nu"] / 30.0) ** -3.1 for b in bands])
+        comps.append(dict(name=name, lmax=cl_lmax, nmaps=1, F_mean=F, sqrtS_mat=sq, sqrtInvS_mat=isq, S_mat=S,
+                          Dl=comp_Dl(name, cl_lmax), active=True))
+    return dict(bands=bands, comps=comps, nside=nside, lmax=lmax, pixels=pixels)
+
+
+def ncr_of(spec):
+    return sum((c["lmax"] + 1) ** 2 * c["nmaps"] for c in spec["comps"])
+
+
+def draw_inputs(spec):
+    """Residual maps d_nu = rms * xi_d (noise-only data; signal content does not change the operator or the cost),
+    RHS noise draws xi and prior draws eta, all unit Gaussians from fixed Philox sub-streams."""
+    nside = spec["nside"]
+    npix = 12 * nside * nside
+    pix = spec["pixels"]
+    resid, xi = [], []
+    for i, b in enumerate(spec["bands"]):
+        g = rng(1, i).standard_normal(npix)
+        z = healpix.pix_z(nside)
+        rms = b["sigma0"] * (1.0 + 0.5 * z)
+        d = rms * g
+        x = rng(2, i).standard_normal(npix)
+        if pix is not None:
+            d, x = d[pix], x[pix]
+        resid.append(d)
+        xi.append(x)
+    eta = rng(3, 0).standard_normal(ncr_of(spec))
+    return resid, xi, eta

@@ -62,6 +62,82 @@ int cmdr_sht_execute(cmdr_sht_plan* plan, int job, int nmaps, double* const* alm
 int cmdr_sht_execute_dev(cmdr_sht_plan* plan, int job, int nmaps, double* alm_dev, int64_t alm_stride,
                          double* map_dev, int64_t map_stride);
 
+/* ------------------------------------------------------------------------------------------------
+ * CR level: the constrained-realization system of commander3/src/comm_cr_mod.f90 for diffuse components with
+ * constant mixing (F_mean) and white per-pixel noise, spin-0 columns.  Call order:
+ *   cmdr_ctx_create -> [cmdr_ctx_set_rings] -> cmdr_band_add (every band, in data(i) order) ->
+ *   cmdr_comp_add (every diffuse component, in compList order) -> cmdr_finalize ->
+ *   cmdr_precond_init_diag -> cmdr_precond_update_diag -> cmdr_compute_rhs / cmdr_solve / cmdr_matmulA / cmdr_invM
+ * The stacked vector x(1:ncr) has exactly Commander's layout (comm_cr_mod.f90:467-501: components in list order,
+ * Stokes outer, packed a_lm inner).  Functions without a _dev suffix take HOST pointers and copy; _dev variants
+ * take DEVICE pointers (cmdr_dev_alloc) and leave every result in HBM.
+ */
+int cmdr_ctx_create(int device, cmdr_ctx** out);
+int cmdr_ctx_destroy(cmdr_ctx* ctx);
+/* Multi-GPU: restrict every band of this nside to the ring pairs led by these northern rings
+ * (Commander's own distribution, comm_map_mod.f90:197-221).  a_lm vectors stay replicated on every rank. */
+int cmdr_ctx_set_rings(cmdr_ctx* ctx, int nside, int nrings, const int* rings);
+/* In-place sum over ranks of n doubles at a DEVICE address; supplied by the host language (MPI in the Fortran
+ * driver, torch.distributed/RCCL in bench.py).  Called once per cr_matmulA / cr_computeRHS on the partial
+ * sum_bands(...) vector, replacing libsharp2's MPI exchange + mpi_dot_product's allreduce
+ * (comm_utils.f90:599-614). */
+typedef void (*cmdr_allreduce_fn)(void* user, double* dev_ptr, int64_t n);
+int cmdr_ctx_set_allreduce(cmdr_ctx* ctx, cmdr_allreduce_fn fn, void* user);
+int cmdr_ctx_set_only_pol(cmdr_ctx* ctx, int only_pol);
+
+/* data(i): comm_data_mod.f90:33-63.  siN = 1/rms (0 in masked pixels, comm_N_rms_mod.f90:179-193),
+ * [npix_local x nmaps]; b_l(0:lmax, nmaps) (comm_B_bl_mod.f90); sg_mask = samp_group_mask or NULL
+ * (comm_N_rms_mod.f90:264-313); wring[2*nside] or NULL.  Returns the 0-based band index (< 0 on error). */
+int cmdr_band_add(cmdr_ctx* ctx, int nside, int lmax, int nmaps, const double* siN, const double* b_l,
+                  double mb_eff, const double* sg_mask, const double* wring);
+/* One comm_diffuse_comp: lmax_amp, nmaps; lmax_cl < 0 means cltype == 'none'; sqrtS_mat / sqrtInvS_mat / S_mat are
+ * (nmaps, nmaps, 0:lmax_cl) as comm_Cl%updateS leaves them (comm_Cl_mod.f90:316-384); F_mean(numband, nmaps) is
+ * c%F_mean(:, 0, :) (comm_diffuse_comp_mod.f90:1991-1999); active = c%active_samp_group(samp_group).
+ * Returns the 0-based component index (< 0 on error). */
+int cmdr_comp_add(cmdr_ctx* ctx, int lmax_amp, int nmaps, int lmax_cl, const double* sqrtS_mat,
+                  const double* sqrtInvS_mat, const double* S_mat, const double* F_mean, int active);
+int cmdr_finalize(cmdr_ctx* ctx);
+int64_t cmdr_ncr(const cmdr_ctx* ctx);                    /* comm_cr_utils.f90:28 ncr */
+int64_t cmdr_band_npix(const cmdr_ctx* ctx, int band);    /* local pixels per Stokes column */
+
+/* initDiffPrecond_diagonal (comm_diffuse_comp_mod.f90:1167-1252) incl. compute_invN_lm (comm_N_mod.f90:127-197),
+ * then updateDiffPrecond_diagonal (:1313-1557). */
+int cmdr_precond_init_diag(cmdr_ctx* ctx);
+int cmdr_precond_update_diag(cmdr_ctx* ctx);
+/* copy out data(band)%N%invN_diag%alm (nalm x nmaps) -- for parity tests */
+int cmdr_get_invN_diag(cmdr_ctx* ctx, int band, double* out_host);
+
+int cmdr_matmulA(cmdr_ctx* ctx, const double* x, double* y);            /* cr_matmulA  comm_cr_mod.f90:771-1024 */
+int cmdr_invM(cmdr_ctx* ctx, const double* x, double* y);               /* cr_invM     comm_cr_mod.f90:1026-1077 */
+int cmdr_matmulA_dev(cmdr_ctx* ctx, const double* x_dev, double* y_dev);
+int cmdr_invM_dev(cmdr_ctx* ctx, const double* x_dev, double* y_dev);
+/* cr_computeRHS (comm_cr_mod.f90:542-769).  sample != 0: operation == 'sample'.
+ *   resid[i] : compute_residual(i) map of band i (comm_chisq_mod.f90:196-267), [npix_local x nmaps]
+ *   xi[i]    : the unit Gaussians the Fortran side drew for band i in its own order (:602-608); ignored if !sample
+ *   eta      : (ncr) unit Gaussians of the prior term in stacked order (:704-709), caller zeroes what only_pol skips
+ *   mu       : (ncr) prior mean amplitudes c%mu in stacked order, or NULL (:712-725) */
+int cmdr_compute_rhs(cmdr_ctx* ctx, int sample, const double* const* resid, const double* const* xi,
+                     const double* eta, const double* mu, double* rhs);
+int cmdr_compute_rhs_dev(cmdr_ctx* ctx, int sample, const double* const* resid_dev, const double* const* xi_dev,
+                         const double* eta_dev, const double* mu_dev, double* rhs_dev);
+/* solve_cr_eqn_by_CG (comm_cr_mod.f90:48-406).  crit: 0 'residual', 1 'fixed_iter' (cpar%cg_conv_crit);
+ * tol = cg_tol, miniter = cg_miniter, maxiter = cg_samp_group_maxiter, check_freq = cg_check_conv_freq;
+ * x0 = NULL <=> cg_init_zero, else the current amplitudes (cr_amp2x).  On return x is already multiplied by
+ * sqrt(S) (:350-389).  stat follows :392-395 (1 = not converged within maxiter; the caller may ignore it, as
+ * comm_signal_mod.f90:181 does).  res[0] = final r^T M^-1 r, res[1] = delta0 = b^T M^-1 b. */
+int cmdr_solve(cmdr_ctx* ctx, const double* b, double* x, int crit, double tol, int miniter, int maxiter,
+               int check_freq, const double* x0, int* niter, double* res, int* stat);
+int cmdr_solve_dev(cmdr_ctx* ctx, const double* b_dev, double* x_dev, int crit, double tol, int miniter,
+                   int maxiter, int check_freq, const double* x0_dev, int* niter, double* res, int* stat);
+
+/* HIP-event timing of the dominant kernels, on the stream they are launched on.  kinds: 0 Legendre synthesis
+ * launches, 1 fused ring-stage launches, 2 Legendre adjoint launches, 3 whole cr_matmulA.  ms_sum[4], count[4]. */
+int cmdr_profile_enable(cmdr_ctx* ctx, int on);
+int cmdr_profile_read(cmdr_ctx* ctx, double* ms_sum, long long* count);
+/* out[0] = number of (band, Stokes) maps, out[1] = wave tasks of the first plan, out[2] = total (ring pair, l, m)
+ * recursion steps one Legendre launch of the first plan performs for ONE map (algorithmic work, mlim-pruned) */
+int cmdr_problem_info(cmdr_ctx* ctx, int64_t* out);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,53 @@
+"""Generates the committed golden vectors of tests/golden/ (run from the repo root: python tests/golden/make_golden.py).
+
+Nothing upstream pins this path (the reference has no tests and no fixtures: SURVEY.md §4), so the goldens are
+produced by checkers that are independent of both the oracle's recursions/FFTs and the HIP kernels:
+  * sht_bruteforce_nside{4,8}.npz : dense direct sums over scipy.special.sph_harm_y (oracle/bruteforce.py)
+  * invn_diag_3j.npz              : compute_invN_lm evaluated literally with exact Racah-formula 3j symbols
+  * lm2i_tables.json              : Commander's a_lm index maps for lmax=4, P=1 and P=3 (comm_map_mod.f90:228-261)
+  * kat.json                      : the reference's own 2x2 PCG known-answer test and the fiducial dipole constants
+"""
+import json
+import os
+import sys
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.dirname(os.path.dirname(HERE)))
+
+from oracle import bruteforce, healpix, sht, wigner  # noqa: E402
+
+
+def main():
+    rng = np.random.default_rng(20261004)
+    for nside, lmax in [(4, 8), (8, 20)]:
+        B = bruteforce.basis_matrix(nside, lmax)
+        w = 1.0 + 0.05 * rng.standard_normal(2 * nside)
+        wp = bruteforce.ring_weight_per_pixel(nside, w)
+        a = rng.standard_normal((lmax + 1) ** 2)
+        m = rng.standard_normal(12 * nside * nside)
+        np.savez_compressed(os.path.join(HERE, "sht_bruteforce_nside%d.npz" % nside), nside=nside, lmax=lmax, wring=w,
+                            alm=a, map=m, Y=B @ a, Yt=B.T @ m, YtW=B.T @ (wp * m), WY=wp * (B @ a))
+    nside, lmax = 4, 12
+    siN2 = 1.0 + 0.5 * rng.random(12 * nside * nside)
+    al0 = sht.YtW(nside, lmax, siN2)[: lmax + 1]
+    np.savez_compressed(os.path.join(HERE, "invn_diag_3j.npz"), nside=nside, lmax=lmax, al0=al0,
+                        diag=wigner.invn_diag_3j(nside, lmax, al0))
+    tables = {}
+    for P in (1, 3):
+        for r in range(P):
+            info = healpix.AlmInfo(4, r, P)
+            tables["P%d_r%d" % (P, r)] = {"lm": info.lm.T.tolist(), "mind": info.mind.tolist(), "nalm": info.nalm}
+    json.dump(tables, open(os.path.join(HERE, "lm2i_tables.json"), "w"), indent=1)
+    kat = {
+        # commander3/todscripts/wmap/cg_solver.py:54-61
+        "pcg2x2": {"A": [[3, 2], [2, 6]], "b": [2, -8], "x": [2, -2]},
+        # commander3/src/comm_chisq_mod.f90:296-301 (uK, (l,m) = (1,-1),(1,0),(1,1))
+        "fiducial_dipole_uK": [-4.54107e3, 5.119744e3, 4.848587e2],
+    }
+    json.dump(kat, open(os.path.join(HERE, "kat.json"), "w"), indent=1)
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,196 @@
+// TEST INFRASTRUCTURE ONLY: host implementations of every launch_* entry of commander_amd/csrc/kernels.hpp as
+// plain loops over the shared kernel bodies (kernels_body.hpp, cr_body.hpp).  Linked with the real host code
+// (plan_tables.cpp, sht_plan.cpp, cr_system.cpp, c_api.cpp) into tests/host_emul/_build/libcmdr_emul.so so the
+// CPU-only test tier can check index maps, normalisations and the CR orchestration against the oracle.
+// Not a fallback: libcmdr_hip.so never contains or loads this.
+#include <algorithm>
+#include <vector>
+
+#include "kernels.hpp"
+
+namespace cmdr {
+
+template <int R>
+static void synth_R(const LegArgs& A, const WaveTask* tasks, int ntasks, const double* ast, double* ph) {
+    for (int t = 0; t < ntasks; ++t)
+        for (int lane = 0; lane < 64; ++lane)
+            leg_synth_lane<R>(A, ast, ph, tasks[t].m, tasks[t].chunk, tasks[t].lw, tasks[t].lAend, lane);
+}
+void launch_leg_synth(const LegArgs& A, const WaveTask* tasks, int ntasks, const double* ast, int64_t ast_stride,
+                      double* ph, int64_t ph_stride, int nmaps, hipStream_t) {
+    for (int k = 0; k < nmaps; ++k) {
+        if (A.R == 1) synth_R<1>(A, tasks, ntasks, ast + k * ast_stride, ph + k * ph_stride);
+        else if (A.R == 2) synth_R<2>(A, tasks, ntasks, ast + k * ast_stride, ph + k * ph_stride);
+        else synth_R<4>(A, tasks, ntasks, ast + k * ast_stride, ph + k * ph_stride);
+    }
+}
+
+template <int R, bool SQ>
+static void adj_R(const LegArgs& A, const WaveTask* tasks, int ntasks, const double* ph, double* part, int64_t pcs) {
+    const int lmax = A.lmax;
+    for (int ti = 0; ti < ntasks; ++ti) {
+        const WaveTask t = tasks[ti];
+        std::vector<AdjLane<R>> S(64);
+        for (int lane = 0; lane < 64; ++lane) leg_adj_load<R, SQ>(A, ph, t.m, t.chunk, lane, S[lane]);
+        const int64_t mo = d_moffp(lmax, t.m);
+        const double* al = A.alpha + (mo - t.m);
+        double* out = part + t.chunk * pcs + 2 * (mo - t.m);
+        for (int l0 = t.lw; l0 <= lmax; l0 += kAdjL_) {
+            double wl[16 * 65];
+            for (int lane = 0; lane < 64; ++lane) {
+                double v[16];
+                if (l0 < t.lAend) leg_adj_group<R, SQ, true>(A, al, l0, S[lane], v);
+                else leg_adj_group<R, SQ, false>(A, al, l0, S[lane], v);
+                for (int j = 0; j < 16; ++j) wl[j * 65 + lane] = v[j];
+            }
+            for (int col = 0; col < 16; ++col) {   // device order: quarter sums, then xor-16, xor-32 butterflies
+                double q[4];
+                for (int qt = 0; qt < 4; ++qt) {
+                    double s = 0.0;
+                    for (int i = 0; i < 16; ++i) s += wl[col * 65 + qt * 16 + i];
+                    q[qt] = s;
+                }
+                const double s = (q[0] + q[1]) + (q[2] + q[3]);
+                const int l = l0 + (col >> 1);
+                if (l <= lmax) out[2 * l + (col & 1)] = s;
+            }
+        }
+    }
+}
+void launch_leg_adj(const LegArgs& A, const WaveTask* tasks, int ntasks, const double* ph, int64_t ph_stride,
+                    double* part, int64_t pms, int64_t pcs, int nmaps, bool square, hipStream_t) {
+    for (int k = 0; k < nmaps; ++k) {
+        const double* p = ph + k * ph_stride;
+        double* o = part + k * pms;
+#define CMDR_E(RR) if (square) adj_R<RR, true>(A, tasks, ntasks, p, o, pcs); else adj_R<RR, false>(A, tasks, ntasks, p, o, pcs);
+        if (A.R == 1) { CMDR_E(1) } else if (A.R == 2) { CMDR_E(2) } else { CMDR_E(4) }
+#undef CMDR_E
+    }
+}
+
+void launch_ring(int mode, const RingDev* rings, const int* cls, int ncls, int log2M, double* ph,
+                 int64_t ph_stride, int64_t npair_pad, double* map, int64_t map_stride, const double* const* mul,
+                 int weighted, const cd* tw, int log2Mmax, const cd* chirp, int nmaps, hipStream_t) {
+    std::vector<cd> bufv((size_t)1 << log2M);
+    cd* buf = bufv.data();
+    const FftCtx c{0, 1};
+    for (int imap = 0; imap < nmaps; ++imap)
+        for (int ib = 0; ib < ncls; ++ib) {
+            const int pair = cls[ib];
+            const RingDev d = rings[pair];
+            double* php = ph + imap * ph_stride;
+            double* mp = map ? map + imap * map_stride : nullptr;
+            const double* mu = mul ? mul[imap] : nullptr;
+            const int n = d.nphi;
+            const double wg = weighted ? d.wgt : 1.0;
+            if (mode == 0 || mode == 2) ring_synth_lds(buf, d, php, npair_pad, pair, tw, log2Mmax, chirp, c);
+            if (mode == 0) {
+                for (int k = 0; k < n; ++k) {
+                    mp[d.startN + k] = buf[k].x * wg * (mu ? mu[d.startN + k] : 1.0);
+                    if (d.startS >= 0) mp[d.startS + k] = buf[k].y * wg * (mu ? mu[d.startS + k] : 1.0);
+                }
+                continue;
+            }
+            if (mode == 1)
+                for (int k = 0; k < n; ++k) {
+                    buf[k].x = mp[d.startN + k] * wg * (mu ? mu[d.startN + k] : 1.0);
+                    buf[k].y = d.startS >= 0 ? mp[d.startS + k] * wg * (mu ? mu[d.startS + k] : 1.0) : 0.0;
+                }
+            if (mode == 2)
+                for (int k = 0; k < n; ++k) {
+                    buf[k].x *= mu[d.startN + k];
+                    buf[k].y = d.startS >= 0 ? buf[k].y * mu[d.startS + k] : 0.0;
+                }
+            ring_anal_lds(buf, d, tw, log2Mmax, chirp, c);
+            ring_store_phases(buf, d, php, npair_pad, pair, c);
+        }
+}
+
+void launch_alm_to_stream(const double* alm, int64_t alm_stride, double* ast, int64_t ast_stride,
+                          const double* cnorm, int lmax, int nmaps, hipStream_t) {
+    for (int k = 0; k < nmaps; ++k)
+        for (int m = 0; m <= lmax; ++m)
+            for (int l = m; l <= lmax + 1; ++l)
+                alm_to_stream_elem(alm + k * alm_stride, ast + k * ast_stride, cnorm, lmax, m, l);
+}
+void launch_part_to_alm(const double* part, int64_t pms, int64_t pcs, int nchunk, double* alm, int64_t alm_stride,
+                        const double* cnorm, int lmax, int nmaps, hipStream_t) {
+    for (int k = 0; k < nmaps; ++k)
+        for (int m = 0; m <= lmax; ++m)
+            for (int l = m; l <= lmax; ++l)
+                part_to_alm_elem(part + k * pms, pcs, nchunk, alm + k * alm_stride, cnorm, lmax, m, l);
+}
+
+void launch_sqrtS(const CompDev* comps, int ncomp, int, const double* smat, int kind, const double* in,
+                  const double* add, double* out, bool pass_inactive, hipStream_t) {
+    for (int c = 0; c < ncomp; ++c)
+        for (int m = 0; m <= comps[c].lmax; ++m)
+            for (int l = m; l <= comps[c].lmax; ++l) sqrtS_elem(comps[c], smat, kind, in, add, out, m, l, pass_inactive);
+}
+void launch_band_prep(const CompDev* comps, int ncomp, const double* sx, const double* w, const int* bm_stokes,
+                      double* ast, int64_t ast_stride, const double* cnorm, int lmax_g, int nbm, hipStream_t) {
+    for (int bm = 0; bm < nbm; ++bm)
+        for (int m = 0; m <= lmax_g; ++m)
+            for (int l = m; l <= lmax_g + 1; ++l)
+                band_prep_elem(comps, ncomp, sx, w + (int64_t)bm * ncomp * (lmax_g + 1), bm_stokes[bm],
+                               ast + bm * ast_stride, cnorm, lmax_g, m, l);
+}
+void launch_band_post(const CompDev* comps, int ncomp, int, const double* part, int64_t pms, int64_t pcs,
+                      int nchunk, int nbm, const int* bm_stokes, const double* w, const double* cnorm, int lmax_g,
+                      double* yc, bool accumulate, hipStream_t) {
+    for (int c = 0; c < ncomp; ++c)
+        for (int m = 0; m <= comps[c].lmax; ++m)
+            for (int l = m; l <= comps[c].lmax; ++l)
+                band_post_elem(comps[c], c, ncomp, part, pms, pcs, nchunk, nbm, bm_stokes, w, cnorm, lmax_g, yc,
+                               accumulate ? 1 : 0, m, l);
+}
+void launch_precond_diag(const CompDev* comps, int ncomp, const double* P, int lmax_pre, int nmaps_pre,
+                         const double* in, double* out, hipStream_t) {
+    for (int m = 0; m <= lmax_pre; ++m)
+        for (int l = m; l <= lmax_pre; ++l) precond_diag_elem(comps, ncomp, P, lmax_pre, nmaps_pre, in, out, m, l);
+}
+void launch_fill_gl(double* ph, const double* wn, const double* ws, int npair_pad, int lmax, hipStream_t) {
+    for (int m = 0; m <= lmax; ++m)
+        for (int p = 0; p < npair_pad; ++p) {
+            double* o = ph + ((int64_t)m * npair_pad + p) * 4;
+            o[0] = wn[p]; o[1] = 0.0; o[2] = ws[p]; o[3] = 0.0;
+        }
+}
+void launch_part_to_diag(const double* part, int64_t pcs, int nchunk, const double* cnorm, double* out, int lmax,
+                         hipStream_t) {
+    for (int m = 0; m <= lmax; ++m)
+        for (int l = m; l <= lmax; ++l) {
+            const int64_t t = d_moffp(lmax, m) + (l - m);
+            double s = 0.0;
+            for (int c = 0; c < nchunk; ++c) s += part[c * pcs + 2 * t];
+            s *= cnorm[t] * cnorm[t];
+            const int64_t i = d_packed_index(lmax, l, m);
+            out[i] = s;
+            if (m > 0) out[i + 1] = s;
+        }
+}
+void launch_pix(int mode, const double* a, const double* b, const double* c, double* out, int64_t n, hipStream_t) {
+    for (int64_t i = 0; i < n; ++i) out[i] = mode == 0 ? a[i] * b[i] : a[i] * (a[i] * b[i] + c[i]);
+}
+int dot_partial_count() { return 1; }
+void launch_dot(const double* a, const double* b, int64_t n, double*, double* scal, int slot, bool shift,
+                hipStream_t) {
+    double s = 0.0;
+    for (int64_t i = 0; i < n; ++i) s += a[i] * b[i];
+    if (shift) scal[slot + 1] = scal[slot];
+    scal[slot] = s;
+}
+void launch_cg_xr(double* x, double* r, const double* d, const double* q, int64_t n, const double* scal, int num,
+                  int den, hipStream_t) {
+    const double alpha = scal[num] / scal[den];
+    for (int64_t i = 0; i < n; ++i) { x[i] += alpha * d[i]; r[i] -= alpha * q[i]; }
+}
+void launch_cg_d(double* d, const double* sv, int64_t n, const double* scal, int num, int den, hipStream_t) {
+    const double beta = scal[num] / scal[den];
+    for (int64_t i = 0; i < n; ++i) d[i] = sv[i] + beta * d[i];
+}
+void launch_axpby(const double* a, const double* b, double cb, double* out, int64_t n, hipStream_t) {
+    for (int64_t i = 0; i < n; ++i) out[i] = a[i] + cb * b[i];
+}
+
+}  // namespace cmdr

@@ -1,0 +1,52 @@
+"""CPU tier: the C-ABI library loads, exports every symbol include/*.h declares, and refuses to compute without a GPU
+(no silent CPU fallback).  No compute calls here."""
+import ctypes
+import glob
+import os
+import re
+
+import pytest
+
+from helpers import ROOT
+
+
+def declared_symbols():
+    syms = []
+    for h in glob.glob(os.path.join(ROOT, "include", "*.h")):
+        txt = re.sub(r"/\*.*?\*/", "", open(h).read(), flags=re.S)
+        syms += re.findall(r"\b((?:cmdr|sharp)_[a-z0-9_]+)\s*\(", txt)
+    return sorted(set(s for s in syms if not s.endswith("_fn")))
+
+
+def test_library_exports_every_declared_symbol():
+    from commander_amd import get_lib
+    L = get_lib()
+    missing = [s for s in declared_symbols() if not hasattr(L, s)]
+    assert not missing, missing
+    assert len(declared_symbols()) >= 30
+
+
+def test_no_cpu_fallback_without_gpu():
+    from commander_amd import get_lib, device_count, CmdrError
+    from commander_amd.cr import CRContext
+    from commander_amd import ShtPlan
+    if device_count() > 0:
+        pytest.skip("GPU present")
+    L = get_lib()
+    h = ctypes.c_void_p()
+    assert L.cmdr_ctx_create(0, ctypes.byref(h)) < 0
+    assert b"no CPU path" in L.cmdr_last_error()
+    with pytest.raises(CmdrError):
+        CRContext(0)
+    with pytest.raises(CmdrError):
+        ShtPlan(4, 8)
+
+
+def test_product_never_imports_oracle():
+    """The oracle is test infrastructure: nothing under commander_amd/ may import or link it."""
+    for path in glob.glob(os.path.join(ROOT, "commander_amd", "**", "*"), recursive=True):
+        if os.path.isfile(path) and path.endswith((".py", ".cpp", ".hpp", ".hip", ".h", "Makefile")):
+            txt = open(path).read()
+            assert not re.search(r"^\s*(from|import)\s+oracle\b", txt, flags=re.M), path
+            if not path.endswith(".py"):
+                assert "sht_oracle" not in txt and "oracle/" not in txt.replace("tests/host_emul", ""), path

@@ -1,0 +1,124 @@
+"""GPU parity of the CR path (cr_matmulA / cr_invM / cr_computeRHS / solve_cr_eqn_by_CG through the C ABI) against
+the numpy+C oracle on identical seeded inputs.  Tolerances from BASELINE.md §4 / SURVEY.md §8c:
+matvec <= 1e-11, fixed_iter solve <= 1e-8, converged solve <= 1e-6 with iteration count +-1."""
+import numpy as np
+import pytest
+
+from helpers import oracle_system, rel
+
+pytestmark = pytest.mark.gpu
+
+
+def _cols(lst):
+    return [np.asarray(v)[:, None] for v in lst]
+
+
+@pytest.fixture(scope="module")
+def small():
+    from commander_amd import synth
+    from commander_amd.cr import build_context
+    spec = synth.make_problem("cfg2", nside=32, lmax=64, comp_lmax=[64, 48])
+    ctx = build_context(spec)
+    ctx.initPrecond()
+    ctx.update_precond()
+    S = oracle_system(spec)
+    S.init_precond_diag()
+    S.update_precond_diag()
+    return spec, ctx, S
+
+
+def test_matmulA_invM_small(small):
+    spec, ctx, S = small
+    rng = np.random.default_rng(11)
+    for _ in range(2):
+        x = rng.standard_normal(ctx.ncr)
+        assert rel(ctx.cr_matmulA(x), S.matmulA(x)) < 1e-11
+        assert rel(ctx.cr_invM(x), S.invM(x)) < 1e-11
+    for b in range(len(spec["bands"])):
+        assert rel(ctx.invN_diag(b)[:, 0], S.bands[b].invN_diag[:, 0]) < 1e-11
+
+
+def test_matmulA_symmetric_positive(small):
+    spec, ctx, S = small
+    rng = np.random.default_rng(12)
+    u, v = rng.standard_normal(ctx.ncr), rng.standard_normal(ctx.ncr)
+    Au, Av = ctx.cr_matmulA(u), ctx.cr_matmulA(v)
+    assert abs(v @ Au - u @ Av) <= 1e-11 * abs(v @ Au)
+    assert u @ Au > u @ u  # A = 1 + (positive semi-definite)
+
+
+def test_rhs_small(small):
+    from commander_amd import synth
+    spec, ctx, S = small
+    resid, xi, eta = synth.draw_inputs(spec)
+    rhs = ctx.cr_computeRHS("sample", resid, xi, eta)
+    assert rel(rhs, S.computeRHS(_cols(resid), "sample", _cols(xi), eta)) < 1e-11
+    rhs2 = ctx.cr_computeRHS("optimize", resid)
+    assert rel(rhs2, S.computeRHS(_cols(resid), "optimize")) < 1e-11
+
+
+def test_solve_fixed_iter_and_residual_small(small):
+    from commander_amd import synth
+    spec, ctx, S = small
+    resid, xi, eta = synth.draw_inputs(spec)
+    b = S.computeRHS(_cols(resid), "sample", _cols(xi), eta)
+    x, n, stat, res = ctx.solve_cr_eqn_by_CG(b, "fixed_iter", 1e-8, 5, 40, 1)
+    xo, no, so = S.solve(b, "fixed_iter", 1e-8, 5, 40, 1)
+    assert n == no == 40 and stat == so == 0
+    assert rel(x, xo) < 1e-8
+    x, n, stat, res = ctx.solve_cr_eqn_by_CG(b, "residual", 1e-4, 5, 200, 1)
+    xo, no, so = S.solve(b, "residual", 1e-4, 5, 200, 1)
+    assert abs(n - no) <= 1 and stat == so == 0
+    assert rel(x, xo) < 1e-6
+    # warm start from the previous solution (cg_init_zero = .false., comm_cr_mod.f90:136-173)
+    x2, n2, stat2, _ = ctx.solve_cr_eqn_by_CG(b, "residual", 1e-4, 1, 200, 1, x0=x)
+    xo2, no2, so2 = S.solve(b, "residual", 1e-4, 1, 200, 1, x0=xo)
+    assert abs(n2 - no2) <= 1 and n2 < n
+    assert rel(x2, xo2) < 1e-6
+
+
+def test_cfg2_matvec_and_rhs_full_size():
+    """BASELINE.json configs[1]: 3 bands, CMB+synch, Nside=256, lmax=512."""
+    from commander_amd import synth
+    from commander_amd.cr import build_context
+    spec = synth.make_problem("cfg2")
+    ctx = build_context(spec)
+    S = oracle_system(spec)
+    rng = np.random.default_rng(13)
+    x = rng.standard_normal(ctx.ncr)
+    assert rel(ctx.cr_matmulA(x), S.matmulA(x)) < 1e-11
+    resid, xi, eta = synth.draw_inputs(spec)
+    assert rel(ctx.cr_computeRHS("sample", resid, xi, eta), S.computeRHS(_cols(resid), "sample", _cols(xi), eta)) < 1e-11
+    ctx.initPrecond()
+    ctx.update_precond()
+    S.init_precond_diag()
+    S.update_precond_diag()
+    assert rel(ctx.cr_invM(x), S.invM(x)) < 1e-11
+    b = S.computeRHS(_cols(resid), "sample", _cols(xi), eta)
+    xg, n, stat, _ = ctx.solve_cr_eqn_by_CG(b, "fixed_iter", 1e-8, 5, 10, 1)
+    xo, no, so = S.solve(b, "fixed_iter", 1e-8, 5, 10, 1)
+    assert n == no == 10
+    assert rel(xg, xo) < 1e-8
+
+
+def test_cfg3_full_size_properties():
+    """BASELINE.json configs[2] geometry (9 bands, Nside=1024, lmax=2000): size-independent properties only --
+    symmetry of A, A u > u, M^-1 positive, and PCG actually reducing r^T M^-1 r by the expected orders."""
+    from commander_amd import synth
+    from commander_amd.cr import build_context
+    spec = synth.make_problem("cfg3")
+    ctx = build_context(spec)
+    rng = np.random.default_rng(14)
+    u, v = rng.standard_normal(ctx.ncr), rng.standard_normal(ctx.ncr)
+    Au, Av = ctx.cr_matmulA(u), ctx.cr_matmulA(v)
+    assert abs(v @ Au - u @ Av) <= 1e-10 * abs(v @ Au)
+    assert u @ Au > u @ u
+    ctx.initPrecond()
+    ctx.update_precond()
+    Mu = ctx.cr_invM(u)
+    assert u @ Mu > 0
+    resid, xi, eta = synth.draw_inputs(spec)
+    b = ctx.cr_computeRHS("sample", resid, xi, eta)
+    x, n, stat, (dn, d0) = ctx.solve_cr_eqn_by_CG(b, "fixed_iter", 1e-8, 5, 40, 1)
+    assert n == 40 and np.isfinite(x).all()
+    assert dn < 1e-3 * d0  # masked sky + diagonal preconditioner: ~4 orders in 40 iterations

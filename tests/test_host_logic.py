@@ -1,0 +1,110 @@
+"""CPU tier: the library's HOST logic (plan tables, a_lm index maps, CR orchestration, C ABI marshalling) exercised
+through tests/host_emul -- the real host sources compiled with g++ against a HIP stand-in, with every kernel body
+executed as a single-thread loop -- and checked against the oracle.  This is NOT a product path (libcmdr_hip.so does
+not contain it); GPU parity proper lives in the -m gpu tests."""
+import numpy as np
+import pytest
+
+from helpers import emul_lib, oracle_system, rel
+
+
+@pytest.fixture(scope="module")
+def EL():
+    return emul_lib()
+
+
+@pytest.mark.parametrize("nside,lmax", [(4, 8), (4, 11), (8, 23), (16, 40), (64, 128)])
+def test_emul_sht_vs_oracle(nside, lmax, EL, oracle_lib):
+    from commander_amd.sht import ShtPlan
+    import commander_amd.sht as shtmod
+    rng = np.random.default_rng(nside * 1000 + lmax)
+    w = 1.0 + 0.05 * rng.standard_normal(2 * nside)
+    old = shtmod.lib
+    shtmod.lib = lambda: EL
+    try:
+        plan = ShtPlan(nside, lmax, wring=w, max_maps=2)
+        a = rng.standard_normal(((lmax + 1) ** 2, 2))
+        m = rng.standard_normal((12 * nside * nside, 2))
+        y, yt, ytw, wy = plan.Y(a), plan.Yt(m), plan.YtW(m), plan.WY(a)
+    finally:
+        shtmod.lib = old
+    for k in range(2):
+        assert rel(y[:, k], oracle_lib.Y(nside, lmax, a[:, k])) < 1e-12
+        assert rel(yt[:, k], oracle_lib.Yt(nside, lmax, m[:, k])) < 1e-12
+        assert rel(ytw[:, k], oracle_lib.YtW(nside, lmax, m[:, k], wring=w)) < 1e-12
+        assert rel(wy[:, k], oracle_lib.WY(nside, lmax, a[:, k], wring=w)) < 1e-12
+
+
+def test_emul_cr_path_vs_oracle(EL):
+    from commander_amd import synth
+    from commander_amd.cr import build_context
+    spec = synth.make_problem("cfg2", nside=16, lmax=32, comp_lmax=[32, 24])
+    spec["comps"][1]["active"] = True
+    S = oracle_system(spec)
+    ctx = build_context(spec, _lib=EL)
+    assert ctx.ncr == S.ncr
+    rng = np.random.default_rng(0)
+    x = rng.standard_normal(ctx.ncr)
+    assert rel(ctx.cr_matmulA(x), S.matmulA(x)) < 1e-12
+    ctx.initPrecond()
+    ctx.update_precond()
+    S.init_precond_diag()
+    S.update_precond_diag()
+    for b in range(3):
+        assert rel(ctx.invN_diag(b)[:, 0], S.bands[b].invN_diag[:, 0]) < 1e-12
+    assert rel(ctx.cr_invM(x), S.invM(x)) < 1e-12
+    resid, xi, eta = synth.draw_inputs(spec)
+    cols = lambda lst: [np.asarray(v)[:, None] for v in lst]  # noqa: E731
+    rhs = ctx.cr_computeRHS("sample", resid, xi, eta)
+    rhso = S.computeRHS(cols(resid), "sample", cols(xi), eta)
+    assert rel(rhs, rhso) < 1e-12
+    assert rel(ctx.cr_computeRHS("optimize", resid), S.computeRHS(cols(resid), "optimize")) < 1e-12
+    xs, n, stat, res = ctx.solve_cr_eqn_by_CG(rhso, "fixed_iter", 1e-8, 5, 15, 1)
+    xo, no, so = S.solve(rhso, "fixed_iter", 1e-8, 5, 15, 1)
+    assert n == no == 15 and rel(xs, xo) < 1e-10
+    xs, n, stat, res = ctx.solve_cr_eqn_by_CG(rhso, "residual", 1e-6, 5, 300, 2)
+    xo, no, so = S.solve(rhso, "residual", 1e-6, 5, 300, 2)
+    assert n == no and stat == so and rel(xs, xo) < 1e-8
+
+
+def test_emul_inactive_component_and_no_prior(EL):
+    """active_samp_group = .false. slots stay zero (comm_cr_mod.f90:800-803); cltype 'none' skips sqrtS."""
+    from commander_amd import synth
+    from commander_amd.cr import build_context
+    spec = synth.make_problem("cfg2", nside=8, lmax=16)
+    spec["comps"][1]["active"] = False
+    S = oracle_system(spec)
+    ctx = build_context(spec, _lib=EL)
+    x = np.random.default_rng(1).standard_normal(ctx.ncr)
+    y, yo = ctx.cr_matmulA(x), S.matmulA(x)
+    assert rel(y, yo) < 1e-12
+    n0 = (16 + 1) ** 2
+    assert np.all(y[n0:] == 0.0)
+    ctx.initPrecond(); ctx.update_precond(); S.init_precond_diag(); S.update_precond_diag()
+    assert rel(ctx.cr_invM(x), S.invM(x)) < 1e-12
+    spec2 = synth.make_problem("cfg2", nside=8, lmax=16)
+    for k in ("sqrtS_mat", "sqrtInvS_mat", "S_mat"):
+        spec2["comps"][1][k] = None
+    S2 = oracle_system(spec2)
+    ctx2 = build_context(spec2, _lib=EL)
+    assert rel(ctx2.cr_matmulA(x), S2.matmulA(x)) < 1e-12
+
+
+def test_emul_ring_sharded_partial_sums(EL):
+    """Ring-pair sharding with replicated a_lm: the per-rank partial matvecs sum to the full one."""
+    from commander_amd import synth, healpix
+    from commander_amd.cr import build_context
+    nside, lmax, P = 16, 32, 3
+    full = synth.make_problem("cfg2", nside=nside, lmax=lmax)
+    ctx = build_context(full, _lib=EL)
+    x = np.random.default_rng(2).standard_normal(ctx.ncr)
+    y = ctx.cr_matmulA(x)
+    acc = np.zeros_like(y)
+    for r in range(P):
+        rings = healpix.rank_rings(nside, r, P)
+        pix = healpix.local_pixels(nside, rings)
+        loc = synth.make_problem("cfg2", nside=nside, lmax=lmax, pixels=pix)
+        c = build_context(loc, rings_by_nside={nside: rings}, _lib=EL)
+        assert c.band_npix(0) == pix.size
+        acc += c.cr_matmulA(x) - x          # each rank adds the unit prior term once
+    assert rel(acc + x, y) < 1e-12

@@ -2,7 +2,8 @@
 import ctypes, sys, time
 import numpy as np
 sys.path.insert(0, ".")
-from commander_amd.lib import lib, check
+import importlib
+_m = importlib.import_module("commander_amd.lib"); lib, check = _m.lib, _m.check
 from commander_amd import ShtPlan
 
 nside = int(sys.argv[1]) if len(sys.argv) > 1 else 1024
