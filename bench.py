@@ -80,7 +80,8 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     dist = None
-    if world > 1:
+    force_dist = os.environ.get("CMDR_BENCH_FORCE_DIST") == "1"   # exercise the RCCL path on a 1-GPU box
+    if world > 1 or force_dist:
         import torch
         import torch.distributed as dist
         torch.cuda.set_device(local_rank)
@@ -96,7 +97,7 @@ def main():
         pixels = healpix.local_pixels(nside, rings)
     spec = synth.make_problem(cfg, pixels=pixels)
     ctx = build_context(spec, device=local_rank, rings_by_nside={nside: rings} if rings is not None else None)
-    if world > 1:
+    if dist is not None:
         import torch
 
         def allreduce(ptr, n):

@@ -56,8 +56,10 @@ CMDR_HD void sqrtS_elem(const CompDev& C, const double* __restrict__ smat, int k
 //   comm_diffuse_comp_mod.f90:2077-2089, comm_B_bl_mod.f90:108-127).
 CMDR_HD void band_prep_elem(const CompDev* __restrict__ comps, int ncomp, const double* __restrict__ sx,
                             const double* __restrict__ w /* [ncomp][lmax_g+1] for this bm */, int stokes,
-                            double* __restrict__ ast, const double* __restrict__ cnorm, int lmax_g, int m, int l) {
+                            double* __restrict__ ast_base, int nbs, int bm, const double* __restrict__ cnorm,
+                            int lmax_g, int m, int l) {
     const int64_t t = d_moffp(lmax_g, m) + (l - m);
+    double* __restrict__ ast = ast_base + 2 * (t * nbs + bm) - 2 * t;  // maps interleaved: slot of (t, bm)
     double re = 0.0, im = 0.0;
     if (l <= lmax_g) {
         for (int c = 0; c < ncomp; ++c) {

@@ -27,19 +27,17 @@ void launch_sqrtS(const CompDev* comps, int ncomp, int lmax_max, const double* s
 
 __global__ void k_band_prep(const CompDev* __restrict__ comps, int ncomp, const double* __restrict__ sx,
                             const double* __restrict__ w, const int* __restrict__ bm_stokes,
-                            double* __restrict__ ast, int64_t ast_stride, const double* __restrict__ cnorm,
-                            int lmax_g) {
+                            double* __restrict__ ast, int nbm, const double* __restrict__ cnorm, int lmax_g) {
     const int m = blockIdx.y, l = m + blockIdx.x * 256 + threadIdx.x;
     if (l > lmax_g + 1) return;
     const int bm = blockIdx.z;
-    band_prep_elem(comps, ncomp, sx, w + (int64_t)bm * ncomp * (lmax_g + 1), bm_stokes[bm], ast + bm * ast_stride,
-                   cnorm, lmax_g, m, l);
+    band_prep_elem(comps, ncomp, sx, w + (int64_t)bm * ncomp * (lmax_g + 1), bm_stokes[bm], ast, nbm, bm, cnorm,
+                   lmax_g, m, l);
 }
 void launch_band_prep(const CompDev* comps, int ncomp, const double* sx, const double* w, const int* bm_stokes,
-                      double* ast, int64_t ast_stride, const double* cnorm, int lmax_g, int nbm, hipStream_t s) {
+                      double* ast, const double* cnorm, int lmax_g, int nbm, hipStream_t s) {
     dim3 grid((lmax_g + 2 + 255) / 256, lmax_g + 1, nbm);
-    hipLaunchKernelGGL(k_band_prep, grid, dim3(256), 0, s, comps, ncomp, sx, w, bm_stokes, ast, ast_stride, cnorm,
-                       lmax_g);
+    hipLaunchKernelGGL(k_band_prep, grid, dim3(256), 0, s, comps, ncomp, sx, w, bm_stokes, ast, nbm, cnorm, lmax_g);
 }
 
 __global__ void k_band_post(const CompDev* __restrict__ comps, int ncomp, const double* __restrict__ part,

@@ -36,7 +36,7 @@ void CrSystem::problem_info(int64_t* out) const {
             if (v != kLsNever) steps += L.lmax - v + 1;
         }
     out[0] = G.nbm;
-    out[1] = (int64_t)L.tasks.size();
+    out[1] = (int64_t)L.tasks.size();  // incl. padding slots
     out[2] = steps;
 }
 
@@ -255,7 +255,7 @@ void CrSystem::matmulA(const double* x, double* y) {
     for (Group& G : groups_) {   // per-band loop :843-954, all bands of a geometry batched
         ShtPlan& P = *G.plan;
         launch_band_prep(comps_dev_.get(), ncomp, sx_.get(), G.w.get(), G.bm_stokes_dev.get(), P.stream(),
-                         P.leg().tri_elems(), P.leg().cnorm.get(), G.lmax, G.nbm, stream_);
+                         P.leg().cnorm.get(), G.lmax, G.nbm, stream_);
         span_begin(0);
         P.synth_from_stream(G.nbm, stream_);                                         // Y        :891
         span_end();
@@ -351,7 +351,8 @@ void CrSystem::precond_init_diag() {
             std::vector<double> x(nhalf), sth(nhalf);
             for (int k = 0; k < nhalf; ++k) { x[k] = std::max(gx[k], 0.0); sth[k] = std::sqrt((1.0 - x[k]) * (1.0 + x[k])); }
             LegendreTables T;
-            T.build(lmax, x, sth, nhalf >= 1024 ? 4 : (nhalf >= 256 ? 2 : 1));
+            const int Rg = nhalf >= 1024 ? 4 : (nhalf >= 256 ? 2 : 1);
+            T.build(lmax, x, sth, Rg, Rg);
             auto L = std::make_unique<LegendreDev>();
             L->upload(T);
             glplans[lmax] = std::move(L);

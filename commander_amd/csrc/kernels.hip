@@ -1,34 +1,42 @@
 // gfx950 kernels of libcmdr_hip and their launchers.  Bodies live in kernels_body.hpp.
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
+#include <cstdlib>
+
 #include "kernels.hpp"
 #include "kernels_body.hpp"
 
 namespace cmdr {
 
 // ===================================================================================== Legendre stage
-// grid.x = ceil(ntasks/4) (one wave task per wavefront), grid.y = nmaps.  No LDS, no barriers.
-template <int R>
+// Synthesis: one wave task (one m x 64*R ring pairs) per wavefront, 4 per workgroup, NB maps per wave sharing the
+// recursion.  No LDS, no barriers: the wave-uniform operands (alpha_l and the a_lm stream) come in through the
+// scalar unit.  Measured on MI355X (tools/microbench/fp64_synth.hip): fp64 FMA sustains ~61 TFLOP/s (clock ~1.9 GHz
+// under load), scalar-cache hits are free, scalar-cache MISSES sustain only ~1.5 B/clk/CU, and LDS broadcast reads
+// ~4 B/clk/CU -- so the stream bytes per VALU cycle, not the VALU itself, bound how many maps can share one
+// recursion.  (R = 4, NB <= 2) is the measured optimum; an LDS-staged variant was slower (register pressure).
+template <int R, int NB>
 __global__ void __launch_bounds__(256) k_leg_synth(LegArgs A, const WaveTask* __restrict__ tasks, int ntasks,
-                                                   const double* __restrict__ ast, int64_t ast_stride,
+                                                   const double* __restrict__ ast, int nbs, int k0,
                                                    double* __restrict__ ph, int64_t ph_stride) {
     const int wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int t = blockIdx.x * 4 + wid;
     if (t >= ntasks) return;
     const WaveTask T = tasks[t];
+    if (T.chunk < 0) return;
     const int m = __builtin_amdgcn_readfirstlane(T.m);
     const int chunk = __builtin_amdgcn_readfirstlane(T.chunk);
     const int lw = __builtin_amdgcn_readfirstlane(T.lw);
     const int lAend = __builtin_amdgcn_readfirstlane(T.lAend);
-    leg_synth_lane<R>(A, ast + blockIdx.y * ast_stride, ph + blockIdx.y * ph_stride, m, chunk, lw, lAend,
-                      threadIdx.x & 63);
+    leg_synth_lane<R, NB>(A, ast, nbs, k0, ph, ph_stride, m, chunk, lw, lAend, threadIdx.x & 63);
 }
 
 // Adjoint: each wave reduces its 64 lanes through a private LDS tile and writes one partial column segment
 // part[map][chunk][padded triangle] (complex).  Deterministic: fixed summation order, no atomics.
-template <int R, bool SQUARE>
+template <int R, int NB, bool SQUARE>
 __global__ void __launch_bounds__(256) k_leg_adj(LegArgs A, const WaveTask* __restrict__ tasks, int ntasks,
-                                                 const double* __restrict__ ph, int64_t ph_stride,
+                                                 const double* __restrict__ ph, int64_t ph_stride, int k0,
                                                  double* __restrict__ part, int64_t part_map_stride,
                                                  int64_t part_chunk_stride) {
     __shared__ double lds[4][16 * 65];
@@ -37,77 +45,113 @@ __global__ void __launch_bounds__(256) k_leg_adj(LegArgs A, const WaveTask* __re
     const int t = blockIdx.x * 4 + wid;
     if (t >= ntasks) return;
     const WaveTask T = tasks[t];
+    if (T.chunk < 0) return;
     const int m = __builtin_amdgcn_readfirstlane(T.m);
     const int chunk = __builtin_amdgcn_readfirstlane(T.chunk);
     const int lw = __builtin_amdgcn_readfirstlane(T.lw);
     const int lAend = __builtin_amdgcn_readfirstlane(T.lAend);
     const int lmax = A.lmax;
-    AdjLane<R> S;
-    leg_adj_load<R, SQUARE>(A, ph + blockIdx.y * ph_stride, m, chunk, lane, S);
+    AdjLane<R, NB> S;
+    leg_adj_load<R, NB, SQUARE>(A, ph, ph_stride, k0, m, chunk, lane, S);
     const int64_t mo = d_moffp(lmax, m);
     const double* __restrict__ al = A.alpha + (mo - m);
-    double* __restrict__ out = part + blockIdx.y * part_map_stride + chunk * part_chunk_stride + 2 * (mo - m);
+    double* __restrict__ out0 = part + chunk * part_chunk_stride + 2 * (mo - m);
     double* wl = lds[wid];
     const int col = lane & 15, qtr = lane >> 4;
     for (int l0 = lw; l0 <= lmax; l0 += kAdjL_) {
-        double v[16];
-        if (l0 < lAend) leg_adj_group<R, SQUARE, true>(A, al, l0, S, v);
-        else            leg_adj_group<R, SQUARE, false>(A, al, l0, S, v);
-#pragma unroll
-        for (int j = 0; j < 16; ++j) wl[j * 65 + lane] = v[j];
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-        double s = 0.0;
-#pragma unroll
-        for (int i = 0; i < 16; ++i) s += wl[col * 65 + qtr * 16 + i];
-        s += __shfl_xor(s, 16);
-        s += __shfl_xor(s, 32);
+        double w[kAdjL_][R];
+        if (l0 < lAend) leg_adj_mu_group<R, NB, SQUARE, true>(al, l0, S, w);
+        else            leg_adj_mu_group<R, NB, SQUARE, false>(al, l0, S, w);
         const int l = l0 + (col >> 1);
-        if (qtr == 0 && l <= lmax) out[2 * l + (col & 1)] = s;
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#pragma unroll
+        for (int k = 0; k < NB; ++k) {
+            double v[16];
+            leg_adj_products<R, NB>(S, w, k, v);
+#pragma unroll
+            for (int j = 0; j < 16; ++j) wl[j * 65 + lane] = v[j];
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            double s = 0.0;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) s += wl[col * 65 + qtr * 16 + i];
+            s += __shfl_xor(s, 16);
+            s += __shfl_xor(s, 32);
+            if (qtr == 0 && l <= lmax) out0[(k0 + k) * part_map_stride + 2 * l + (col & 1)] = s;
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        }
     }
 }
 
-template <int R>
-static void launch_leg_synth_R(const LegArgs& A, const WaveTask* tasks, int ntasks, const double* ast,
-                               int64_t ast_stride, double* ph, int64_t ph_stride, int nmaps, hipStream_t s) {
-    dim3 grid((ntasks + 3) / 4, nmaps);
-    hipLaunchKernelGGL(k_leg_synth<R>, grid, dim3(256), 0, s, A, tasks, ntasks, ast, ast_stride, ph, ph_stride);
+int leg_max_batch(int R) {
+    int nb = R == 1 ? 9 : (R == 2 ? 4 : 2);
+    if (const char* e = std::getenv("CMDR_LEG_NB")) {   // tuning knob: cap the maps per wave
+        const int v = std::atoi(e);
+        if (v >= 1 && v < nb) nb = v;
+    }
+    return nb;
 }
-void launch_leg_synth(const LegArgs& A, const WaveTask* tasks, int ntasks, const double* ast, int64_t ast_stride,
-                      double* ph, int64_t ph_stride, int nmaps, hipStream_t s) {
+
+template <int R, int NB>
+static void synth_RN(const LegArgs& A, const WaveTask* tasks, int ntasks, const double* ast, int nbs, int k0,
+                     double* ph, int64_t ph_stride, hipStream_t s) {
+    hipLaunchKernelGGL((k_leg_synth<R, NB>), dim3(ntasks / 4), dim3(256), 0, s, A, tasks, ntasks, ast, nbs, k0, ph,
+                       ph_stride);
+}
+void launch_leg_synth(const LegArgs& A, const WaveTask* tasks, int ntasks, const double* ast, double* ph,
+                      int64_t ph_stride, int nmaps, hipStream_t s) {
     if (ntasks == 0 || nmaps == 0) return;
-    switch (A.R) {
-        case 1: launch_leg_synth_R<1>(A, tasks, ntasks, ast, ast_stride, ph, ph_stride, nmaps, s); break;
-        case 2: launch_leg_synth_R<2>(A, tasks, ntasks, ast, ast_stride, ph, ph_stride, nmaps, s); break;
-        default: launch_leg_synth_R<4>(A, tasks, ntasks, ast, ast_stride, ph, ph_stride, nmaps, s); break;
+    const int nbmax = leg_max_batch(A.R);
+    const int nbatch = (nmaps + nbmax - 1) / nbmax;
+    for (int k0 = 0, ib = 0; ib < nbatch; ++ib) {
+        const int nb = (nmaps - k0 + (nbatch - ib) - 1) / (nbatch - ib);   // balanced split, e.g. 9 -> 3+3+3
+#define CMDR_S(RR, NN) case NN: synth_RN<RR, NN>(A, tasks, ntasks, ast, nmaps, k0, ph, ph_stride, s); break;
+        if (A.R == 1) {
+            switch (nb) { CMDR_S(1, 1) CMDR_S(1, 2) CMDR_S(1, 3) CMDR_S(1, 4) CMDR_S(1, 5) CMDR_S(1, 6) CMDR_S(1, 7)
+                          CMDR_S(1, 8) CMDR_S(1, 9) }
+        } else if (A.R == 2) {
+            switch (nb) { CMDR_S(2, 1) CMDR_S(2, 2) CMDR_S(2, 3) CMDR_S(2, 4) }
+        } else {
+            switch (nb) { CMDR_S(4, 1) CMDR_S(4, 2) }
+        }
+#undef CMDR_S
+        k0 += nb;
     }
 }
 
-template <int R, bool SQ>
-static void launch_leg_adj_R(const LegArgs& A, const WaveTask* tasks, int ntasks, const double* ph,
-                             int64_t ph_stride, double* part, int64_t pms, int64_t pcs, int nmaps, hipStream_t s) {
-    dim3 grid((ntasks + 3) / 4, nmaps);
-    hipLaunchKernelGGL((k_leg_adj<R, SQ>), grid, dim3(256), 0, s, A, tasks, ntasks, ph, ph_stride, part, pms, pcs);
+template <int R, int NB, bool SQ>
+static void adj_RN(const LegArgs& A, const WaveTask* tasks, int ntasks, const double* ph, int64_t ph_stride, int k0,
+                   double* part, int64_t pms, int64_t pcs, hipStream_t s) {
+    hipLaunchKernelGGL((k_leg_adj<R, NB, SQ>), dim3(ntasks / 4), dim3(256), 0, s, A, tasks, ntasks, ph,
+                       ph_stride, k0, part, pms, pcs);
 }
 void launch_leg_adj(const LegArgs& A, const WaveTask* tasks, int ntasks, const double* ph, int64_t ph_stride,
-                    double* part, int64_t part_map_stride, int64_t part_chunk_stride, int nmaps, bool square,
-                    hipStream_t s) {
+                    double* part, int64_t pms, int64_t pcs, int nmaps, bool square, hipStream_t s) {
     if (ntasks == 0 || nmaps == 0) return;
-#define CMDR_ADJ(RR)                                                                                           \
-    if (square) launch_leg_adj_R<RR, true>(A, tasks, ntasks, ph, ph_stride, part, part_map_stride,             \
-                                           part_chunk_stride, nmaps, s);                                       \
-    else launch_leg_adj_R<RR, false>(A, tasks, ntasks, ph, ph_stride, part, part_map_stride, part_chunk_stride, \
-                                     nmaps, s);
-    switch (A.R) {
-        case 1: CMDR_ADJ(1) break;
-        case 2: CMDR_ADJ(2) break;
-        default: CMDR_ADJ(4) break;
+    if (square) {  // setup-time only (noise diagonal): one map at a time
+        for (int k0 = 0; k0 < nmaps; ++k0) {
+            if (A.R == 1) adj_RN<1, 1, true>(A, tasks, ntasks, ph, ph_stride, k0, part, pms, pcs, s);
+            else if (A.R == 2) adj_RN<2, 1, true>(A, tasks, ntasks, ph, ph_stride, k0, part, pms, pcs, s);
+            else adj_RN<4, 1, true>(A, tasks, ntasks, ph, ph_stride, k0, part, pms, pcs, s);
+        }
+        return;
     }
-#undef CMDR_ADJ
+    const int nbmax = leg_max_batch(A.R);
+    for (int k0 = 0; k0 < nmaps; k0 += nbmax) {
+        const int nb = std::min(nbmax, nmaps - k0);
+#define CMDR_A(RR, NN) case NN: adj_RN<RR, NN, false>(A, tasks, ntasks, ph, ph_stride, k0, part, pms, pcs, s); break;
+        if (A.R == 1) {
+            switch (nb) { CMDR_A(1, 1) CMDR_A(1, 2) CMDR_A(1, 3) CMDR_A(1, 4) CMDR_A(1, 5) CMDR_A(1, 6) CMDR_A(1, 7)
+                          CMDR_A(1, 8) CMDR_A(1, 9) }
+        } else if (A.R == 2) {
+            switch (nb) { CMDR_A(2, 1) CMDR_A(2, 2) CMDR_A(2, 3) CMDR_A(2, 4) }
+        } else {
+            switch (nb) { CMDR_A(4, 1) CMDR_A(4, 2) }
+        }
+#undef CMDR_A
+    }
 }
 
 // ===================================================================================== ring stage
@@ -204,15 +248,15 @@ void launch_ring(int mode, const RingDev* rings, const int* cls, int ncls, int l
 // Commander real-packed a_lm (one column) -> padded-triangle complex stream, times cnorm * kappa_m * scale.
 // kappa_m = 1/sqrt2 for m>0 (Hermitian pair construction in the ring stage), 1 for m=0.
 __global__ void k_alm_to_stream(const double* __restrict__ alm, int64_t alm_stride, double* __restrict__ ast,
-                                int64_t ast_stride, const double* __restrict__ cnorm, int lmax) {
+                                int nbs, const double* __restrict__ cnorm, int lmax) {
     const int m = blockIdx.y, l = m + blockIdx.x * 256 + threadIdx.x;
     if (l > lmax + 1) return;
-    alm_to_stream_elem(alm + blockIdx.z * alm_stride, ast + blockIdx.z * ast_stride, cnorm, lmax, m, l);
+    alm_to_stream_elem(alm + blockIdx.z * alm_stride, ast, nbs, blockIdx.z, cnorm, lmax, m, l);
 }
-void launch_alm_to_stream(const double* alm, int64_t alm_stride, double* ast, int64_t ast_stride,
-                          const double* cnorm, int lmax, int nmaps, hipStream_t s) {
+void launch_alm_to_stream(const double* alm, int64_t alm_stride, double* ast, const double* cnorm, int lmax,
+                          int nmaps, hipStream_t s) {
     dim3 grid((lmax + 2 + 255) / 256, lmax + 1, nmaps);
-    hipLaunchKernelGGL(k_alm_to_stream, grid, dim3(256), 0, s, alm, alm_stride, ast, ast_stride, cnorm, lmax);
+    hipLaunchKernelGGL(k_alm_to_stream, grid, dim3(256), 0, s, alm, alm_stride, ast, nmaps, cnorm, lmax);
 }
 
 // partial columns -> Commander real-packed a_lm: alm = kappa'_m * cnorm * sum_chunks part ; kappa' = sqrt2 (m>0).

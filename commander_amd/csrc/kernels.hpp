@@ -10,8 +10,10 @@
 
 namespace cmdr {
 
-void launch_leg_synth(const LegArgs& A, const WaveTask* tasks, int ntasks, const double* ast, int64_t ast_stride,
-                      double* ph, int64_t ph_stride, int nmaps, hipStream_t s);
+// coefficient stream: maps interleaved, ast[((t * nmaps) + k) * 2 + {re, im}]
+int leg_max_batch(int R);
+void launch_leg_synth(const LegArgs& A, const WaveTask* tasks, int ntasks, const double* ast, double* ph,
+                      int64_t ph_stride, int nmaps, hipStream_t s);
 void launch_leg_adj(const LegArgs& A, const WaveTask* tasks, int ntasks, const double* ph, int64_t ph_stride,
                     double* part, int64_t part_map_stride, int64_t part_chunk_stride, int nmaps, bool square,
                     hipStream_t s);
@@ -19,8 +21,8 @@ void launch_leg_adj(const LegArgs& A, const WaveTask* tasks, int ntasks, const d
 void launch_ring(int mode, const RingDev* rings, const int* cls, int ncls, int log2M, double* ph,
                  int64_t ph_stride, int64_t npair_pad, double* map, int64_t map_stride, const double* const* mul,
                  int weighted, const cd* tw, int log2Mmax, const cd* chirp, int nmaps, hipStream_t s);
-void launch_alm_to_stream(const double* alm, int64_t alm_stride, double* ast, int64_t ast_stride,
-                          const double* cnorm, int lmax, int nmaps, hipStream_t s);
+void launch_alm_to_stream(const double* alm, int64_t alm_stride, double* ast, const double* cnorm, int lmax,
+                          int nmaps, hipStream_t s);
 void launch_part_to_alm(const double* part, int64_t pms, int64_t pcs, int nchunk, double* alm, int64_t alm_stride,
                         const double* cnorm, int lmax, int nmaps, hipStream_t s);
 
@@ -28,7 +30,7 @@ void launch_part_to_alm(const double* part, int64_t pms, int64_t pcs, int nchunk
 void launch_sqrtS(const CompDev* comps, int ncomp, int lmax_max, const double* smat, int kind, const double* in,
                   const double* add, double* out, bool pass_inactive, hipStream_t s);
 void launch_band_prep(const CompDev* comps, int ncomp, const double* sx, const double* w, const int* bm_stokes,
-                      double* ast, int64_t ast_stride, const double* cnorm, int lmax_g, int nbm, hipStream_t s);
+                      double* ast, const double* cnorm, int lmax_g, int nbm, hipStream_t s);
 void launch_band_post(const CompDev* comps, int ncomp, int lmax_max, const double* part, int64_t pms, int64_t pcs,
                       int nchunk, int nbm, const int* bm_stokes, const double* w, const double* cnorm, int lmax_g,
                       double* yc, bool accumulate, hipStream_t s);

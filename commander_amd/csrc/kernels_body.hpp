@@ -36,7 +36,7 @@ CMDR_HD int64_t d_moffp(int lmax, int m) { return (int64_t)m * (lmax + 2) - (int
 struct LegArgs {
     int lmax;
     int npair_pad;
-    int R;
+    int R;                 // ring pairs per lane of the kernel these args are passed to
     const double* x;       // [npair_pad]
     const int* ls;         // [(lmax+1) * npair_pad]
     const double* seedc;   // mu_{ls}
@@ -45,17 +45,22 @@ struct LegArgs {
 };
 
 // ---------------------------------------------------------------------------------------------------------
-// Legendre synthesis, one lane: F_N/S(m, pair) = sum_l a~_lm mu_l(x_pair)  (even +/- odd parity parts).
-//   ast : this map's coefficient stream, complex, padded-triangle layout, already multiplied by cnorm etc.
-//   ph  : this map's phase array [(lmax+1)][npair_pad][4] = (N.re, N.im, S.re, S.im)
-template <int R>
-CMDR_HD void leg_synth_lane(const LegArgs& A, const double* __restrict__ ast, double* __restrict__ ph, int m,
-                            int chunk, int lw, int lAend, int lane) {
+// Legendre synthesis, one lane, NB maps at once: F^(k)_N/S(m, pair) = sum_l a~^(k)_lm mu_l(x_pair).
+// The recursion (2 fp64 ops per l) is shared by the NB maps, each map adds 2 FMAs per l.
+//   ast : coefficient stream, complex, padded-triangle layout, maps interleaved: ast[((t*nbs)+k)*2 + {re,im}],
+//         already multiplied by cnorm etc.;  k0 = first map of this launch slice
+//   ph  : phase arrays [map][(lmax+1)][npair_pad][4] = (N.re, N.im, S.re, S.im)
+template <int R, int NB>
+CMDR_HD void leg_synth_lane(const LegArgs& A, const double* __restrict__ ast, int nbs, int k0,
+                            double* __restrict__ ph, int64_t ph_stride, int m, int chunk, int lw, int lAend,
+                            int lane) {
     const int lmax = A.lmax;
     const int64_t mo = d_moffp(lmax, m);
     const double* __restrict__ al = A.alpha + (mo - m);
-    const double* __restrict__ as = ast + 2 * (mo - m);
-    double x[R], mc[R], mp[R], sc[R], sp[R], Er[R], Ei[R], Or[R], Oi[R];
+    const double* __restrict__ as = ast + 2 * ((int64_t)nbs * (mo - m) + k0);
+    const int64_t ls2 = 2 * (int64_t)nbs;  // stride between consecutive l
+    double x[R], mc[R], mp[R], sc[R], sp[R];
+    double Er[R][NB], Ei[R][NB], Or[R][NB], Oi[R][NB];
     int ls[R];
     const int base = chunk * 64 * R + lane;
 #pragma unroll
@@ -67,42 +72,82 @@ CMDR_HD void leg_synth_lane(const LegArgs& A, const double* __restrict__ ast, do
         sc[r] = A.seedc[idx];
         sp[r] = A.seedp[idx];
         mc[r] = mp[r] = 0.0;
-        Er[r] = Ei[r] = Or[r] = Oi[r] = 0.0;
+#pragma unroll
+        for (int k = 0; k < NB; ++k) Er[r][k] = Ei[r][k] = Or[r][k] = Oi[r][k] = 0.0;
     }
     int l = lw;
     // Phase A: lanes switch on at their own ls
     for (; l < lAend && l <= lmax; l += 2) {
-        const double a0r = as[2 * l], a0i = as[2 * l + 1], a1r = as[2 * l + 2], a1i = as[2 * l + 3];
+        const double* __restrict__ c0 = as + ls2 * l;
+        const double* __restrict__ c1 = c0 + ls2;
         const double al1 = al[l + 1], al2 = al[l + 2];
 #pragma unroll
         for (int r = 0; r < R; ++r) {
             if (ls[r] == l) { mc[r] = sc[r]; mp[r] = sp[r]; }
-            Er[r] += mc[r] * a0r;
-            Ei[r] += mc[r] * a0i;
+#pragma unroll
+            for (int k = 0; k < NB; ++k) { Er[r][k] += mc[r] * c0[2 * k]; Ei[r][k] += mc[r] * c0[2 * k + 1]; }
             double t = al1 * x[r] * mc[r] - mp[r];
             mp[r] = mc[r];
             mc[r] = t;
             if (ls[r] == l + 1) { mc[r] = sc[r]; mp[r] = sp[r]; }
-            Or[r] += mc[r] * a1r;
-            Oi[r] += mc[r] * a1i;
+#pragma unroll
+            for (int k = 0; k < NB; ++k) { Or[r][k] += mc[r] * c1[2 * k]; Oi[r][k] += mc[r] * c1[2 * k + 1]; }
             t = al2 * x[r] * mc[r] - mp[r];
             mp[r] = mc[r];
             mc[r] = t;
         }
     }
-    // Phase B: every started lane is running; pure recursion + accumulate
+    // Phase B: every started lane is running; pure recursion + accumulate.  The wave-uniform coefficients come in
+    // through scalar loads.  Scalar loads return out of order (only lgkmcnt(0) exists), so a wave cannot pipeline
+    // its own loads and their ~500-800 cycle latency (scalar-cache misses to L2; measured) must be covered by the
+    // other waves of the SIMD: each trip therefore consumes FOUR l (one batch of loads, one wait) when the SGPR
+    // budget allows, which makes the VALU block between two waits long enough for 4 waves/SIMD to hide it.
+    constexpr bool kQuad = (2 + 4 * NB) * 4 <= 76;  // SGPRs for 4 l of (alpha, NB complex)
+    if (kQuad) {
+        for (; l + 2 <= lmax; l += 4) {
+            const double* __restrict__ c0 = as + ls2 * l;
+            const double* __restrict__ c1 = c0 + ls2;
+            const double* __restrict__ c2 = c1 + ls2;
+            const double* __restrict__ c3 = c2 + ls2;
+            const double al1 = al[l + 1], al2 = al[l + 2], al3 = al[l + 3], al4 = al[l + 4];
+#pragma unroll
+            for (int r = 0; r < R; ++r) {
+#pragma unroll
+                for (int k = 0; k < NB; ++k) { Er[r][k] += mc[r] * c0[2 * k]; Ei[r][k] += mc[r] * c0[2 * k + 1]; }
+                double t = al1 * x[r] * mc[r] - mp[r];
+                mp[r] = mc[r];
+                mc[r] = t;
+#pragma unroll
+                for (int k = 0; k < NB; ++k) { Or[r][k] += mc[r] * c1[2 * k]; Oi[r][k] += mc[r] * c1[2 * k + 1]; }
+                t = al2 * x[r] * mc[r] - mp[r];
+                mp[r] = mc[r];
+                mc[r] = t;
+#pragma unroll
+                for (int k = 0; k < NB; ++k) { Er[r][k] += mc[r] * c2[2 * k]; Ei[r][k] += mc[r] * c2[2 * k + 1]; }
+                t = al3 * x[r] * mc[r] - mp[r];
+                mp[r] = mc[r];
+                mc[r] = t;
+#pragma unroll
+                for (int k = 0; k < NB; ++k) { Or[r][k] += mc[r] * c3[2 * k]; Oi[r][k] += mc[r] * c3[2 * k + 1]; }
+                t = al4 * x[r] * mc[r] - mp[r];
+                mp[r] = mc[r];
+                mc[r] = t;
+            }
+        }
+    }
     for (; l <= lmax; l += 2) {
-        const double a0r = as[2 * l], a0i = as[2 * l + 1], a1r = as[2 * l + 2], a1i = as[2 * l + 3];
+        const double* __restrict__ c0 = as + ls2 * l;
+        const double* __restrict__ c1 = c0 + ls2;
         const double al1 = al[l + 1], al2 = al[l + 2];
 #pragma unroll
         for (int r = 0; r < R; ++r) {
-            Er[r] += mc[r] * a0r;
-            Ei[r] += mc[r] * a0i;
+#pragma unroll
+            for (int k = 0; k < NB; ++k) { Er[r][k] += mc[r] * c0[2 * k]; Ei[r][k] += mc[r] * c0[2 * k + 1]; }
             double t = al1 * x[r] * mc[r] - mp[r];
             mp[r] = mc[r];
             mc[r] = t;
-            Or[r] += mc[r] * a1r;
-            Oi[r] += mc[r] * a1i;
+#pragma unroll
+            for (int k = 0; k < NB; ++k) { Or[r][k] += mc[r] * c1[2 * k]; Oi[r][k] += mc[r] * c1[2 * k + 1]; }
             t = al2 * x[r] * mc[r] - mp[r];
             mp[r] = mc[r];
             mc[r] = t;
@@ -111,26 +156,30 @@ CMDR_HD void leg_synth_lane(const LegArgs& A, const double* __restrict__ ast, do
 #pragma unroll
     for (int r = 0; r < R; ++r) {
         const int p = base + r * 64;
-        double* o = ph + ((int64_t)m * A.npair_pad + p) * 4;
-        o[0] = Er[r] + Or[r];
-        o[1] = Ei[r] + Oi[r];
-        o[2] = Er[r] - Or[r];
-        o[3] = Ei[r] - Oi[r];
+#pragma unroll
+        for (int k = 0; k < NB; ++k) {
+            double* o = ph + (k0 + k) * ph_stride + ((int64_t)m * A.npair_pad + p) * 4;
+            o[0] = Er[r][k] + Or[r][k];
+            o[1] = Ei[r][k] + Oi[r][k];
+            o[2] = Er[r][k] - Or[r][k];
+            o[3] = Ei[r][k] - Oi[r][k];
+        }
     }
 }
 
 // ---------------------------------------------------------------------------------------------------------
-// Legendre adjoint, per-lane state and one group of kAdjL (=8) l values.
-template <int R>
+// Legendre adjoint: per-lane state, NB maps sharing one recursion, groups of kAdjL_ (= 8) l values.
+template <int R, int NB>
 struct AdjLane {
-    double x[R], mc[R], mp[R], sc[R], sp[R], Ger[R], Gei[R], Gor[R], Goi[R];
+    double x[R], mc[R], mp[R], sc[R], sp[R];
+    double Ger[R][NB], Gei[R][NB], Gor[R][NB], Goi[R][NB];
     int ls[R];
 };
 
 // SQUARE: accumulate mu^2 * G (used for the harmonic-space noise diagonal, comm_N_mod.f90:127-197)
-template <int R, bool SQUARE>
-CMDR_HD void leg_adj_load(const LegArgs& A, const double* __restrict__ ph, int m, int chunk, int lane,
-                          AdjLane<R>& S) {
+template <int R, int NB, bool SQUARE>
+CMDR_HD void leg_adj_load(const LegArgs& A, const double* __restrict__ ph, int64_t ph_stride, int k0, int m,
+                          int chunk, int lane, AdjLane<R, NB>& S) {
     const int base = chunk * 64 * R + lane;
 #pragma unroll
     for (int r = 0; r < R; ++r) {
@@ -141,39 +190,48 @@ CMDR_HD void leg_adj_load(const LegArgs& A, const double* __restrict__ ph, int m
         S.sc[r] = A.seedc[idx];
         S.sp[r] = A.seedp[idx];
         S.mc[r] = S.mp[r] = 0.0;
-        const double* g = ph + idx * 4;
-        const double nr = g[0], ni = g[1], sr = g[2], si = g[3];
-        S.Ger[r] = nr + sr;
-        S.Gei[r] = ni + si;
-        if (SQUARE) { S.Gor[r] = nr + sr; S.Goi[r] = ni + si; }
-        else        { S.Gor[r] = nr - sr; S.Goi[r] = ni - si; }
+#pragma unroll
+        for (int k = 0; k < NB; ++k) {
+            const double* g = ph + (k0 + k) * ph_stride + idx * 4;
+            const double nr = g[0], ni = g[1], sr = g[2], si = g[3];
+            S.Ger[r][k] = nr + sr;
+            S.Gei[r][k] = ni + si;
+            if (SQUARE) { S.Gor[r][k] = nr + sr; S.Goi[r][k] = ni + si; }
+            else        { S.Gor[r][k] = nr - sr; S.Goi[r][k] = ni - si; }
+        }
     }
 }
 
-// v[2*j] , v[2*j+1] = (re, im) partial sums of this lane for l = l0 + j, j < 8
-template <int R, bool SQUARE, bool INJECT>
-CMDR_HD void leg_adj_group(const LegArgs& A, const double* __restrict__ al, int l0, AdjLane<R>& S, double* v) {
+// Advance the recursion over l0 .. l0+7 and keep the (possibly squared) mu values: w[j][r]
+template <int R, int NB, bool SQUARE, bool INJECT>
+CMDR_HD void leg_adj_mu_group(const double* __restrict__ al, int l0, AdjLane<R, NB>& S, double (*w)[R]) {
 #pragma unroll
-    for (int j = 0; j < kAdjL_; j += 2) {
+    for (int j = 0; j < kAdjL_; ++j) {
         const int l = l0 + j;
-        const double al1 = al[l + 1], al2 = al[l + 2];
-        double tr = 0.0, ti = 0.0, ur = 0.0, ui = 0.0;
+        const double al1 = al[l + 1];
 #pragma unroll
         for (int r = 0; r < R; ++r) {
             if (INJECT) if (S.ls[r] == l) { S.mc[r] = S.sc[r]; S.mp[r] = S.sp[r]; }
-            double w = SQUARE ? S.mc[r] * S.mc[r] : S.mc[r];
-            tr += w * S.Ger[r];
-            ti += w * S.Gei[r];
-            double t = al1 * S.x[r] * S.mc[r] - S.mp[r];
+            w[j][r] = SQUARE ? S.mc[r] * S.mc[r] : S.mc[r];
+            const double t = al1 * S.x[r] * S.mc[r] - S.mp[r];
             S.mp[r] = S.mc[r];
             S.mc[r] = t;
-            if (INJECT) if (S.ls[r] == l + 1) { S.mc[r] = S.sc[r]; S.mp[r] = S.sp[r]; }
-            w = SQUARE ? S.mc[r] * S.mc[r] : S.mc[r];
-            ur += w * S.Gor[r];
-            ui += w * S.Goi[r];
-            t = al2 * S.x[r] * S.mc[r] - S.mp[r];
-            S.mp[r] = S.mc[r];
-            S.mc[r] = t;
+        }
+    }
+}
+
+// v[2*j], v[2*j+1] = (re, im) partial sums of this lane for l = l0 + j (j < 8), map k
+template <int R, int NB>
+CMDR_HD void leg_adj_products(const AdjLane<R, NB>& S, const double (*w)[R], int k, double* v) {
+#pragma unroll
+    for (int j = 0; j < kAdjL_; j += 2) {
+        double tr = 0.0, ti = 0.0, ur = 0.0, ui = 0.0;
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            tr += w[j][r] * S.Ger[r][k];
+            ti += w[j][r] * S.Gei[r][k];
+            ur += w[j + 1][r] * S.Gor[r][k];
+            ui += w[j + 1][r] * S.Goi[r][k];
         }
         v[2 * j] = tr;
         v[2 * j + 1] = ti;
@@ -394,9 +452,10 @@ CMDR_HD int64_t d_packed_index(int lmax, int l, int m) {
 
 // packed a_lm -> padded-triangle complex stream entry, times cnorm * kappa_m; kappa = 1/sqrt2 for m > 0
 // (the ring stage builds X[m] += G, X[-m] += conj G), 1 for m = 0.  l = lmax+1 is the zero pad entry.
-CMDR_HD void alm_to_stream_elem(const double* __restrict__ a, double* __restrict__ o,
+CMDR_HD void alm_to_stream_elem(const double* __restrict__ a, double* __restrict__ ast, int nbs, int k,
                                 const double* __restrict__ cnorm, int lmax, int m, int l) {
     const int64_t t = d_moffp(lmax, m) + (l - m);
+    double* __restrict__ o = ast + 2 * (t * nbs + k) - 2 * t;  // so that o[2t] is this map's slot
     double re = 0.0, im = 0.0;
     if (l <= lmax) {
         const double cn = cnorm[t];

@@ -4,6 +4,7 @@
 #include <algorithm>
 #include <cmath>
 #include <complex>
+#include <cstdlib>
 #include <map>
 
 #include "common_host.hpp"
@@ -19,13 +20,16 @@ static inline double eps_lm(int l, int m) {
 static constexpr int kStartExp = -280;
 
 void LegendreTables::build(int lmax_, const std::vector<double>& x_, const std::vector<double>& sth_, int R_,
-                           int nthreads) {
+                           int Rs_, int nthreads) {
     lmax = lmax_;
     npair = (int)x_.size();
     R = R_;
+    Rs = Rs_;
     const int per = kWave * R;
-    nchunk = (npair + per - 1) / per;
-    npair_pad = nchunk * per;
+    const int padto = kWave * std::max(R, Rs);
+    npair_pad = (npair + padto - 1) / padto * padto;
+    nchunk = npair_pad / per;
+    nchunk_s = npair_pad / (kWave * Rs);
     x.assign(npair_pad, 0.0);
     sth.assign(npair_pad, 1.0);
     mlim.assign(npair_pad, -1);
@@ -45,7 +49,6 @@ void LegendreTables::build(int lmax_, const std::vector<double>& x_, const std::
     logpref[0] = -0.5 * std::log(4.0 * kPi);
     for (int m = 1; m <= lmax; ++m) logpref[m] = logpref[m - 1] + 0.5 * std::log((2.0 * m + 1.0) / (2.0 * m));
 
-    std::vector<std::vector<WaveTask>> tasks_m(nm);
     host_parallel_for(nm, [&](int mi) {
         // interleave long and short columns for balance
         const int m = (mi & 1) ? lmax - mi / 2 : mi / 2;
@@ -102,29 +105,46 @@ void LegendreTables::build(int lmax_, const std::vector<double>& x_, const std::
                 }
             }
         }
-        for (int ch = 0; ch < nchunk; ++ch) {
-            int lo = kLsNever, hi = -1;
-            for (int p = ch * per; p < (ch + 1) * per; ++p) {
-                const int v = lsm[p];
-                if (v == kLsNever) continue;
-                lo = std::min(lo, v);
-                hi = std::max(hi, v);
-            }
-            if (hi < 0) continue;
-            WaveTask t;
-            t.m = m;
-            t.chunk = ch;
-            t.lw = lo - ((lo - m) & 1);
-            int a = hi + 1;
-            a += (a - m) & 1;
-            t.lAend = a;
-            tasks_m[m].push_back(t);
-        }
     }, nthreads);
+    // ---- task lists
+    auto make_tasks = [&](int Rt, std::vector<std::vector<WaveTask>>& out) {
+        const int pr = kWave * Rt, nch = npair_pad / pr;
+        out.assign(nm, {});
+        for (int m = 0; m < nm; ++m) {
+            const int* lsm = ls.data() + (size_t)m * npair_pad;
+            for (int ch = 0; ch < nch; ++ch) {
+                int lo = kLsNever, hi = -1;
+                for (int p = ch * pr; p < (ch + 1) * pr; ++p) {
+                    const int v = lsm[p];
+                    if (v == kLsNever) continue;
+                    lo = std::min(lo, v);
+                    hi = std::max(hi, v);
+                }
+                if (hi < 0) continue;
+                WaveTask t;
+                t.m = m;
+                t.chunk = ch;
+                t.lw = lo - ((lo - m) & 1);
+                int a = hi + 1;
+                a += (a - m) & 1;
+                t.lAend = a;
+                out[m].push_back(t);
+            }
+        }
+    };
+    std::vector<std::vector<WaveTask>> tm;
+    make_tasks(R, tm);
     tasks.clear();
-    for (int m = 0; m < nm; ++m) tasks.insert(tasks.end(), tasks_m[m].begin(), tasks_m[m].end());
+    for (int m = 0; m < nm; ++m) tasks.insert(tasks.end(), tm[m].begin(), tm[m].end());
     // longest first == smallest lw first (all columns end at lmax)
     std::stable_sort(tasks.begin(), tasks.end(), [](const WaveTask& a, const WaveTask& b) { return a.lw < b.lw; });
+    while (tasks.size() % 4) { WaveTask t; t.m = 0; t.chunk = -1; t.lw = lmax + 1; t.lAend = lmax + 1; tasks.push_back(t); }
+    group = 4;
+    make_tasks(Rs, tm);
+    tasks_s.clear();
+    for (int m = 0; m < nm; ++m) tasks_s.insert(tasks_s.end(), tm[m].begin(), tm[m].end());
+    std::stable_sort(tasks_s.begin(), tasks_s.end(), [](const WaveTask& a, const WaveTask& b) { return a.lw < b.lw; });
+    while (tasks_s.size() % 4) { WaveTask t; t.m = 0; t.chunk = -1; t.lw = lmax + 1; t.lAend = lmax + 1; tasks_s.push_back(t); }
 }
 
 static int bitrev(int v, int bits) {
@@ -237,7 +257,8 @@ void RingTables::build(int nside_, int lmax_, const std::vector<int>& rings, con
     }
 }
 
-void ShtTables::build(int nside_, int lmax_, const std::vector<int>& rings_in, const double* wring, int nthreads) {
+void ShtTables::build(int nside_, int lmax_, const std::vector<int>& rings_in, const double* wring, int max_maps,
+                      int nthreads) {
     nside = nside_;
     lmax = lmax_;
     std::vector<int> rings = rings_in;
@@ -250,8 +271,16 @@ void ShtTables::build(int nside_, int lmax_, const std::vector<int>& rings_in, c
         sth[p] = r.sth;
     }
     const int np = (int)rings.size();
-    const int R = np >= 1024 ? 4 : (np >= 256 ? 2 : 1);
-    leg.build(lmax, x, sth, R, nthreads);
+    // 4 ring pairs per lane: amortises the adjoint's LDS transpose-reduce and the scalar coefficient stream of the
+    // synthesis (measured optimum on MI355X; tunable through CMDR_LEG_R / CMDR_LEG_RS).  Small problems: keep the
+    // wave count up.
+    int R = 4, Rs = 4;
+    while (R > 1 && np < 256 * R) R >>= 1;
+    while (Rs > 1 && np < 256 * Rs) Rs >>= 1;
+    if (const char* e = std::getenv("CMDR_LEG_R")) { const int v = std::atoi(e); if (v == 1 || v == 2 || v == 4) R = v; }
+    if (const char* e = std::getenv("CMDR_LEG_RS")) { const int v = std::atoi(e); if (v == 1 || v == 2 || v == 4) Rs = v; }
+    (void)max_maps;
+    leg.build(lmax, x, sth, R, Rs, nthreads);
     ring.build(nside, lmax, rings, wring, leg.mlim);
 }
 

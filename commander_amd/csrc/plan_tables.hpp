@@ -17,7 +17,7 @@ constexpr int kAdjL = 8;              // l per transpose-reduce group in the adj
 
 // Padded triangle: column m holds l = m..lmax+1 (one zero pad entry), so kernels may run l in (even, odd) pairs.
 inline int64_t moffp(int lmax, int m) { return (int64_t)m * (lmax + 2) - (int64_t)m * (m - 1) / 2; }
-inline int64_t ntrip(int lmax) { return moffp(lmax, lmax + 1) + 16; }  // + slack for look-ahead reads
+inline int64_t ntrip(int lmax) { return moffp(lmax, lmax + 1) + 16; }  // + slack for look-ahead reads (l+4)
 
 struct WaveTask {  // one wavefront's work item: 64*R colatitude pairs of one m
     int m, chunk, lw, lAend;
@@ -32,8 +32,14 @@ struct LegendreTables {
     std::vector<double> cnorm;          // [ntrip] lambda_lm = cnorm * mu_l  (pad entries 0)
     std::vector<int> ls;                // [(lmax+1) * npair_pad] first l with |mu| above threshold
     std::vector<double> seedc, seedp;   // mu_{ls}, mu_{ls-1}
-    std::vector<WaveTask> tasks;        // sorted by decreasing length
-    void build(int lmax, const std::vector<double>& x, const std::vector<double>& sth, int R, int nthreads = 0);
+    // adjoint kernel: R pairs per lane, one task per wavefront, 4 per workgroup, longest first
+    std::vector<WaveTask> tasks;
+    int group = 4;
+    // synthesis kernel: Rs pairs per lane, same layout (its own list so R and Rs can be tuned independently)
+    int Rs = 1, nchunk_s = 0;
+    std::vector<WaveTask> tasks_s;
+    void build(int lmax, const std::vector<double>& x, const std::vector<double>& sth, int R, int Rs,
+               int nthreads = 0);
 };
 
 struct RingPairDesc {   // one north/south ring pair (or the equator alone: startS = -1)
@@ -66,7 +72,10 @@ struct ShtTables {
     LegendreTables leg;
     RingTables ring;
     // rings: northern ring numbers (1..2*nside) this plan owns; empty = all (single GPU)
-    void build(int nside, int lmax, const std::vector<int>& rings, const double* wring, int nthreads = 0);
+    // max_maps: how many maps one call transforms at once; picks the ring pairs per lane R (more maps per wave ->
+    // fewer ring pairs per lane, same register budget)
+    void build(int nside, int lmax, const std::vector<int>& rings, const double* wring, int max_maps = 1,
+               int nthreads = 0);
 };
 
 // Gauss-Legendre nodes/weights on (-1,1), descending x (north first).

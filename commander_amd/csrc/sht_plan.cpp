@@ -7,6 +7,9 @@ void LegendreDev::upload(const LegendreTables& T) {
     npair_pad = T.npair_pad;
     R = T.R;
     nchunk = T.nchunk;
+    Rs = T.Rs;
+    ntasks_s = (int)T.tasks_s.size();
+    tasks_s.upload(T.tasks_s);
     ntasks = (int)T.tasks.size();
     x.upload(T.x);
     ls.upload(T.ls);
@@ -30,12 +33,18 @@ LegArgs LegendreDev::args() const {
     return A;
 }
 
+LegArgs LegendreDev::args_synth() const {
+    LegArgs A = args();
+    A.R = Rs;
+    return A;
+}
+
 ShtPlan::ShtPlan(int nside, int lmax, const std::vector<int>& rings, const double* wring, int max_maps)
     : max_maps_(max_maps) {
     CMDR_REQUIRE(nside >= 1 && (nside & (nside - 1)) == 0, "nside must be a power of two");
     CMDR_REQUIRE(lmax >= 0, "lmax must be >= 0");
     CMDR_REQUIRE(max_maps >= 1, "max_maps must be >= 1");
-    T_.build(nside, lmax, rings, wring);
+    T_.build(nside, lmax, rings, wring, max_maps);
     CMDR_REQUIRE(T_.ring.log2Mmax <= 13, "ring FFT larger than 8192 points (nside > 1024) is not supported yet");
     leg_.upload(T_.leg);
     std::vector<RingDev> rd(T_.ring.npair);
@@ -74,8 +83,8 @@ ShtPlan::ShtPlan(int nside, int lmax, const std::vector<int>& rings, const doubl
 }
 
 void ShtPlan::synth_from_stream(int nmaps, hipStream_t s) {
-    launch_leg_synth(leg_.args(), leg_.tasks.get(), leg_.ntasks, ast_.get(), leg_.tri_elems(), ph_.get(),
-                     leg_.ph_elems(), nmaps, s);
+    launch_leg_synth(leg_.args_synth(), leg_.tasks_s.get(), leg_.ntasks_s, ast_.get(), ph_.get(), leg_.ph_elems(), nmaps,
+                     s);
 }
 
 void ShtPlan::rings(int mode, double* d_map, int64_t map_stride, const double* const* d_mul, bool weighted,
@@ -98,8 +107,7 @@ void ShtPlan::alm2map(const double* d_alm, int64_t alm_stride, double* d_map, in
                       bool weighted, hipStream_t s) {
     for (int i0 = 0; i0 < nmaps; i0 += max_maps_) {
         const int nb = std::min(max_maps_, nmaps - i0);
-        launch_alm_to_stream(d_alm + i0 * alm_stride, alm_stride, ast_.get(), leg_.tri_elems(), leg_.cnorm.get(),
-                             T_.lmax, nb, s);
+        launch_alm_to_stream(d_alm + i0 * alm_stride, alm_stride, ast_.get(), leg_.cnorm.get(), T_.lmax, nb, s);
         synth_from_stream(nb, s);
         rings(0, d_map + i0 * map_stride, map_stride, nullptr, weighted, nb, s);
     }

@@ -14,11 +14,12 @@ namespace cmdr {
 class LegendreDev {  // device mirror of LegendreTables
   public:
     void upload(const LegendreTables& T);
-    LegArgs args() const;
-    int lmax = -1, npair_pad = 0, R = 1, nchunk = 0, ntasks = 0;
+    LegArgs args() const;        // adjoint kernel (R pairs per lane)
+    LegArgs args_synth() const;  // synthesis kernel (Rs pairs per lane)
+    int lmax = -1, npair_pad = 0, R = 1, Rs = 1, nchunk = 0, ntasks = 0, ntasks_s = 0;
     DevBuf<double> x, seedc, seedp, alpha, cnorm;
     DevBuf<int> ls;
-    DevBuf<WaveTask> tasks;
+    DevBuf<WaveTask> tasks, tasks_s;
     int64_t ph_elems() const { return (int64_t)(lmax + 1) * npair_pad * 4; }       // doubles per map
     int64_t tri_elems() const { return 2 * ntrip(lmax); }                          // doubles per map
 };

@@ -1,0 +1,186 @@
+!================================================================================
+! cmdr_hip_mod -- ISO_C_BINDING interface to libcmdr_hip.so (include/cmdr_hip.h),
+! written in the style of Commander3's own libsharp2 shim (commander3/src/sharp.f90:32-105).
+!
+! A Commander3 maintainer adds this file to commander3/src/, links -lcmdr_hip, and replaces the bodies of
+!   cr_matmulA / cr_invM / cr_computeRHS / solve_cr_eqn_by_CG (commander3/src/comm_cr_mod.f90)
+! by calls to the cmdr_* routines below (see INTEGRATION.md for the exact call sites).  The Fortran driver keeps
+! ownership of the RNG (planck_rng), the component list and the parameter file; only arrays cross the boundary.
+!================================================================================
+module cmdr_hip_mod
+  use iso_c_binding
+  implicit none
+
+  integer(c_int), parameter :: CMDR_YtW = 0, CMDR_Y = 1, CMDR_Yt = 2, CMDR_WY = 3   ! sharp.f90:8-14
+  integer(c_int), parameter :: CMDR_CRIT_RESIDUAL = 0, CMDR_CRIT_FIXED_ITER = 1      ! cpar%cg_conv_crit
+
+  interface
+     function cmdr_last_error() bind(c, name='cmdr_last_error') result(msg)
+       import :: c_ptr
+       type(c_ptr) :: msg
+     end function cmdr_last_error
+
+     function cmdr_device_count() bind(c, name='cmdr_device_count') result(n)
+       import :: c_int
+       integer(c_int) :: n
+     end function cmdr_device_count
+
+     ! ---- SHT level (replaces sharp_make_*_info + sharp_execute, sharp.f90:44-104)
+     function cmdr_sht_plan_create(nside, lmax, nrings, rings, wring, max_maps, plan) &
+          & bind(c, name='cmdr_sht_plan_create') result(ierr)
+       import :: c_int, c_ptr, c_double
+       integer(c_int), value        :: nside, lmax, nrings, max_maps
+       type(c_ptr),    value        :: rings     ! c_loc(info%rings) or c_null_ptr
+       type(c_ptr),    value        :: wring     ! c_loc(info%W(:,1)) or c_null_ptr
+       type(c_ptr),    intent(out)  :: plan
+       integer(c_int)               :: ierr
+     end function cmdr_sht_plan_create
+
+     function cmdr_sht_plan_destroy(plan) bind(c, name='cmdr_sht_plan_destroy') result(ierr)
+       import :: c_int, c_ptr
+       type(c_ptr), value :: plan
+       integer(c_int)     :: ierr
+     end function cmdr_sht_plan_destroy
+
+     function cmdr_sht_execute(plan, job, nmaps, alm, map) bind(c, name='cmdr_sht_execute') result(ierr)
+       import :: c_int, c_ptr
+       type(c_ptr),    value      :: plan
+       integer(c_int), value      :: job, nmaps
+       type(c_ptr),    intent(in) :: alm(*), map(*)     ! one column pointer per map, as sharp.f90:203-224
+       integer(c_int)             :: ierr
+     end function cmdr_sht_execute
+
+     ! ---- CR level
+     function cmdr_ctx_create(device, ctx) bind(c, name='cmdr_ctx_create') result(ierr)
+       import :: c_int, c_ptr
+       integer(c_int), value       :: device
+       type(c_ptr),    intent(out) :: ctx
+       integer(c_int)              :: ierr
+     end function cmdr_ctx_create
+
+     function cmdr_ctx_destroy(ctx) bind(c, name='cmdr_ctx_destroy') result(ierr)
+       import :: c_int, c_ptr
+       type(c_ptr), value :: ctx
+       integer(c_int)     :: ierr
+     end function cmdr_ctx_destroy
+
+     function cmdr_ctx_set_rings(ctx, nside, nrings, rings) bind(c, name='cmdr_ctx_set_rings') result(ierr)
+       import :: c_int, c_ptr
+       type(c_ptr),    value      :: ctx
+       integer(c_int), value      :: nside, nrings
+       integer(c_int), intent(in) :: rings(nrings)
+       integer(c_int)             :: ierr
+     end function cmdr_ctx_set_rings
+
+     function cmdr_ctx_set_allreduce(ctx, fn, user) bind(c, name='cmdr_ctx_set_allreduce') result(ierr)
+       import :: c_int, c_ptr, c_funptr
+       type(c_ptr),    value :: ctx, user
+       type(c_funptr), value :: fn          ! subroutine(user, dev_ptr, n) bind(c)
+       integer(c_int)        :: ierr
+     end function cmdr_ctx_set_allreduce
+
+     function cmdr_band_add(ctx, nside, lmax, nmaps, siN, b_l, mb_eff, sg_mask, wring) &
+          & bind(c, name='cmdr_band_add') result(idx)
+       import :: c_int, c_ptr, c_double
+       type(c_ptr),    value      :: ctx
+       integer(c_int), value      :: nside, lmax, nmaps
+       real(c_double), intent(in) :: siN(*), b_l(*)
+       real(c_double), value      :: mb_eff
+       type(c_ptr),    value      :: sg_mask, wring      ! c_loc(...) or c_null_ptr
+       integer(c_int)             :: idx
+     end function cmdr_band_add
+
+     function cmdr_comp_add(ctx, lmax_amp, nmaps, lmax_cl, sqrtS_mat, sqrtInvS_mat, S_mat, F_mean, active) &
+          & bind(c, name='cmdr_comp_add') result(idx)
+       import :: c_int, c_ptr, c_double
+       type(c_ptr),    value      :: ctx
+       integer(c_int), value      :: lmax_amp, nmaps, lmax_cl, active
+       type(c_ptr),    value      :: sqrtS_mat, sqrtInvS_mat, S_mat   ! c_loc(c%Cl%sqrtS_mat) ... or c_null_ptr
+       real(c_double), intent(in) :: F_mean(*)
+       integer(c_int)             :: idx
+     end function cmdr_comp_add
+
+     function cmdr_finalize(ctx) bind(c, name='cmdr_finalize') result(ierr)
+       import :: c_int, c_ptr
+       type(c_ptr), value :: ctx
+       integer(c_int)     :: ierr
+     end function cmdr_finalize
+
+     function cmdr_ncr(ctx) bind(c, name='cmdr_ncr') result(n)
+       import :: c_int64_t, c_ptr
+       type(c_ptr), value :: ctx
+       integer(c_int64_t) :: n
+     end function cmdr_ncr
+
+     function cmdr_precond_init_diag(ctx) bind(c, name='cmdr_precond_init_diag') result(ierr)
+       import :: c_int, c_ptr
+       type(c_ptr), value :: ctx
+       integer(c_int)     :: ierr
+     end function cmdr_precond_init_diag
+
+     function cmdr_precond_update_diag(ctx) bind(c, name='cmdr_precond_update_diag') result(ierr)
+       import :: c_int, c_ptr
+       type(c_ptr), value :: ctx
+       integer(c_int)     :: ierr
+     end function cmdr_precond_update_diag
+
+     function cmdr_matmulA(ctx, x, y) bind(c, name='cmdr_matmulA') result(ierr)
+       import :: c_int, c_ptr, c_double
+       type(c_ptr),    value       :: ctx
+       real(c_double), intent(in)  :: x(*)
+       real(c_double), intent(out) :: y(*)
+       integer(c_int)              :: ierr
+     end function cmdr_matmulA
+
+     function cmdr_invM(ctx, x, y) bind(c, name='cmdr_invM') result(ierr)
+       import :: c_int, c_ptr, c_double
+       type(c_ptr),    value       :: ctx
+       real(c_double), intent(in)  :: x(*)
+       real(c_double), intent(out) :: y(*)
+       integer(c_int)              :: ierr
+     end function cmdr_invM
+
+     function cmdr_compute_rhs(ctx, sample, resid, xi, eta, mu, rhs) bind(c, name='cmdr_compute_rhs') result(ierr)
+       import :: c_int, c_ptr, c_double
+       type(c_ptr),    value       :: ctx
+       integer(c_int), value       :: sample
+       type(c_ptr),    intent(in)  :: resid(*), xi(*)    ! c_loc(map%map) per band
+       type(c_ptr),    value       :: eta, mu            ! c_loc(...) or c_null_ptr
+       real(c_double), intent(out) :: rhs(*)
+       integer(c_int)              :: ierr
+     end function cmdr_compute_rhs
+
+     function cmdr_solve(ctx, b, x, crit, tol, miniter, maxiter, check_freq, x0, niter, res, stat) &
+          & bind(c, name='cmdr_solve') result(ierr)
+       import :: c_int, c_ptr, c_double
+       type(c_ptr),    value       :: ctx
+       real(c_double), intent(in)  :: b(*)
+       real(c_double), intent(out) :: x(*)
+       integer(c_int), value       :: crit, miniter, maxiter, check_freq
+       real(c_double), value       :: tol
+       type(c_ptr),    value       :: x0                 ! c_null_ptr <=> cpar%cg_init_zero
+       integer(c_int), intent(out) :: niter, stat
+       real(c_double), intent(out) :: res(2)
+       integer(c_int)              :: ierr
+     end function cmdr_solve
+  end interface
+
+contains
+
+  subroutine cmdr_check(ierr, where)
+    integer(c_int),   intent(in) :: ierr
+    character(len=*), intent(in) :: where
+    character(kind=c_char), pointer :: cmsg(:)
+    integer :: i
+    if (ierr >= 0) return
+    call c_f_pointer(cmdr_last_error(), cmsg, [512])
+    write(*,'(a)',advance='no') 'cmdr_hip error in '//trim(where)//': '
+    do i = 1, 512
+       if (cmsg(i) == c_null_char) exit
+       write(*,'(a)',advance='no') cmsg(i)
+    end do
+    write(*,*)
+    stop 1
+  end subroutine cmdr_check
+
+end module cmdr_hip_mod

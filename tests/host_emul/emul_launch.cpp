@@ -10,61 +10,99 @@
 
 namespace cmdr {
 
-template <int R>
-static void synth_R(const LegArgs& A, const WaveTask* tasks, int ntasks, const double* ast, double* ph) {
+int leg_max_batch(int R) { return R == 1 ? 9 : (R == 2 ? 4 : 2); }
+
+template <int R, int NB>
+static void synth_RN(const LegArgs& A, const WaveTask* tasks, int ntasks, const double* ast, int nbs, int k0,
+                     double* ph, int64_t ph_stride) {
     for (int t = 0; t < ntasks; ++t)
-        for (int lane = 0; lane < 64; ++lane)
-            leg_synth_lane<R>(A, ast, ph, tasks[t].m, tasks[t].chunk, tasks[t].lw, tasks[t].lAend, lane);
+        for (int lane = 0; lane < 64 && tasks[t].chunk >= 0; ++lane)
+            leg_synth_lane<R, NB>(A, ast, nbs, k0, ph, ph_stride, tasks[t].m, tasks[t].chunk, tasks[t].lw,
+                                  tasks[t].lAend, lane);
 }
-void launch_leg_synth(const LegArgs& A, const WaveTask* tasks, int ntasks, const double* ast, int64_t ast_stride,
-                      double* ph, int64_t ph_stride, int nmaps, hipStream_t) {
-    for (int k = 0; k < nmaps; ++k) {
-        if (A.R == 1) synth_R<1>(A, tasks, ntasks, ast + k * ast_stride, ph + k * ph_stride);
-        else if (A.R == 2) synth_R<2>(A, tasks, ntasks, ast + k * ast_stride, ph + k * ph_stride);
-        else synth_R<4>(A, tasks, ntasks, ast + k * ast_stride, ph + k * ph_stride);
+void launch_leg_synth(const LegArgs& A, const WaveTask* tasks, int ntasks, const double* ast, double* ph,
+                      int64_t ph_stride, int nmaps, hipStream_t) {
+    const int nbmax = leg_max_batch(A.R);
+    for (int k0 = 0; k0 < nmaps; k0 += nbmax) {
+        const int nb = std::min(nbmax, nmaps - k0);
+#define CMDR_S(RR, NN) case NN: synth_RN<RR, NN>(A, tasks, ntasks, ast, nmaps, k0, ph, ph_stride); break;
+        if (A.R == 1) {
+            switch (nb) { CMDR_S(1, 1) CMDR_S(1, 2) CMDR_S(1, 3) CMDR_S(1, 4) CMDR_S(1, 5) CMDR_S(1, 6) CMDR_S(1, 7)
+                          CMDR_S(1, 8) CMDR_S(1, 9) }
+        } else if (A.R == 2) {
+            switch (nb) { CMDR_S(2, 1) CMDR_S(2, 2) CMDR_S(2, 3) CMDR_S(2, 4) }
+        } else {
+            switch (nb) { CMDR_S(4, 1) CMDR_S(4, 2) }
+        }
+#undef CMDR_S
     }
 }
 
-template <int R, bool SQ>
-static void adj_R(const LegArgs& A, const WaveTask* tasks, int ntasks, const double* ph, double* part, int64_t pcs) {
+template <int R, int NB, bool SQ>
+static void adj_RN(const LegArgs& A, const WaveTask* tasks, int ntasks, const double* ph, int64_t ph_stride, int k0,
+                   double* part, int64_t pms, int64_t pcs) {
     const int lmax = A.lmax;
     for (int ti = 0; ti < ntasks; ++ti) {
         const WaveTask t = tasks[ti];
-        std::vector<AdjLane<R>> S(64);
-        for (int lane = 0; lane < 64; ++lane) leg_adj_load<R, SQ>(A, ph, t.m, t.chunk, lane, S[lane]);
+        if (t.chunk < 0) continue;
+        std::vector<AdjLane<R, NB>> S(64);
+        for (int lane = 0; lane < 64; ++lane) leg_adj_load<R, NB, SQ>(A, ph, ph_stride, k0, t.m, t.chunk, lane, S[lane]);
         const int64_t mo = d_moffp(lmax, t.m);
         const double* al = A.alpha + (mo - t.m);
-        double* out = part + t.chunk * pcs + 2 * (mo - t.m);
+        double* out0 = part + t.chunk * pcs + 2 * (mo - t.m);
+        std::vector<double> wbuf((size_t)64 * kAdjL_ * R);
         for (int l0 = t.lw; l0 <= lmax; l0 += kAdjL_) {
-            double wl[16 * 65];
             for (int lane = 0; lane < 64; ++lane) {
-                double v[16];
-                if (l0 < t.lAend) leg_adj_group<R, SQ, true>(A, al, l0, S[lane], v);
-                else leg_adj_group<R, SQ, false>(A, al, l0, S[lane], v);
-                for (int j = 0; j < 16; ++j) wl[j * 65 + lane] = v[j];
+                double (*w)[R] = reinterpret_cast<double (*)[R]>(wbuf.data() + (size_t)lane * kAdjL_ * R);
+                if (l0 < t.lAend) leg_adj_mu_group<R, NB, SQ, true>(al, l0, S[lane], w);
+                else leg_adj_mu_group<R, NB, SQ, false>(al, l0, S[lane], w);
             }
-            for (int col = 0; col < 16; ++col) {   // device order: quarter sums, then xor-16, xor-32 butterflies
-                double q[4];
-                for (int qt = 0; qt < 4; ++qt) {
-                    double s = 0.0;
-                    for (int i = 0; i < 16; ++i) s += wl[col * 65 + qt * 16 + i];
-                    q[qt] = s;
+            for (int k = 0; k < NB; ++k) {
+                double wl[16 * 65];
+                for (int lane = 0; lane < 64; ++lane) {
+                    double v[16];
+                    const double (*w)[R] = reinterpret_cast<const double (*)[R]>(wbuf.data() + (size_t)lane * kAdjL_ * R);
+                    leg_adj_products<R, NB>(S[lane], w, k, v);
+                    for (int j = 0; j < 16; ++j) wl[j * 65 + lane] = v[j];
                 }
-                const double s = (q[0] + q[1]) + (q[2] + q[3]);
-                const int l = l0 + (col >> 1);
-                if (l <= lmax) out[2 * l + (col & 1)] = s;
+                for (int col = 0; col < 16; ++col) {  // device order: quarter sums, then xor-16 / xor-32 butterflies
+                    double q[4];
+                    for (int qt = 0; qt < 4; ++qt) {
+                        double s = 0.0;
+                        for (int i = 0; i < 16; ++i) s += wl[col * 65 + qt * 16 + i];
+                        q[qt] = s;
+                    }
+                    const double s = (q[0] + q[1]) + (q[2] + q[3]);
+                    const int l = l0 + (col >> 1);
+                    if (l <= lmax) out0[(k0 + k) * pms + 2 * l + (col & 1)] = s;
+                }
             }
         }
     }
 }
 void launch_leg_adj(const LegArgs& A, const WaveTask* tasks, int ntasks, const double* ph, int64_t ph_stride,
                     double* part, int64_t pms, int64_t pcs, int nmaps, bool square, hipStream_t) {
-    for (int k = 0; k < nmaps; ++k) {
-        const double* p = ph + k * ph_stride;
-        double* o = part + k * pms;
-#define CMDR_E(RR) if (square) adj_R<RR, true>(A, tasks, ntasks, p, o, pcs); else adj_R<RR, false>(A, tasks, ntasks, p, o, pcs);
-        if (A.R == 1) { CMDR_E(1) } else if (A.R == 2) { CMDR_E(2) } else { CMDR_E(4) }
-#undef CMDR_E
+    if (square) {
+        for (int k0 = 0; k0 < nmaps; ++k0) {
+            if (A.R == 1) adj_RN<1, 1, true>(A, tasks, ntasks, ph, ph_stride, k0, part, pms, pcs);
+            else if (A.R == 2) adj_RN<2, 1, true>(A, tasks, ntasks, ph, ph_stride, k0, part, pms, pcs);
+            else adj_RN<4, 1, true>(A, tasks, ntasks, ph, ph_stride, k0, part, pms, pcs);
+        }
+        return;
+    }
+    const int nbmax = leg_max_batch(A.R);
+    for (int k0 = 0; k0 < nmaps; k0 += nbmax) {
+        const int nb = std::min(nbmax, nmaps - k0);
+#define CMDR_A(RR, NN) case NN: adj_RN<RR, NN, false>(A, tasks, ntasks, ph, ph_stride, k0, part, pms, pcs); break;
+        if (A.R == 1) {
+            switch (nb) { CMDR_A(1, 1) CMDR_A(1, 2) CMDR_A(1, 3) CMDR_A(1, 4) CMDR_A(1, 5) CMDR_A(1, 6) CMDR_A(1, 7)
+                          CMDR_A(1, 8) CMDR_A(1, 9) }
+        } else if (A.R == 2) {
+            switch (nb) { CMDR_A(2, 1) CMDR_A(2, 2) CMDR_A(2, 3) CMDR_A(2, 4) }
+        } else {
+            switch (nb) { CMDR_A(4, 1) CMDR_A(4, 2) }
+        }
+#undef CMDR_A
     }
 }
 
@@ -106,12 +144,12 @@ void launch_ring(int mode, const RingDev* rings, const int* cls, int ncls, int l
         }
 }
 
-void launch_alm_to_stream(const double* alm, int64_t alm_stride, double* ast, int64_t ast_stride,
-                          const double* cnorm, int lmax, int nmaps, hipStream_t) {
+void launch_alm_to_stream(const double* alm, int64_t alm_stride, double* ast, const double* cnorm, int lmax,
+                          int nmaps, hipStream_t) {
     for (int k = 0; k < nmaps; ++k)
         for (int m = 0; m <= lmax; ++m)
             for (int l = m; l <= lmax + 1; ++l)
-                alm_to_stream_elem(alm + k * alm_stride, ast + k * ast_stride, cnorm, lmax, m, l);
+                alm_to_stream_elem(alm + k * alm_stride, ast, nmaps, k, cnorm, lmax, m, l);
 }
 void launch_part_to_alm(const double* part, int64_t pms, int64_t pcs, int nchunk, double* alm, int64_t alm_stride,
                         const double* cnorm, int lmax, int nmaps, hipStream_t) {
@@ -128,12 +166,12 @@ void launch_sqrtS(const CompDev* comps, int ncomp, int, const double* smat, int 
             for (int l = m; l <= comps[c].lmax; ++l) sqrtS_elem(comps[c], smat, kind, in, add, out, m, l, pass_inactive);
 }
 void launch_band_prep(const CompDev* comps, int ncomp, const double* sx, const double* w, const int* bm_stokes,
-                      double* ast, int64_t ast_stride, const double* cnorm, int lmax_g, int nbm, hipStream_t) {
+                      double* ast, const double* cnorm, int lmax_g, int nbm, hipStream_t) {
     for (int bm = 0; bm < nbm; ++bm)
         for (int m = 0; m <= lmax_g; ++m)
             for (int l = m; l <= lmax_g + 1; ++l)
-                band_prep_elem(comps, ncomp, sx, w + (int64_t)bm * ncomp * (lmax_g + 1), bm_stokes[bm],
-                               ast + bm * ast_stride, cnorm, lmax_g, m, l);
+                band_prep_elem(comps, ncomp, sx, w + (int64_t)bm * ncomp * (lmax_g + 1), bm_stokes[bm], ast, nbm, bm,
+                               cnorm, lmax_g, m, l);
 }
 void launch_band_post(const CompDev* comps, int ncomp, int, const double* part, int64_t pms, int64_t pcs,
                       int nchunk, int nbm, const int* bm_stokes, const double* w, const double* cnorm, int lmax_g,
