@@ -160,7 +160,7 @@ void launch_leg_adj(const LegArgs& A, const WaveTask* tasks, int ntasks, const d
 //   MODE 1: pixels -> phases (map2alm head)         in  map * (mul ? mul[pix] : 1) * (weighted ? wgt : 1)
 //   MODE 2: phases -> pixels * mul[pix] -> phases   (fused Y, N^-1, Y^T of the CR matvec; map never hits HBM)
 template <int MODE>
-__global__ void __launch_bounds__(512) k_ring(const RingDev* __restrict__ rings, const int* __restrict__ cls,
+__global__ void __launch_bounds__(1024) k_ring(const RingDev* __restrict__ rings, const int* __restrict__ cls,
                                               double* __restrict__ ph, int64_t ph_stride, int64_t npair_pad,
                                               double* __restrict__ map, int64_t map_stride,
                                               const double* const* __restrict__ mul, int weighted,
@@ -183,7 +183,7 @@ __global__ void __launch_bounds__(512) k_ring(const RingDev* __restrict__ rings,
     }
     if (MODE == 0) {
         for (int k = c.tid; k < n; k += c.nthr) {
-            const cd v = buf[k];
+            const cd v = buf[lds_pad(k)];
             const double fn = wg * (mu ? mu[d.startN + k] : 1.0);
             mp[d.startN + k] = v.x * fn;
             if (d.startS >= 0) {
@@ -201,29 +201,31 @@ __global__ void __launch_bounds__(512) k_ring(const RingDev* __restrict__ rings,
                 const double fs = wg * (mu ? mu[d.startS + k] : 1.0);
                 v.y = mp[d.startS + k] * fs;
             }
-            buf[k] = v;
+            buf[lds_pad(k)] = v;
         }
         __syncthreads();
     }
     if (MODE == 2) {
         for (int k = c.tid; k < n; k += c.nthr) {
-            cd v = buf[k];
+            cd v = buf[lds_pad(k)];
             v.x *= mu[d.startN + k];
             v.y = d.startS >= 0 ? v.y * mu[d.startS + k] : 0.0;
-            buf[k] = v;
+            buf[lds_pad(k)] = v;
         }
         __syncthreads();
     }
     ring_anal_lds(buf, d, tw, log2Mmax, chirp, c);
-    ring_store_phases(buf, d, php, npair_pad, pair, c);
+    ring_store_phases(buf, d, php, npair_pad, pair, chirp, c);
 }
 
 void launch_ring(int mode, const RingDev* rings, const int* cls, int ncls, int log2M, double* ph,
                  int64_t ph_stride, int64_t npair_pad, double* map, int64_t map_stride, const double* const* mul,
                  int weighted, const cd* tw, int log2Mmax, const cd* chirp, int nmaps, hipStream_t s) {
     if (ncls == 0 || nmaps == 0) return;
-    const size_t lds = (size_t)sizeof(cd) << log2M;
-    const int nthr = log2M >= 13 ? 512 : 256;
+    const size_t lds = sizeof(cd) * (size_t)lds_elems(log2M);
+    int nthr = 512;   // measured: 512 > 256 threads per ring pair (more waves to cover LDS / global latency)
+    if (const char* e = std::getenv("CMDR_RING_THREADS")) { const int v = std::atoi(e); if (v == 256 || v == 512 || v == 1024) nthr = v; }
+    if (nthr > (1 << log2M) / 2) nthr = std::max(64, (1 << log2M) / 2);
     dim3 grid(ncls, nmaps);
 #define CMDR_RING(MM)                                                                                            \
     do {                                                                                                         \

@@ -241,7 +241,10 @@ CMDR_HD void leg_adj_products(const AdjLane<R, NB>& S, const double (*w)[R], int
 }
 
 // ---------------------------------------------------------------------------------------------------------
-// Ring FFT pieces.  buf = LDS array of M complex; tw = exp(+2 pi i k / Mmax), k < Mmax/2.
+// Ring FFT pieces.  buf = LDS image of M complex at padded positions lds_pad(i) (one 16-B pad per 8 elements, so
+// that both "8 consecutive elements per lane" and "stride-h" register passes are bank-conflict free);
+// tw = exp(+2 pi i k / Mmax), k < Mmax/2.  Transforms run as register passes of up to 3 radix-2 stages (radix-8
+// butterflies): 12 stages = 4 passes = 4 barriers instead of 12.
 struct FftCtx {
     int tid, nthr;
 };
@@ -252,40 +255,83 @@ struct FftCtx {
 #define CMDR_BLOCK_SYNC() ((void)0)
 #endif
 
-// natural order in -> bit-reversed order out, kernel exp(+2 pi i jk/M)
-CMDR_HD void fft_dif_plus(cd* buf, int log2M, const cd* __restrict__ tw, int log2Mmax, FftCtx c) {
-    const int M = 1 << log2M;
-    for (int s = log2M; s >= 1; --s) {
-        const int half = 1 << (s - 1);
-        const int tws = log2Mmax - s;  // twiddle stride = Mmax/len
-        for (int b = c.tid; b < (M >> 1); b += c.nthr) {
-            const int pos = b & (half - 1);
-            const int i0 = ((b >> (s - 1)) << s) + pos;
-            const int i1 = i0 + half;
-            const cd u = buf[i0], v = buf[i1];
-            buf[i0] = cadd(u, v);
-            buf[i1] = cmul(csub(u, v), tw[pos << tws]);
+CMDR_HD int lds_pad(int i) { return i + (i >> 3); }
+CMDR_HD int lds_elems(int log2M) { return (1 << log2M) + (1 << log2M >> 3) + 1; }
+
+// K radix-2 DIT stages (halves h, 2h, .. h<<(K-1), h = 1<<hl) on the 2^K elements i0 + j*h held in registers.
+// bit-reversed order in -> natural order out, kernel exp(+2 pi i jk/M)
+template <int K>
+CMDR_HD void fft_dit_pass(cd* buf, int log2M, int hl, const cd* __restrict__ tw, int log2Mmax, FftCtx c) {
+    constexpr int N = 1 << K;
+    const int ngroups = 1 << (log2M - K);
+    const int hmask = (1 << hl) - 1;
+    for (int g = c.tid; g < ngroups; g += c.nthr) {
+        const int pos = g & hmask;
+        const int i0 = ((g >> hl) << (hl + K)) + pos;
+        cd v[N];
+#pragma unroll
+        for (int j = 0; j < N; ++j) v[j] = buf[lds_pad(i0 + (j << hl))];
+#pragma unroll
+        for (int t = 0; t < K; ++t) {
+#pragma unroll
+            for (int j = 0; j < N; ++j) {
+                if (j & (1 << t)) continue;
+                const int e = pos + ((j & ((1 << t) - 1)) << hl);             // < h << t
+                const cd w = tw[e << (log2Mmax - (hl + t + 1))];
+                const cd u = v[j], x = cmul(v[j + (1 << t)], w);
+                v[j] = cadd(u, x);
+                v[j + (1 << t)] = csub(u, x);
+            }
         }
-        CMDR_BLOCK_SYNC();
+#pragma unroll
+        for (int j = 0; j < N; ++j) buf[lds_pad(i0 + (j << hl))] = v[j];
     }
+    CMDR_BLOCK_SYNC();
 }
 
-// bit-reversed order in -> natural order out, kernel exp(+2 pi i jk/M)
-CMDR_HD void fft_dit_plus(cd* buf, int log2M, const cd* __restrict__ tw, int log2Mmax, FftCtx c) {
-    const int M = 1 << log2M;
-    for (int s = 1; s <= log2M; ++s) {
-        const int half = 1 << (s - 1);
-        const int tws = log2Mmax - s;
-        for (int b = c.tid; b < (M >> 1); b += c.nthr) {
-            const int pos = b & (half - 1);
-            const int i0 = ((b >> (s - 1)) << s) + pos;
-            const int i1 = i0 + half;
-            const cd u = buf[i0], v = cmul(buf[i1], tw[pos << tws]);
-            buf[i0] = cadd(u, v);
-            buf[i1] = csub(u, v);
+// K radix-2 DIF stages (halves h<<(K-1), .., 2h, h).  natural order in -> bit-reversed order out.
+template <int K>
+CMDR_HD void fft_dif_pass(cd* buf, int log2M, int hl, const cd* __restrict__ tw, int log2Mmax, FftCtx c) {
+    constexpr int N = 1 << K;
+    const int ngroups = 1 << (log2M - K);
+    const int hmask = (1 << hl) - 1;
+    for (int g = c.tid; g < ngroups; g += c.nthr) {
+        const int pos = g & hmask;
+        const int i0 = ((g >> hl) << (hl + K)) + pos;
+        cd v[N];
+#pragma unroll
+        for (int j = 0; j < N; ++j) v[j] = buf[lds_pad(i0 + (j << hl))];
+#pragma unroll
+        for (int t = K - 1; t >= 0; --t) {
+#pragma unroll
+            for (int j = 0; j < N; ++j) {
+                if (j & (1 << t)) continue;
+                const int e = pos + ((j & ((1 << t) - 1)) << hl);
+                const cd w = tw[e << (log2Mmax - (hl + t + 1))];
+                const cd u = v[j], x = v[j + (1 << t)];
+                v[j] = cadd(u, x);
+                v[j + (1 << t)] = cmul(csub(u, x), w);
+            }
         }
-        CMDR_BLOCK_SYNC();
+#pragma unroll
+        for (int j = 0; j < N; ++j) buf[lds_pad(i0 + (j << hl))] = v[j];
     }
+    CMDR_BLOCK_SYNC();
+}
+
+CMDR_HD void fft_dit_plus(cd* buf, int log2M, const cd* __restrict__ tw, int log2Mmax, FftCtx c) {
+    int hl = 0;
+    const int k0 = log2M % 3;
+    if (k0 == 1) { fft_dit_pass<1>(buf, log2M, 0, tw, log2Mmax, c); hl = 1; }
+    else if (k0 == 2) { fft_dit_pass<2>(buf, log2M, 0, tw, log2Mmax, c); hl = 2; }
+    for (; hl < log2M; hl += 3) fft_dit_pass<3>(buf, log2M, hl, tw, log2Mmax, c);
+}
+
+CMDR_HD void fft_dif_plus(cd* buf, int log2M, const cd* __restrict__ tw, int log2Mmax, FftCtx c) {
+    const int k0 = log2M % 3;
+    for (int hl = log2M - 3; hl >= k0; hl -= 3) fft_dif_pass<3>(buf, log2M, hl, tw, log2Mmax, c);
+    if (k0 == 1) fft_dif_pass<1>(buf, log2M, 0, tw, log2Mmax, c);
+    else if (k0 == 2) fft_dif_pass<2>(buf, log2M, 0, tw, log2Mmax, c);
 }
 
 CMDR_HD int d_bitrev(int v, int bits) {
@@ -302,143 +348,182 @@ struct RingDev {  // device mirror of RingPairDesc
     int nphi, log2M, bluestein, mmax_eff;
     long long startN, startS;
     double phi0, wgt;
-    long long chirp_off;
+    long long chirp_off;   // per-length table: rot[n] (, w[n], chat[M] for Bluestein)
     int ring, pad;
 };
 
-// exp(i * m * phi0) for HEALPix: phi0 = pi/(4 i) (cap), pi/(4 N) or 0 (belt) -> exact argument reduction on
-// integers before the libm call: m*phi0 = 2 pi (m mod 8q) / (8 q).
-CMDR_HD cd phase_mphi0(int m, int q /* 8q = period; q=0: phi0=0 */) {
-    if (q == 0) return {1.0, 0.0};
-    const int per = 8 * q;
-    const int k = m % per;
-    const double ang = 6.283185307179586476925286766559 * (double)k / (double)per;
-    double s, c;
-#if defined(__HIPCC__) && defined(__HIP_DEVICE_COMPILE__)
-    sincos(ang, &s, &c);
-#else
-    s = __builtin_sin(ang);
-    c = __builtin_cos(ang);
-#endif
-    return {c, s};
-}
-
-// Build the packed spectrum Z_j = X^N_j + i X^S_j (j < n) of a ring pair from its phases, store at buf[pos(j)].
-//   X[m mod n] += G_m ; X[(-m) mod n] += conj(G_m) (m>0) ; G_m = kappa_m F_m e^{i m phi0}; kappa = 1 (m=0) (sqrt2 is
-//   already folded into the coefficient stream).
-// Gather form (slot j sums its aliases) so no atomics are needed.  For Bluestein the slot is pre-multiplied by
-// the chirp and conjugated (see ring_synth_finish).
-CMDR_HD cd ring_gather_slot(const double* __restrict__ ph, int64_t npair_pad, int pair, int n, int mmax, int q,
-                            int j) {
-    cd z = {0.0, 0.0};
+// HEALPix rings have n*phi0 = pi (phi0 = pi/(4i), n = 4i; belt: pi/(4N), n = 4N) or phi0 = 0, hence
+//   e^{i (j + k n) phi0} = (-1)^k rot_j ,  e^{i (k n - j) phi0} = (-1)^k conj(rot_j) ,  rot_j = e^{i pi j / n}
+// and one tabulated rotation per slot replaces every sincos.  For phi0 = 0 the (-1)^k signs disappear.
+//
+// Packed spectrum slot j of a ring pair from its phases (gather form, no atomics):
+//   Z_j = X^N_j + i X^S_j ,  X_j = rot_j [ sum_k s^k F_{j+kn} + sum_{k>=1} s^k conj F_{kn-j} ],  s = -1 (or +1)
+CMDR_HD cd ring_gather_slot(const double* __restrict__ ph, int64_t npair_pad, int pair, int n, int mmax, cd rot,
+                            bool flip, int j) {
+    double nr = 0.0, ni = 0.0, sr = 0.0, si = 0.0;
+    double sg = 1.0;
     for (int m = j; m <= mmax; m += n) {  // direct aliases
         const double* f = ph + ((int64_t)m * npair_pad + pair) * 4;
-        const cd e = phase_mphi0(m, q);
-        const cd gn = cmul({f[0], f[1]}, e), gs = cmul({f[2], f[3]}, e);
-        // Z += gn + i gs
-        z.x += gn.x - gs.y;
-        z.y += gn.y + gs.x;
+        nr += sg * f[0]; ni += sg * f[1]; sr += sg * f[2]; si += sg * f[3];
+        if (flip) sg = -sg;
     }
+    sg = flip ? -1.0 : 1.0;
     for (int m = (j == 0 ? n : n - j); m <= mmax; m += n) {  // conjugate aliases (m > 0)
         const double* f = ph + ((int64_t)m * npair_pad + pair) * 4;
-        const cd e = phase_mphi0(m, q);
-        const cd gn = cconj(cmul({f[0], f[1]}, e)), gs = cconj(cmul({f[2], f[3]}, e));
-        z.x += gn.x - gs.y;
-        z.y += gn.y + gs.x;
+        nr += sg * f[0]; ni -= sg * f[1]; sr += sg * f[2]; si -= sg * f[3];
+        if (flip) sg = -sg;
     }
-    return z;
+    const cd gn = cmul({nr, ni}, rot), gs = cmul({sr, si}, rot);
+    return {gn.x - gs.y, gn.y + gs.x};   // gn + i gs
 }
 
-// Full inverse (synthesis) ring transform in LDS: on return buf[k], k<n holds y^N_k + i y^S_k (natural order).
+// Scatter form of the spectrum build for rings without aliasing (n > 2 mmax: the belt and the larger cap rings, i.e.
+// almost all of the work): every m owns slot m and slot n-m exclusively, so each thread streams its m values with
+// independent (unrolled) global loads instead of a dependent gather per slot.
+//   BLUE: slot value is conj(Z_j w_j) at natural position (Bluestein input); else Z_j at the bit-reversed position.
+template <bool BLUE>
+CMDR_HD void ring_scatter(cd* buf, const RingDev& d, const double* __restrict__ ph, int64_t npair_pad, int pair,
+                          const cd* __restrict__ rot, const cd* __restrict__ w, FftCtx c) {
+    const int n = d.nphi, M = 1 << d.log2M, mmax = d.mmax_eff;
+    const bool flip = d.phi0 != 0.0;
+    for (int j = c.tid; j < (BLUE ? M : n); j += c.nthr) buf[lds_pad(j)] = {0.0, 0.0};
+    CMDR_BLOCK_SYNC();
+    constexpr int U = 4;
+    for (int m0 = c.tid; m0 <= mmax; m0 += U * c.nthr) {
+        double f[U][4];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int m = m0 + u * c.nthr;
+            const double* q = ph + ((int64_t)(m <= mmax ? m : mmax) * npair_pad + pair) * 4;
+            f[u][0] = q[0]; f[u][1] = q[1]; f[u][2] = q[2]; f[u][3] = q[3];
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int m = m0 + u * c.nthr;
+            if (m > mmax) continue;
+            const cd r = flip ? rot[m] : cd{1.0, 0.0};
+            const cd gn = cmul({f[u][0], f[u][1]}, r), gs = cmul({f[u][2], f[u][3]}, r);
+            cd z = {gn.x - gs.y, gn.y + gs.x};          // X^N_m + i X^S_m
+            cd zc = {gn.x + gs.y, gs.x - gn.y};         // conj(gn) + i conj(gs)  -> slot n - m
+            if (BLUE) {
+                buf[lds_pad(m)] = cconj(cmul(z, w[m]));
+                if (m > 0) buf[lds_pad(n - m)] = cconj(cmul(zc, w[n - m]));
+            } else {
+                buf[lds_pad(d_bitrev(m, d.log2M))] = z;
+                if (m > 0) buf[lds_pad(d_bitrev(n - m, d.log2M))] = zc;
+            }
+        }
+    }
+    CMDR_BLOCK_SYNC();
+}
+
+// Full inverse (synthesis) ring transform in LDS: on return buf[lds_pad(k)], k<n holds y^N_k + i y^S_k.
 CMDR_HD void ring_synth_lds(cd* buf, const RingDev& d, const double* __restrict__ ph, int64_t npair_pad, int pair,
                             const cd* __restrict__ tw, int log2Mmax, const cd* __restrict__ chirp, FftCtx c) {
     const int n = d.nphi, M = 1 << d.log2M;
-    const int q = d.phi0 == 0.0 ? 0 : n / 4;  // phi0 = pi/(4i) with n = 4i (cap) or pi/(4N) with n = 4N (belt)
+    const bool flip = d.phi0 != 0.0;
+    const cd* rot = chirp + d.chirp_off;   // rot_j, j < n
+    const bool noalias = n > 2 * d.mmax_eff;
     if (!d.bluestein) {
-        for (int j = c.tid; j < n; j += c.nthr)
-            buf[d_bitrev(j, d.log2M)] = ring_gather_slot(ph, npair_pad, pair, n, d.mmax_eff, q, j);
-        CMDR_BLOCK_SYNC();
+        if (noalias) {
+            ring_scatter<false>(buf, d, ph, npair_pad, pair, rot, nullptr, c);
+        } else {
+            for (int j = c.tid; j < n; j += c.nthr) {
+                const cd r = flip ? rot[j] : cd{1.0, 0.0};
+                buf[lds_pad(d_bitrev(j, d.log2M))] = ring_gather_slot(ph, npair_pad, pair, n, d.mmax_eff, r, flip, j);
+            }
+            CMDR_BLOCK_SYNC();
+        }
         fft_dit_plus(buf, d.log2M, tw, log2Mmax, c);
     } else {
-        const cd* w = chirp + d.chirp_off;   // w_j, j<n
+        const cd* w = rot + n;               // chirp w_j = e^{i pi j^2 / n}
         const cd* chat = w + n;              // bit-reversed FFT_M^- of the conj chirp
         // a_j = Z_j w_j ; we need F^-(a) = conj(F^+(conj a))
-        for (int j = c.tid; j < M; j += c.nthr) {
-            cd v = {0.0, 0.0};
-            if (j < n) v = cconj(cmul(ring_gather_slot(ph, npair_pad, pair, n, d.mmax_eff, q, j), w[j]));
-            buf[j] = v;
+        if (noalias) {
+            ring_scatter<true>(buf, d, ph, npair_pad, pair, rot, w, c);
+        } else {
+            for (int j = c.tid; j < M; j += c.nthr) {
+                cd v = {0.0, 0.0};
+                if (j < n) {
+                    const cd r = flip ? rot[j] : cd{1.0, 0.0};
+                    v = cconj(cmul(ring_gather_slot(ph, npair_pad, pair, n, d.mmax_eff, r, flip, j), w[j]));
+                }
+                buf[lds_pad(j)] = v;
+            }
+            CMDR_BLOCK_SYNC();
         }
-        CMDR_BLOCK_SYNC();
         fft_dif_plus(buf, d.log2M, tw, log2Mmax, c);
-        for (int p = c.tid; p < M; p += c.nthr) buf[p] = cmul(cconj(buf[p]), chat[p]);
+        for (int p = c.tid; p < M; p += c.nthr) buf[lds_pad(p)] = cmul(cconj(buf[lds_pad(p)]), chat[p]);
         CMDR_BLOCK_SYNC();
         fft_dit_plus(buf, d.log2M, tw, log2Mmax, c);
         const double inv = 1.0 / (double)M;
         for (int k = c.tid; k < n; k += c.nthr) {
-            const cd v = cmul(buf[k], w[k]);
-            buf[k] = {v.x * inv, v.y * inv};
+            const cd v = cmul(buf[lds_pad(k)], w[k]);
+            buf[lds_pad(k)] = {v.x * inv, v.y * inv};
         }
         CMDR_BLOCK_SYNC();
     }
 }
 
-// Forward (analysis) ring transform in LDS.  On entry buf[k], k<n holds z_k = y^N_k + i y^S_k (natural order).
+// Forward (analysis) ring transform in LDS.  On entry buf[lds_pad(k)], k<n holds z_k = y^N_k + i y^S_k.
 // On return the spectrum Z_j = sum_k z_k e^{-2 pi i jk/n} is available through ring_spec_at().
 CMDR_HD void ring_anal_lds(cd* buf, const RingDev& d, const cd* __restrict__ tw, int log2Mmax,
                            const cd* __restrict__ chirp, FftCtx c) {
     const int n = d.nphi, M = 1 << d.log2M;
     if (!d.bluestein) {
         // Z = conj(F^+(conj z)); DIF leaves it bit-reversed
-        for (int k = c.tid; k < n; k += c.nthr) buf[k] = cconj(buf[k]);
+        for (int k = c.tid; k < n; k += c.nthr) buf[lds_pad(k)] = cconj(buf[lds_pad(k)]);
         CMDR_BLOCK_SYNC();
         fft_dif_plus(buf, d.log2M, tw, log2Mmax, c);
     } else {
         // conj(Z)_j = sum_k conj(z_k) e^{+...} = w_j sum_k (conj(z_k) w_k) conj(w_{j-k})  (same chirp machinery)
-        const cd* w = chirp + d.chirp_off;
+        const cd* w = chirp + d.chirp_off + n;
         const cd* chat = w + n;
         for (int k = c.tid; k < M; k += c.nthr) {
             cd v = {0.0, 0.0};
-            if (k < n) v = cconj(cmul(cconj(buf[k]), w[k]));   // conj(a_k), a_k = conj(z_k) w_k
-            buf[k] = v;
+            if (k < n) v = cconj(cmul(cconj(buf[lds_pad(k)]), w[k]));   // conj(a_k), a_k = conj(z_k) w_k
+            buf[lds_pad(k)] = v;
         }
         CMDR_BLOCK_SYNC();
         fft_dif_plus(buf, d.log2M, tw, log2Mmax, c);
-        for (int p = c.tid; p < M; p += c.nthr) buf[p] = cmul(cconj(buf[p]), chat[p]);
+        for (int p = c.tid; p < M; p += c.nthr) buf[lds_pad(p)] = cmul(cconj(buf[lds_pad(p)]), chat[p]);
         CMDR_BLOCK_SYNC();
         fft_dit_plus(buf, d.log2M, tw, log2Mmax, c);
         const double inv = 1.0 / (double)M;
         for (int j = c.tid; j < n; j += c.nthr) {
-            const cd v = cmul(buf[j], w[j]);      // conj(Z_j) * M
-            buf[j] = {v.x * inv, -v.y * inv};     // Z_j, natural order
+            const cd v = cmul(buf[lds_pad(j)], w[j]);      // conj(Z_j) * M
+            buf[lds_pad(j)] = {v.x * inv, -v.y * inv};     // Z_j, natural order
         }
         CMDR_BLOCK_SYNC();
     }
 }
 
 CMDR_HD cd ring_spec_at(const cd* buf, const RingDev& d, int j) {
-    if (!d.bluestein) return cconj(buf[d_bitrev(j, d.log2M)]);
-    return buf[j];
+    if (!d.bluestein) return cconj(buf[lds_pad(d_bitrev(j, d.log2M))]);
+    return buf[lds_pad(j)];
 }
 
 // Extract G^N_m, G^S_m (m <= mmax_eff) from the packed spectrum and store them as phases for the adjoint
-// Legendre stage: X^N_j = (Z_j + conj Z_{n-j})/2, X^S_j = (Z_j - conj Z_{n-j})/(2i); G_m = X[m mod n] e^{-i m phi0}.
+// Legendre stage: X^N_j = (Z_j + conj Z_{n-j})/2, X^S_j = (Z_j - conj Z_{n-j})/(2i);
+// G_{j+kn} = X_j e^{-i m phi0} = X_j s^k conj(rot_j).
 CMDR_HD void ring_store_phases(const cd* buf, const RingDev& d, double* __restrict__ ph, int64_t npair_pad,
-                               int pair, FftCtx c) {
+                               int pair, const cd* __restrict__ chirp, FftCtx c) {
     const int n = d.nphi;
-    const int q = d.phi0 == 0.0 ? 0 : n / 4;
-    for (int m = c.tid; m <= d.mmax_eff; m += c.nthr) {
-        const int j = m % n;
+    const bool flip = d.phi0 != 0.0;
+    const cd* rot = chirp + d.chirp_off;
+    const int jmax = d.mmax_eff < n - 1 ? d.mmax_eff : n - 1;
+    for (int j = c.tid; j <= jmax; j += c.nthr) {
         const cd a = ring_spec_at(buf, d, j), b = cconj(ring_spec_at(buf, d, j == 0 ? 0 : n - j));
         const cd xn = {0.5 * (a.x + b.x), 0.5 * (a.y + b.y)};
         const cd dm = {0.5 * (a.x - b.x), 0.5 * (a.y - b.y)};
         const cd xs = {dm.y, -dm.x};  // dm / i
-        const cd e = cconj(phase_mphi0(m, q));
-        const cd gn = cmul(xn, e), gs = cmul(xs, e);
-        double* o = ph + ((int64_t)m * npair_pad + pair) * 4;
-        o[0] = gn.x;
-        o[1] = gn.y;
-        o[2] = gs.x;
-        o[3] = gs.y;
+        const cd e = flip ? cconj(rot[j]) : cd{1.0, 0.0};
+        cd gn = cmul(xn, e), gs = cmul(xs, e);
+        for (int m = j; m <= d.mmax_eff; m += n) {
+            double* o = ph + ((int64_t)m * npair_pad + pair) * 4;
+            o[0] = gn.x; o[1] = gn.y; o[2] = gs.x; o[3] = gs.y;
+            if (flip) { gn.x = -gn.x; gn.y = -gn.y; gs.x = -gs.x; gs.y = -gs.y; }
+        }
     }
 }
 

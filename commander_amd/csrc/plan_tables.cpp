@@ -208,22 +208,25 @@ void RingTables::build(int nside_, int lmax_, const std::vector<int>& rings, con
         d.mmax_eff = std::min(mlim[p], lmax);
         d.wgt = (wring ? wring[rings[p] - 1] : 1.0) * 4.0 * kPi / npix_full;
         const int n = r.nphi;
-        if ((n & (n - 1)) == 0) {
-            d.bluestein = 0;
-            int lg = 0;
-            while ((1 << lg) < n) ++lg;
-            d.log2M = lg;
-            d.chirp_off = -1;
-        } else {
-            d.bluestein = 1;
-            int lg = 0;
-            while ((1 << lg) < 2 * n - 1) ++lg;
-            d.log2M = lg;
-            auto it = chirp_of.find(n);
-            if (it == chirp_of.end()) {
+        const bool pow2 = (n & (n - 1)) == 0;
+        int lg = 0;
+        if (pow2) { while ((1 << lg) < n) ++lg; }
+        else      { while ((1 << lg) < 2 * n - 1) ++lg; }
+        d.bluestein = pow2 ? 0 : 1;
+        d.log2M = lg;
+        auto it = chirp_of.find(n);
+        if (it == chirp_of.end()) {
+            // per-length table: rot_j = e^{i pi j/n} (j<n); Bluestein lengths add the chirp w_j = e^{i pi j^2/n} (j<n)
+            // and the FFT_M^- of the conjugate chirp in bit-reversed order (M entries)
+            const int64_t o = (int64_t)chirp.size() / 2;
+            chirp_of[n] = o;
+            for (int j = 0; j < n; ++j) {
+                const double ang = kPi * (double)j / (double)n;
+                chirp.push_back(std::cos(ang));
+                chirp.push_back(std::sin(ang));
+            }
+            if (!pow2) {
                 const int M = 1 << lg;
-                const int64_t o = (int64_t)chirp.size() / 2;
-                chirp_of[n] = o;
                 std::vector<std::complex<double>> w(n), c(M, 0.0);
                 for (int j = 0; j < n; ++j) {
                     const int64_t q = ((int64_t)j * j) % (2 * (int64_t)n);
@@ -239,10 +242,10 @@ void RingTables::build(int nside_, int lmax_, const std::vector<int>& rings, con
                     chirp.push_back(v.real());
                     chirp.push_back(v.imag());
                 }
-                d.chirp_off = o;
-            } else {
-                d.chirp_off = it->second;
             }
+            d.chirp_off = o;
+        } else {
+            d.chirp_off = it->second;
         }
         log2Mmax = std::max(log2Mmax, d.log2M);
     }

@@ -71,7 +71,7 @@ ShtPlan::ShtPlan(int nside, int lmax, const std::vector<int>& rings, const doubl
         if (ncls_[c]) cls_[c].upload(T_.ring.classes[c]);
     }
     tw_.upload(T_.ring.twiddle);
-    if (!T_.ring.chirp.empty()) chirp_.upload(T_.ring.chirp);
+    chirp_.upload(T_.ring.chirp);
     ast_.alloc((size_t)max_maps * leg_.tri_elems());
     ph_.alloc((size_t)max_maps * leg_.ph_elems());
     part_.alloc((size_t)max_maps * part_map_stride());

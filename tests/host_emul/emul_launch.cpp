@@ -109,7 +109,7 @@ void launch_leg_adj(const LegArgs& A, const WaveTask* tasks, int ntasks, const d
 void launch_ring(int mode, const RingDev* rings, const int* cls, int ncls, int log2M, double* ph,
                  int64_t ph_stride, int64_t npair_pad, double* map, int64_t map_stride, const double* const* mul,
                  int weighted, const cd* tw, int log2Mmax, const cd* chirp, int nmaps, hipStream_t) {
-    std::vector<cd> bufv((size_t)1 << log2M);
+    std::vector<cd> bufv((size_t)lds_elems(log2M));
     cd* buf = bufv.data();
     const FftCtx c{0, 1};
     for (int imap = 0; imap < nmaps; ++imap)
@@ -124,23 +124,23 @@ void launch_ring(int mode, const RingDev* rings, const int* cls, int ncls, int l
             if (mode == 0 || mode == 2) ring_synth_lds(buf, d, php, npair_pad, pair, tw, log2Mmax, chirp, c);
             if (mode == 0) {
                 for (int k = 0; k < n; ++k) {
-                    mp[d.startN + k] = buf[k].x * wg * (mu ? mu[d.startN + k] : 1.0);
-                    if (d.startS >= 0) mp[d.startS + k] = buf[k].y * wg * (mu ? mu[d.startS + k] : 1.0);
+                    mp[d.startN + k] = buf[lds_pad(k)].x * wg * (mu ? mu[d.startN + k] : 1.0);
+                    if (d.startS >= 0) mp[d.startS + k] = buf[lds_pad(k)].y * wg * (mu ? mu[d.startS + k] : 1.0);
                 }
                 continue;
             }
             if (mode == 1)
                 for (int k = 0; k < n; ++k) {
-                    buf[k].x = mp[d.startN + k] * wg * (mu ? mu[d.startN + k] : 1.0);
-                    buf[k].y = d.startS >= 0 ? mp[d.startS + k] * wg * (mu ? mu[d.startS + k] : 1.0) : 0.0;
+                    buf[lds_pad(k)].x = mp[d.startN + k] * wg * (mu ? mu[d.startN + k] : 1.0);
+                    buf[lds_pad(k)].y = d.startS >= 0 ? mp[d.startS + k] * wg * (mu ? mu[d.startS + k] : 1.0) : 0.0;
                 }
             if (mode == 2)
                 for (int k = 0; k < n; ++k) {
-                    buf[k].x *= mu[d.startN + k];
-                    buf[k].y = d.startS >= 0 ? buf[k].y * mu[d.startS + k] : 0.0;
+                    buf[lds_pad(k)].x *= mu[d.startN + k];
+                    buf[lds_pad(k)].y = d.startS >= 0 ? buf[lds_pad(k)].y * mu[d.startS + k] : 0.0;
                 }
             ring_anal_lds(buf, d, tw, log2Mmax, chirp, c);
-            ring_store_phases(buf, d, php, npair_pad, pair, c);
+            ring_store_phases(buf, d, php, npair_pad, pair, chirp, c);
         }
 }
 
