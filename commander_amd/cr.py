@@ -246,3 +246,13 @@ def build_context(spec, device=0, rings_by_nside=None, _lib=None):
                      c.get("active", True))
     ctx.finalize()
     return ctx
+
+
+def getSigmaL(alm, lmax, _lib=None):
+    """``comm_map%getSigmaL`` (comm_map_mod.f90:1302-1351): alm (nalm[, nmaps]) -> sigma_l (lmax+1, nspec)."""
+    L = _lib if _lib is not None else _libmod.lib()
+    a = _f(np.asarray(alm, dtype=np.float64).reshape((lmax + 1) ** 2, -1))
+    nmaps = a.shape[1]
+    out = np.zeros((lmax + 1, nmaps * (nmaps + 1) // 2), order="F")
+    check(L.cmdr_sigma_l(_p(a), int(lmax), nmaps, _p(out)), L)
+    return out

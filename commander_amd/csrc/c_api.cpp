@@ -361,4 +361,26 @@ int cmdr_problem_info(cmdr_ctx* ctx, int64_t* out) {
     });
 }
 
+int cmdr_sigma_l(const double* alm, int lmax, int nmaps, double* sigma_l) {
+    return guarded([&] {
+        CMDR_REQUIRE(alm && sigma_l && lmax >= 0 && nmaps >= 1 && nmaps <= 3, "bad arguments");
+        CMDR_REQUIRE(cmdr_device_count() > 0, "no HIP device available: libcmdr_hip has no CPU path");
+        const int64_t na = cmdr::nalm_packed(lmax);
+        const int nspec = nmaps * (nmaps + 1) / 2;
+        cmdr::DevBuf<double> d((size_t)na * nmaps), o((size_t)(lmax + 1) * nspec);
+        CMDR_HIP_CHECK(hipMemcpy(d.get(), alm, sizeof(double) * na * nmaps, hipMemcpyHostToDevice));
+        cmdr::launch_sigma_l(d.get(), na, lmax, nmaps, o.get(), nullptr);
+        CMDR_HIP_CHECK(hipGetLastError());
+        CMDR_HIP_CHECK(hipMemcpy(sigma_l, o.get(), sizeof(double) * (lmax + 1) * nspec, hipMemcpyDeviceToHost));
+    });
+}
+int cmdr_sigma_l_dev(const double* alm_dev, int64_t stride, int lmax, int nmaps, double* sigma_l_dev) {
+    return guarded([&] {
+        CMDR_REQUIRE(alm_dev && sigma_l_dev && lmax >= 0 && nmaps >= 1 && nmaps <= 3, "bad arguments");
+        cmdr::launch_sigma_l(alm_dev, stride, lmax, nmaps, sigma_l_dev, nullptr);
+        CMDR_HIP_CHECK(hipGetLastError());
+        CMDR_HIP_CHECK(hipStreamSynchronize(nullptr));
+    });
+}
+
 }  // extern "C"

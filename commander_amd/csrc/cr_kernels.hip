@@ -202,4 +202,31 @@ void launch_axpby(const double* a, const double* b, double cb, double* out, int6
     hipLaunchKernelGGL(k_axpby, dim3(nb), dim3(256), 0, s, a, b, cb, out, n);
 }
 
+// ----------------------------------------------------------------------------- sigma_l (K13)
+// getSigmaL (commander3/src/comm_map_mod.f90:1302-1351): sigma_l(l, k) = sum_{m=-l..l} a_lm^i a_lm^j / (2l+1) for
+// the nspec = nmaps(nmaps+1)/2 pairs (i<=j) in Commander's order.  One workgroup per l; fixed-order block reduction.
+__global__ void __launch_bounds__(256) k_sigma_l(const double* __restrict__ alm, int64_t stride, int lmax, int nmaps,
+                                                 double* __restrict__ out) {
+    const int l = blockIdx.x;
+    double acc[6] = {0, 0, 0, 0, 0, 0};
+    for (int m = threadIdx.x; m <= l; m += 256) {
+        const int64_t i0 = d_packed_index(lmax, l, m);
+        for (int sl = 0; sl < (m == 0 ? 1 : 2); ++sl) {
+            double v[3];
+            for (int a = 0; a < nmaps; ++a) v[a] = alm[a * stride + i0 + sl];
+            int k = 0;
+            for (int a = 0; a < nmaps; ++a)
+                for (int b = a; b < nmaps; ++b) acc[k++] += v[a] * v[b];
+        }
+    }
+    const int nspec = nmaps * (nmaps + 1) / 2;
+    for (int k = 0; k < nspec; ++k) {
+        const double r = block_sum_256(acc[k]);
+        if (threadIdx.x == 0) out[l + (int64_t)(lmax + 1) * k] = r / (double)(2 * l + 1);
+    }
+}
+void launch_sigma_l(const double* alm, int64_t stride, int lmax, int nmaps, double* out, hipStream_t s) {
+    hipLaunchKernelGGL(k_sigma_l, dim3(lmax + 1), dim3(256), 0, s, alm, stride, lmax, nmaps, out);
+}
+
 }  // namespace cmdr

@@ -65,6 +65,8 @@ def _sig(L):
     L.cmdr_compute_rhs.argtypes = [c_vp, c_int, pdp, pdp, dp, dp, dp]
     L.cmdr_compute_rhs_dev.argtypes = [c_vp, c_int, pvp, pvp, c_vp, c_vp, c_vp]
     pint = ctypes.POINTER(c_int)
+    L.cmdr_sigma_l.argtypes = [dp, c_int, c_int, dp]
+    L.cmdr_sigma_l_dev.argtypes = [c_vp, c_i64, c_int, c_int, c_vp]
     L.cmdr_profile_enable.argtypes = [c_vp, c_int]
     L.cmdr_profile_read.argtypes = [c_vp, dp, ctypes.POINTER(ctypes.c_longlong)]
     L.cmdr_problem_info.argtypes = [c_vp, ctypes.POINTER(c_i64)]

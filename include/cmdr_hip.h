@@ -130,6 +130,12 @@ int cmdr_solve(cmdr_ctx* ctx, const double* b, double* x, int crit, double tol, 
 int cmdr_solve_dev(cmdr_ctx* ctx, const double* b_dev, double* x_dev, int crit, double tol, int miniter,
                    int maxiter, int check_freq, const double* x0_dev, int* niter, double* res, int* stat);
 
+/* getSigmaL (commander3/src/comm_map_mod.f90:1302-1351): sigma_l(0:lmax, nspec), nspec = nmaps(nmaps+1)/2 in
+ * Commander's (1,1),(1,2)..(nmaps,nmaps) order, from a packed a_lm(0:nalm-1, nmaps) -- the power-spectrum statistic the
+ * C_l Gibbs step (sample_powspec, commander.f90:229) consumes right after the amplitude solve. */
+int cmdr_sigma_l(const double* alm, int lmax, int nmaps, double* sigma_l);
+int cmdr_sigma_l_dev(const double* alm_dev, int64_t stride, int lmax, int nmaps, double* sigma_l_dev);
+
 /* HIP-event timing of the dominant kernels, on the stream they are launched on.  kinds: 0 Legendre synthesis
  * launches, 1 fused ring-stage launches, 2 Legendre adjoint launches, 3 whole cr_matmulA.  ms_sum[4], count[4]. */
 int cmdr_profile_enable(cmdr_ctx* ctx, int on);

@@ -516,3 +516,17 @@ def cg_solve_2x2_kat():
         d = s + (delta_new / delta_old) * d
         it += 1
     return x, it
+
+
+def getSigmaL(alm, lmax):
+    """comm_map_mod.f90:1302-1351: sigma_l(l, k) = sum_m a_lm^i a_lm^j / (2l+1), pairs (i<=j) in Commander's order."""
+    info = healpix.AlmInfo(lmax)
+    alm = np.asarray(alm, dtype=np.float64).reshape(info.nalm, -1)
+    nmaps = alm.shape[1]
+    out = np.zeros((lmax + 1, nmaps * (nmaps + 1) // 2))
+    k = 0
+    for i in range(nmaps):
+        for j in range(i, nmaps):
+            np.add.at(out[:, k], info.l, alm[:, i] * alm[:, j])
+            k += 1
+    return out / (2.0 * np.arange(lmax + 1)[:, None] + 1.0)

@@ -231,4 +231,20 @@ void launch_axpby(const double* a, const double* b, double cb, double* out, int6
     for (int64_t i = 0; i < n; ++i) out[i] = a[i] + cb * b[i];
 }
 
+void launch_sigma_l(const double* alm, int64_t stride, int lmax, int nmaps, double* out, hipStream_t) {
+    const int nspec = nmaps * (nmaps + 1) / 2;
+    for (int l = 0; l <= lmax; ++l) {
+        double acc[6] = {0, 0, 0, 0, 0, 0};
+        for (int m = 0; m <= l; ++m) {
+            const int64_t i0 = d_packed_index(lmax, l, m);
+            for (int sl = 0; sl < (m == 0 ? 1 : 2); ++sl) {
+                int k = 0;
+                for (int a = 0; a < nmaps; ++a)
+                    for (int b = a; b < nmaps; ++b) acc[k++] += alm[a * stride + i0 + sl] * alm[b * stride + i0 + sl];
+            }
+        }
+        for (int k = 0; k < nspec; ++k) out[l + (int64_t)(lmax + 1) * k] = acc[k] / (double)(2 * l + 1);
+    }
+}
+
 }  // namespace cmdr

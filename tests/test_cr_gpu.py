@@ -122,3 +122,12 @@ def test_cfg3_full_size_properties():
     x, n, stat, (dn, d0) = ctx.solve_cr_eqn_by_CG(b, "fixed_iter", 1e-8, 5, 40, 1)
     assert n == 40 and np.isfinite(x).all()
     assert dn < 1e-3 * d0  # masked sky + diagonal preconditioner: ~4 orders in 40 iterations
+
+
+def test_sigma_l_gpu():
+    from commander_amd.cr import getSigmaL
+    from oracle import cr_oracle
+    rng = np.random.default_rng(9)
+    for lmax, nmaps in [(300, 1), (257, 3)]:
+        a = rng.standard_normal(((lmax + 1) ** 2, nmaps))
+        assert rel(getSigmaL(a, lmax), cr_oracle.getSigmaL(a, lmax)) < 1e-12

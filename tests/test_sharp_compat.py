@@ -1,0 +1,66 @@
+"""The literal libsharp2 symbols of include/cmdr_sharp.h (what commander3/src/sharp.f90 binds), driven the way
+``sharp_execute_d`` drives them (sharp.f90:186-241): info objects, array-of-column-pointers, job codes."""
+import ctypes
+
+import numpy as np
+import pytest
+
+from helpers import emul_lib, rel
+
+SHARP_DP = 1 << 4
+dp = ctypes.POINTER(ctypes.c_double)
+
+
+def run_sharp(L, oracle_lib, nside, lmax, P=1, rank=0):
+    vp = ctypes.c_void_p
+    L.sharp_alm_count.restype = ctypes.c_ssize_t
+    L.sharp_alm_count.argtypes = [vp]
+    L.sharp_map_size.restype = ctypes.c_ssize_t
+    L.sharp_map_size.argtypes = [vp]
+    L.sharp_make_mmajor_real_packed_alm_info.argtypes = [ctypes.c_int] * 3 + [ctypes.POINTER(ctypes.c_int), ctypes.POINTER(vp)]
+    L.sharp_make_subset_healpix_geom_info.argtypes = [ctypes.c_int] * 3 + [ctypes.POINTER(ctypes.c_int), dp, ctypes.POINTER(vp)]
+    L.sharp_execute_mpi_fortran.argtypes = [ctypes.c_int] * 3 + [vp, vp, vp, vp, ctypes.c_int, dp, ctypes.POINTER(ctypes.c_ulonglong)]
+    L.sharp_destroy_alm_info.argtypes = [vp]
+    L.sharp_destroy_geom_info.argtypes = [vp]
+    from oracle import healpix
+    rng = np.random.default_rng(nside + lmax)
+    ms = np.arange(lmax + 1, dtype=np.int32)
+    ainfo, ginfo = vp(), vp()
+    L.sharp_make_mmajor_real_packed_alm_info(lmax, 1, lmax + 1, ms.ctypes.data_as(ctypes.POINTER(ctypes.c_int)), ctypes.byref(ainfo))
+    assert L.sharp_alm_count(ainfo) == (lmax + 1) ** 2
+    north = np.arange(1 + rank, 2 * nside + 1, P)
+    rings = np.array(sorted(list(north) + [4 * nside - i for i in north if i < 2 * nside]), dtype=np.int32)
+    w = 1.0 + 0.05 * rng.standard_normal(2 * nside)
+    L.sharp_make_subset_healpix_geom_info(nside, 1, rings.size, rings.ctypes.data_as(ctypes.POINTER(ctypes.c_int)),
+                                          w.ctypes.data_as(dp), ctypes.byref(ginfo))
+    idx = np.concatenate([np.arange(healpix.ring_info(nside, i)[4], healpix.ring_info(nside, i)[4] + healpix.ring_info(nside, i)[0]) for i in rings])
+    assert L.sharp_map_size(ginfo) == idx.size
+    a = rng.standard_normal((lmax + 1) ** 2)
+    m = np.zeros(idx.size)
+    pa = (dp * 1)(a.ctypes.data_as(dp))
+    pm = (dp * 1)(m.ctypes.data_as(dp))
+    t = ctypes.c_double(0)
+    L.sharp_execute_mpi_fortran(0, 1, 0, pa, pm, ginfo, ainfo, SHARP_DP, ctypes.byref(t), None)     # SHARP_Y
+    assert rel(m, oracle_lib.Y(nside, lmax, a)[idx]) < 1e-11
+    if P == 1:
+        m2 = rng.standard_normal(idx.size)
+        out = np.zeros_like(a)
+        pa = (dp * 1)(out.ctypes.data_as(dp))
+        pm = (dp * 1)(m2.ctypes.data_as(dp))
+        L.sharp_execute_mpi_fortran(0, 0, 0, pa, pm, ginfo, ainfo, SHARP_DP, None, None)            # SHARP_YtW
+        assert rel(out, oracle_lib.YtW(nside, lmax, m2, wring=w)) < 1e-11
+    L.sharp_destroy_alm_info(ainfo)
+    L.sharp_destroy_geom_info(ginfo)
+
+
+def test_sharp_symbols_host_logic(oracle_lib):
+    EL = emul_lib()
+    run_sharp(EL, oracle_lib, 8, 16)
+    run_sharp(EL, oracle_lib, 8, 16, P=2, rank=1)
+
+
+@pytest.mark.gpu
+def test_sharp_symbols_gpu(oracle_lib):
+    from commander_amd import get_lib
+    run_sharp(get_lib(), oracle_lib, 64, 128)
+    run_sharp(get_lib(), oracle_lib, 32, 64, P=3, rank=2)
