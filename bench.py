@@ -157,6 +157,13 @@ def main():
         npix_loc = sum(s[0] for s in ctx.band_shape)
         b_iter = 8.0 * (2 * (lmax + 1) ** 2 * len(spec["bands"]) + 3 * npix_loc) + 80.0 * ctx.ncr
         t_mv = ms[3] / max(int(cnt[3]), 1) * 1e-3
+        traffic = None   # HBM bytes per Legendre launch from separate rocprofv3 --pmc passes (profiles/), if present
+        try:
+            tj = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")))
+            if world == 1 and cfg == "cfg3":
+                traffic = tj["legendre_span_bytes"]["mean"]
+        except Exception:
+            pass
         out = {
             "metric": "cg_solves_per_sec", "value": args.steps / dt, "unit": "solves/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
@@ -167,7 +174,7 @@ def main():
                        "parallelism": "ring-pair sharding x%d, replicated a_lm, 1 all-reduce(ncr) per matvec" % world
                        if world > 1 else "single GPU", "ncr": ctx.ncr, "cg_iters_per_sec": args.steps * NITER / dt},
             "roofline": {"bound": "mfma", "achieved": achieved, "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s",
-                         "frac": achieved / FP64_PEAK_TFLOPS, "traffic": None,
+                         "frac": achieved / FP64_PEAK_TFLOPS, "traffic": traffic,
                          "kernel": "k_leg_synth + k_leg_adj (fp64 Legendre stage; VALU-bound, MI355X fp64 matrix "
                                    "peak equals the vector peak)",
                          "avg_launch_ms": t_leg * 1e3, "launches": nl, "flop_per_launch": flop_launch,
