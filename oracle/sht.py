@@ -36,6 +36,9 @@ def lib():
         L.orc_sht.restype = ctypes.c_int
         L.orc_invn_diag.argtypes = [ctypes.c_int, ctypes.c_int, dp, dp, ctypes.c_int]
         L.orc_invn_diag.restype = ctypes.c_int
+        L.orc_sht_spin2.argtypes = [ctypes.c_int, ctypes.c_int, ctypes.c_int, dp, dp, dp, dp, dp, ctypes.c_int,
+                                    ctypes.c_int, ctypes.c_int]
+        L.orc_sht_spin2.restype = ctypes.c_int
         L.orc_lm2i.argtypes = [ctypes.c_int, ctypes.c_int, ctypes.c_int]
         L.orc_lm2i.restype = ctypes.c_int64
         _LIB = L
@@ -101,3 +104,26 @@ def invn_diag(nside, lmax, al0, nthreads=0):
     out = np.zeros(nalm(lmax))
     L.orc_invn_diag(nside, lmax, _p(al0), _p(out), int(nthreads))
     return out
+
+
+def sht_spin2(job, nside, lmax, almE=None, almB=None, mapQ=None, mapU=None, wring=None, fft_mode=1, use_mlim=True,
+              nthreads=0):
+    """One spin-2 transform (Q,U) <-> (E,B), Commander's polarisation call (comm_map_mod.f90:446-449).
+    Returns (mapQ, mapU) for Y/WY, (almE, almB) for Yt/YtW."""
+    L = lib()
+    wp = None
+    if wring is not None:
+        wring = np.ascontiguousarray(wring, dtype=np.float64)
+        wp = _p(wring)
+    if job in (JOB_Y, JOB_WY):
+        e = np.ascontiguousarray(almE, dtype=np.float64)
+        b = np.ascontiguousarray(almB, dtype=np.float64)
+        q, u = np.zeros(npix(nside)), np.zeros(npix(nside))
+    else:
+        q = np.ascontiguousarray(mapQ, dtype=np.float64)
+        u = np.ascontiguousarray(mapU, dtype=np.float64)
+        e, b = np.zeros(nalm(lmax)), np.zeros(nalm(lmax))
+    rc = L.orc_sht_spin2(job, nside, lmax, wp, _p(e), _p(b), _p(q), _p(u), int(fft_mode), int(use_mlim), int(nthreads))
+    if rc != 0:
+        raise RuntimeError("orc_sht_spin2 failed")
+    return (q, u) if job in (JOB_Y, JOB_WY) else (e, b)

@@ -190,42 +190,17 @@ static int mlim_of(int lmax, int spin, double sth, double cth) {
 #define RESCALE_BIG 0x1p+300
 #define RESCALE_INV 0x1p-300
 
-/*
- * Scalar (spin-0) SHT on the full HEALPix sphere, one map.
- *   job      : JOB_Y / JOB_WY (alm -> map), JOB_Yt / JOB_YtW (map -> alm)
- *   wring    : [2*nside] ring weights W (comm_map_mod.f90:266-283 passes 1+weight_ring); NULL = 1
- *   alm      : real-packed m-major, (lmax+1)^2 doubles
- *   map      : RING-ordered, 12*nside^2 doubles
- *   fft_mode : 0 direct DFT per ring (independent check), 1 FFT
- *   use_mlim : 1 = skip (ring,m) pairs beyond libsharp's mlim
- * Returns 0.
- */
-int orc_sht(int job, int nside, int lmax, const double* wring, double* alm, double* map, int fft_mode,
-            int use_mlim, int nthreads) {
-    const int nring = 4 * nside - 1, npair = 2 * nside, mmax = lmax, nm = mmax + 1;
+/* ring stage shared by the spin-0 and spin-2 transforms: direction 0 = pixels -> phases, 1 = phases -> pixels */
+static void ring_stage(int synth, int nside, int lmax, const double* wring, int weighted, double* map, cplx* ph,
+                       int fft_mode, const ringinfo* ri) {
+    const int nring = 4 * nside - 1, mmax = lmax, nm = mmax + 1;
     const int64_t npix = 12 * (int64_t)nside * nside;
-    const int synth = (job == JOB_Y || job == JOB_WY);
-    const int weighted = (job == JOB_YtW || job == JOB_WY);
-    const double sqrt2 = sqrt(2.0);
-#ifdef _OPENMP
-    if (nthreads > 0) omp_set_num_threads(nthreads);
-#endif
-    (void)nthreads;
-    cplx* ph = (cplx*)calloc((size_t)nring * nm, sizeof(cplx)); /* ph[(ring-1)*nm + m] */
-    if (!ph) return -1;
-    ringinfo* ri = (ringinfo*)malloc(sizeof(ringinfo) * (nring + 1));
-    for (int r = 1; r <= nring; ++r) ri[r] = ring_info(nside, r);
-    /* log lambda_mm prefactors: lambda_mm = (-1)^m sqrt((2m+1)!!/(4 pi (2m)!!)) sin^m */
-    double* logpref = (double*)malloc(sizeof(double) * nm);
-    logpref[0] = -0.5 * log(4.0 * PI);
-    for (int m = 1; m <= mmax; ++m) logpref[m] = logpref[m - 1] + 0.5 * log((2.0 * m + 1.0) / (2.0 * m));
-
-    /* ---------------- analysis: pixels -> phases (per ring) */
     fftplan* plans = NULL;
     if (fft_mode) {
         plans = (fftplan*)malloc(sizeof(fftplan) * (nside + 1));
         for (int i = 1; i <= nside; ++i) plan_init(&plans[i], 4 * i);
     }
+    /* ---------------- analysis: pixels -> phases (per ring) */
     if (!synth) {
 #pragma omp parallel
         {
@@ -268,6 +243,86 @@ int orc_sht(int job, int nside, int lmax, const double* wring, double* alm, doub
             free(x); free(y); free(work); free(ct); free(st);
         }
     }
+
+    /* ---------------- synthesis: phases -> pixels (per ring) */
+    if (synth) {
+#pragma omp parallel
+        {
+            cplx* x = (cplx*)malloc(sizeof(cplx) * 4 * nside);
+            cplx* y = (cplx*)malloc(sizeof(cplx) * 4 * nside);
+            cplx* work = (cplx*)malloc(sizeof(cplx) * 16 * nside);
+            double* ct = (double*)malloc(sizeof(double) * 4 * nside);
+            double* st = (double*)malloc(sizeof(double) * 4 * nside);
+#pragma omp for schedule(dynamic, 4)
+            for (int r = 1; r <= nring; ++r) {
+                const ringinfo R = ri[r];
+                const int n = R.nphi;
+                const int northring = r > 2 * nside ? 4 * nside - r : r;
+                double wgt = 1.0;
+                if (weighted) wgt = (wring ? wring[northring - 1] : 1.0) * 4.0 * PI / (double)npix;
+                double* pm = map + R.start;
+                const cplx* in = ph + (size_t)(r - 1) * nm;
+                if (fft_mode) {
+                    for (int k = 0; k < n; ++k) x[k] = 0;
+                    for (int m = 0; m <= mmax; ++m) {
+                        double ang = (double)m * R.phi0;
+                        x[m % n] += in[m] * (cos(ang) + I * sin(ang));
+                    }
+                    fft_any(&plans[n / 4], x, y, work, +1);
+                    for (int k = 0; k < n; ++k) pm[k] = creal(y[k]) * wgt;
+                } else {
+                    for (int j = 0; j < n; ++j) { ct[j] = cos(TWOPI * j / n); st[j] = sin(TWOPI * j / n); }
+                    for (int k = 0; k < n; ++k) pm[k] = 0;
+                    for (int m = 0; m <= mmax; ++m) {
+                        double ang = (double)m * R.phi0;
+                        cplx g = in[m] * (cos(ang) + I * sin(ang));
+                        double gr = creal(g), gi = cimag(g);
+                        int64_t idx = 0, step = m % n;
+                        for (int k = 0; k < n; ++k) {
+                            pm[k] += gr * ct[idx] - gi * st[idx];
+                            idx += step; if (idx >= n) idx -= n;
+                        }
+                    }
+                    if (wgt != 1.0) for (int k = 0; k < n; ++k) pm[k] *= wgt;
+                }
+            }
+            free(x); free(y); free(work); free(ct); free(st);
+        }
+    }
+    if (plans) { for (int i = 1; i <= nside; ++i) plan_free(&plans[i]); free(plans); }
+}
+
+/*
+ * Scalar (spin-0) SHT on the full HEALPix sphere, one map.
+ *   job      : JOB_Y / JOB_WY (alm -> map), JOB_Yt / JOB_YtW (map -> alm)
+ *   wring    : [2*nside] ring weights W (comm_map_mod.f90:266-283 passes 1+weight_ring); NULL = 1
+ *   alm      : real-packed m-major, (lmax+1)^2 doubles
+ *   map      : RING-ordered, 12*nside^2 doubles
+ *   fft_mode : 0 direct DFT per ring (independent check), 1 FFT
+ *   use_mlim : 1 = skip (ring,m) pairs beyond libsharp's mlim
+ * Returns 0.
+ */
+int orc_sht(int job, int nside, int lmax, const double* wring, double* alm, double* map, int fft_mode,
+            int use_mlim, int nthreads) {
+    const int nring = 4 * nside - 1, npair = 2 * nside, mmax = lmax, nm = mmax + 1;
+    const int64_t npix = 12 * (int64_t)nside * nside;
+    const int synth = (job == JOB_Y || job == JOB_WY);
+    const int weighted = (job == JOB_YtW || job == JOB_WY);
+    const double sqrt2 = sqrt(2.0);
+#ifdef _OPENMP
+    if (nthreads > 0) omp_set_num_threads(nthreads);
+#endif
+    (void)nthreads;
+    cplx* ph = (cplx*)calloc((size_t)nring * nm, sizeof(cplx)); /* ph[(ring-1)*nm + m] */
+    if (!ph) return -1;
+    ringinfo* ri = (ringinfo*)malloc(sizeof(ringinfo) * (nring + 1));
+    for (int r = 1; r <= nring; ++r) ri[r] = ring_info(nside, r);
+    /* log lambda_mm prefactors: lambda_mm = (-1)^m sqrt((2m+1)!!/(4 pi (2m)!!)) sin^m */
+    double* logpref = (double*)malloc(sizeof(double) * nm);
+    logpref[0] = -0.5 * log(4.0 * PI);
+    for (int m = 1; m <= mmax; ++m) logpref[m] = logpref[m - 1] + 0.5 * log((2.0 * m + 1.0) / (2.0 * m));
+
+    if (!synth) ring_stage(0, nside, lmax, wring, weighted, map, ph, fft_mode, ri);
 
     /* ---------------- Legendre stage, parallel over m */
 #pragma omp parallel
@@ -339,52 +394,7 @@ int orc_sht(int job, int nside, int lmax, const double* wring, double* alm, doub
         free(ieps); free(epsv); free(a);
     }
 
-    /* ---------------- synthesis: phases -> pixels (per ring) */
-    if (synth) {
-#pragma omp parallel
-        {
-            cplx* x = (cplx*)malloc(sizeof(cplx) * 4 * nside);
-            cplx* y = (cplx*)malloc(sizeof(cplx) * 4 * nside);
-            cplx* work = (cplx*)malloc(sizeof(cplx) * 16 * nside);
-            double* ct = (double*)malloc(sizeof(double) * 4 * nside);
-            double* st = (double*)malloc(sizeof(double) * 4 * nside);
-#pragma omp for schedule(dynamic, 4)
-            for (int r = 1; r <= nring; ++r) {
-                const ringinfo R = ri[r];
-                const int n = R.nphi;
-                const int northring = r > 2 * nside ? 4 * nside - r : r;
-                double wgt = 1.0;
-                if (weighted) wgt = (wring ? wring[northring - 1] : 1.0) * 4.0 * PI / (double)npix;
-                double* pm = map + R.start;
-                const cplx* in = ph + (size_t)(r - 1) * nm;
-                if (fft_mode) {
-                    for (int k = 0; k < n; ++k) x[k] = 0;
-                    for (int m = 0; m <= mmax; ++m) {
-                        double ang = (double)m * R.phi0;
-                        x[m % n] += in[m] * (cos(ang) + I * sin(ang));
-                    }
-                    fft_any(&plans[n / 4], x, y, work, +1);
-                    for (int k = 0; k < n; ++k) pm[k] = creal(y[k]) * wgt;
-                } else {
-                    for (int j = 0; j < n; ++j) { ct[j] = cos(TWOPI * j / n); st[j] = sin(TWOPI * j / n); }
-                    for (int k = 0; k < n; ++k) pm[k] = 0;
-                    for (int m = 0; m <= mmax; ++m) {
-                        double ang = (double)m * R.phi0;
-                        cplx g = in[m] * (cos(ang) + I * sin(ang));
-                        double gr = creal(g), gi = cimag(g);
-                        int64_t idx = 0, step = m % n;
-                        for (int k = 0; k < n; ++k) {
-                            pm[k] += gr * ct[idx] - gi * st[idx];
-                            idx += step; if (idx >= n) idx -= n;
-                        }
-                    }
-                    if (wgt != 1.0) for (int k = 0; k < n; ++k) pm[k] *= wgt;
-                }
-            }
-            free(x); free(y); free(work); free(ct); free(st);
-        }
-    }
-    if (plans) { for (int i = 1; i <= nside; ++i) plan_free(&plans[i]); free(plans); }
+    if (synth) ring_stage(1, nside, lmax, wring, weighted, map, ph, fft_mode, ri);
     free(logpref); free(ri); free(ph);
     return 0;
 }
@@ -473,5 +483,181 @@ int orc_invn_diag(int nside, int lmax, const double* al0, double* out, int nthre
         free(acc); free(epsv);
     }
     free(logpref); free(gx); free(gw); free(g);
+    return 0;
+}
+
+/* ======================================================================================= spin-2 (Q,U <-> E,B)
+ * What Commander issues for the polarisation columns: one spin-2 call on alm(:,2:3) / map(:,2:3)
+ * (commander3/src/comm_map_mod.f90:446-449, :519-523, :549-553) -- "COSMO" convention (POLCCONV, :1002):
+ *     (Q +- iU)(p) = sum_lm a_{+-2,lm} +-2Y_lm(p),    a_{+-2,lm} = -(E_lm +- i B_lm)            
+ * With W = (2lam + -2lam)/2, X = (2lam - -2lam)/2 this is the HEALPix form
+ *     F^Q_m = -sum_l (E W + i B X),   F^U_m = -sum_l (B W - i E X),   map = Re F_0 + 2 Re sum_{m>0} F_m e^{i m phi}.
+ * The spin-weighted lambdas follow the three-term recursion (pinned numerically against the Goldberg closed form,
+ * oracle/bruteforce.py::spin_Y):
+ *     s_lam_{l+1} = [ (x + s m / (l(l+1))) s_lam_l - C_l s_lam_{l-1} ] / C_{l+1},
+ *     C_l = sqrt((l^2-m^2)(l^2-s^2) / (l^2 (4l^2-1))),   start l0 = max(m, 2),   s_lam(pi-theta) = (-1)^{l+m} (-s)_lam(theta).
+ */
+static double slam_start(int s, int m, double cth2, double sth2, double* log2mag) {
+    /* s_lam_{l0,m}(theta), l0 = max(m,2), via the Goldberg sum (l0 <= m+2 terms only matter for m < 2);
+       returns the sign, *log2mag = log2|value| (cth2 = cos(theta/2), sth2 = sin(theta/2)) */
+    const int l = m > 2 ? m : 2;
+    if (m >= 2) {
+        /* (-1)^m sqrt((2m+1)/4pi (2m)!/((m+s)!(m-s)!)) cos^{m-s} sin^{m+s} */
+        double lg = 0.5 * (log(2.0 * m + 1.0) - log(4.0 * PI) + lgamma(2.0 * m + 1.0) - lgamma(m + s + 1.0) - lgamma(m - s + 1.0));
+        lg += (m - s) * log(cth2) + (m + s) * log(sth2);
+        *log2mag = lg / M_LN2;
+        return (m & 1) ? -1.0 : 1.0;
+    }
+    /* m = 0, 1: explicit Goldberg sum at l = 2 */
+    double fact[8] = {1, 1, 2, 6, 24, 120, 720, 5040};
+    double pref = ((m & 1) ? -1.0 : 1.0) * sqrt((2 * l + 1) / (4 * PI) * fact[l + m] * fact[l - m] / (fact[l + s] * fact[l - s]));
+    double acc = 0;
+    for (int r = 0; r <= l - s; ++r) {
+        int k = r + s - m;
+        if (k < 0 || k > l + s) continue;
+        double c1 = fact[l - s] / (fact[r] * fact[l - s - r]), c2 = fact[l + s] / (fact[k] * fact[l + s - k]);
+        acc += c1 * c2 * (((l - r - s) & 1) ? -1.0 : 1.0) * pow(sth2, 2 * l - 2 * r - s + m) * pow(cth2, 2 * r + s - m);
+    }
+    double v = pref * acc;
+    if (v == 0.0) { *log2mag = -1e30; return 1.0; }
+    *log2mag = log2(fabs(v));
+    return v < 0 ? -1.0 : 1.0;
+}
+
+typedef struct { double lc, lp, sf; long e; } chain;
+
+static void chain_init(chain* c, double sign, double l2) {
+    if (l2 < -1e20) { c->lc = 0; c->lp = 0; c->e = 0; c->sf = 1.0; return; }
+    double fl = floor(l2);
+    c->e = (long)fl;
+    c->lc = sign * exp2(l2 - fl);
+    c->lp = 0.0;
+    c->sf = (c->e < -900) ? 0.0 : ldexp(1.0, (int)c->e);
+}
+static inline void chain_step(chain* c, double coef, double cl, double icl1) {
+    double ln = (coef * c->lc - cl * c->lp) * icl1;
+    c->lp = c->lc; c->lc = ln;
+    if (fabs(c->lc) > RESCALE_BIG) {
+        c->lc *= RESCALE_INV; c->lp *= RESCALE_INV; c->e += 300;
+        c->sf = (c->e < -900) ? 0.0 : ldexp(1.0, (int)c->e);
+    }
+}
+
+int orc_sht_spin2(int job, int nside, int lmax, const double* wring, double* almE, double* almB, double* mapQ,
+                  double* mapU, int fft_mode, int use_mlim, int nthreads) {
+    const int nring = 4 * nside - 1, npair = 2 * nside, mmax = lmax, nm = mmax + 1;
+    const int synth = (job == JOB_Y || job == JOB_WY);
+    const int weighted = (job == JOB_YtW || job == JOB_WY);
+    const double sqrt2 = sqrt(2.0);
+#ifdef _OPENMP
+    if (nthreads > 0) omp_set_num_threads(nthreads);
+#endif
+    (void)nthreads;
+    cplx* phQ = (cplx*)calloc((size_t)nring * nm, sizeof(cplx));
+    cplx* phU = (cplx*)calloc((size_t)nring * nm, sizeof(cplx));
+    if (!phQ || !phU) return -1;
+    ringinfo* ri = (ringinfo*)malloc(sizeof(ringinfo) * (nring + 1));
+    for (int r = 1; r <= nring; ++r) ri[r] = ring_info(nside, r);
+    if (!synth) {
+        ring_stage(0, nside, lmax, wring, weighted, mapQ, phQ, fft_mode, ri);
+        ring_stage(0, nside, lmax, wring, weighted, mapU, phU, fft_mode, ri);
+    }
+#pragma omp parallel
+    {
+        double* Cl = (double*)malloc(sizeof(double) * (lmax + 3));
+        cplx* aE = (cplx*)malloc(sizeof(cplx) * (lmax + 1));
+        cplx* aB = (cplx*)malloc(sizeof(cplx) * (lmax + 1));
+#pragma omp for schedule(dynamic, 1)
+        for (int mi = 0; mi <= mmax; ++mi) {
+            const int m = (mi & 1) ? mmax - mi / 2 : mi / 2;
+            const int l0 = m > 2 ? m : 2;
+            if (l0 > lmax) continue;
+            for (int l = l0; l <= lmax + 1; ++l) {
+                double dl = l, dm = m;
+                Cl[l] = sqrt((dl * dl - dm * dm) * (dl * dl - 4.0) / (dl * dl * (4.0 * dl * dl - 1.0)));
+            }
+            const int64_t base = mind(lmax, m);
+            const double mfac = m > 0 ? sqrt2 : 1.0;
+            for (int l = 0; l <= lmax; ++l) { aE[l] = 0; aB[l] = 0; }
+            if (synth)
+                for (int l = l0; l <= lmax; ++l) {
+                    if (m == 0) { aE[l] = almE[base + l]; aB[l] = almB[base + l]; }
+                    else {
+                        aE[l] = (almE[base + 2 * (l - m)] + I * almE[base + 2 * (l - m) + 1]) * mfac;
+                        aB[l] = (almB[base + 2 * (l - m)] + I * almB[base + 2 * (l - m) + 1]) * mfac;
+                    }
+                }
+            for (int rp = 1; rp <= npair; ++rp) {
+                const ringinfo R = ri[rp];
+                const double x = R.z, sth = R.sth;
+                if (use_mlim && m > mlim_of(lmax, 2, sth, x)) continue;
+                const int has_south = rp < npair;
+                const double th = atan2(sth, x), c2 = cos(0.5 * th), s2 = sin(0.5 * th);
+                chain cp, cm;  /* +2 and -2 chains */
+                double lg, sg;
+                sg = slam_start(2, m, c2, s2, &lg);  chain_init(&cp, sg, lg);
+                sg = slam_start(-2, m, c2, s2, &lg); chain_init(&cm, sg, lg);
+                cplx GQn = 0, GQs = 0, GUn = 0, GUs = 0;
+                if (!synth) {
+                    GQn = phQ[(size_t)(rp - 1) * nm + m]; GUn = phU[(size_t)(rp - 1) * nm + m];
+                    if (has_south) { GQs = phQ[(size_t)(4 * nside - rp - 1) * nm + m]; GUs = phU[(size_t)(4 * nside - rp - 1) * nm + m]; }
+                }
+                /* accumulators: "same-sign" (keeps sign in the south) and "flip" parts */
+                cplx Qk = 0, Qf = 0, Uk = 0, Uf = 0;
+                for (int l = l0;; ++l) {
+                    const double lp2 = cp.lc * cp.sf, lm2 = cm.lc * cm.sf;
+                    if (lp2 != 0.0 || lm2 != 0.0) {
+                        const double W = 0.5 * (lp2 + lm2), X = 0.5 * (lp2 - lm2);
+                        const int odd = (l + m) & 1;  /* W has parity (-1)^{l+m}, X the opposite */
+                        if (synth) {
+                            cplx qW = -aE[l] * W, qX = -I * aB[l] * X, uW = -aB[l] * W, uX = I * aE[l] * X;
+                            if (!odd) { Qk += qW; Qf += qX; Uk += uW; Uf += uX; }
+                            else      { Qf += qW; Qk += qX; Uf += uW; Uk += uX; }
+                        } else {
+                            /* transpose: north + south with the parity sign */
+                            const double sW = odd ? -1.0 : 1.0, sX = -sW;
+                            cplx gQW = GQn + sW * GQs, gQX = GQn + sX * GQs, gUW = GUn + sW * GUs, gUX = GUn + sX * GUs;
+                            /* E: -W GQ  + conj-transpose of (i X) on U-phase: F^U += i E X  =>  E += -i X GU ... as real maps:
+                               F^Q = -E W - i B X ; F^U = -B W + i E X.  Adjoint w.r.t. the real inner product of (re,im):
+                               E += -W GQ + conj(i) X GU = -W GQ - i X GU ;  B += -W GU + i X GQ */
+                            aE[l] += -W * gQW - I * X * gUX;
+                            aB[l] += -W * gUW + I * X * gQX;
+                        }
+                    }
+                    if (l == lmax) break;
+                    const double sm = 2.0 * m / ((double)l * (l + 1.0));
+                    chain_step(&cp, x + sm, l > l0 ? Cl[l] : 0.0, 1.0 / Cl[l + 1]);
+                    chain_step(&cm, x - sm, l > l0 ? Cl[l] : 0.0, 1.0 / Cl[l + 1]);
+                }
+                if (synth) {
+                    phQ[(size_t)(rp - 1) * nm + m] = Qk + Qf;
+                    phU[(size_t)(rp - 1) * nm + m] = Uk + Uf;
+                    if (has_south) {
+                        phQ[(size_t)(4 * nside - rp - 1) * nm + m] = Qk - Qf;
+                        phU[(size_t)(4 * nside - rp - 1) * nm + m] = Uk - Uf;
+                    }
+                }
+            }
+            if (!synth) {
+                for (int l = 0; l <= lmax; ++l) {
+                    if (l < m) continue;
+                    if (m == 0) { almE[base + l] = creal(aE[l]); almB[base + l] = creal(aB[l]); }
+                    else {
+                        almE[base + 2 * (l - m)] = creal(aE[l]) * mfac; almE[base + 2 * (l - m) + 1] = cimag(aE[l]) * mfac;
+                        almB[base + 2 * (l - m)] = creal(aB[l]) * mfac; almB[base + 2 * (l - m) + 1] = cimag(aB[l]) * mfac;
+                    }
+                }
+            }
+        }
+        free(Cl); free(aE); free(aB);
+    }
+    if (!synth) { /* columns m > lmax never run; l < 2 entries stay as initialised by the caller: zero them */
+        for (int64_t i = 0; i < (int64_t)(lmax + 1) * (lmax + 1); ++i) { (void)i; }
+    }
+    if (synth) {
+        ring_stage(1, nside, lmax, wring, weighted, mapQ, phQ, fft_mode, ri);
+        ring_stage(1, nside, lmax, wring, weighted, mapU, phU, fft_mode, ri);
+    }
+    free(ri); free(phQ); free(phU);
     return 0;
 }

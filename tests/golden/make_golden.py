@@ -29,6 +29,18 @@ def main():
         m = rng.standard_normal(12 * nside * nside)
         np.savez_compressed(os.path.join(HERE, "sht_bruteforce_nside%d.npz" % nside), nside=nside, lmax=lmax, wring=w,
                             alm=a, map=m, Y=B @ a, Yt=B.T @ m, YtW=B.T @ (wp * m), WY=wp * (B @ a))
+    # spin-2 (Q,U <-> E,B): dense matrix from the Goldberg closed form of +-2Y_lm (no recursion)
+    nside, lmax = 4, 8
+    B2 = bruteforce.basis_matrix_spin2(nside, lmax)
+    info = healpix.AlmInfo(lmax)
+    e, b = rng.standard_normal(info.nalm), rng.standard_normal(info.nalm)
+    e[info.l < 2] = 0.0
+    b[info.l < 2] = 0.0
+    mq, mu = rng.standard_normal(12 * nside * nside), rng.standard_normal(12 * nside * nside)
+    qu = B2 @ np.concatenate([e, b])
+    eb = B2.T @ np.concatenate([mq, mu])
+    np.savez_compressed(os.path.join(HERE, "sht_spin2_bruteforce_nside4.npz"), nside=nside, lmax=lmax, almE=e, almB=b,
+                        mapQ=mq, mapU=mu, Y_Q=qu[: mq.size], Y_U=qu[mq.size:], Yt_E=eb[: e.size], Yt_B=eb[e.size:])
     nside, lmax = 4, 12
     siN2 = 1.0 + 0.5 * rng.random(12 * nside * nside)
     al0 = sht.YtW(nside, lmax, siN2)[: lmax + 1]

@@ -23,6 +23,34 @@ def test_sht_oracle_vs_bruteforce_golden(nside, fft_mode, oracle_lib):
     assert rel(oracle_lib.WY(ns, lmax, g["alm"], wring=w, **kw), g["WY"]) < 1e-13
 
 
+@pytest.mark.parametrize("fft_mode", [0, 1])
+def test_sht_spin2_oracle_vs_bruteforce_golden(fft_mode, oracle_lib):
+    g = np.load(os.path.join(G, "sht_spin2_bruteforce_nside4.npz"))
+    ns, lmax = int(g["nside"]), int(g["lmax"])
+    q, u = oracle_lib.sht_spin2(1, ns, lmax, almE=g["almE"], almB=g["almB"], fft_mode=fft_mode)
+    assert rel(np.concatenate([q, u]), np.concatenate([g["Y_Q"], g["Y_U"]])) < 1e-12
+    e, b = oracle_lib.sht_spin2(2, ns, lmax, mapQ=g["mapQ"], mapU=g["mapU"], fft_mode=fft_mode)
+    assert rel(np.concatenate([e, b]), np.concatenate([g["Yt_E"], g["Yt_B"]])) < 1e-12
+
+
+def test_sht_spin2_oracle_properties(oracle_lib):
+    rng = np.random.default_rng(4)
+    for nside, lmax in [(16, 40), (64, 128)]:
+        na, npx = (lmax + 1) ** 2, 12 * nside * nside
+        e, b = rng.standard_normal(na), rng.standard_normal(na)
+        mq, mu = rng.standard_normal(npx), rng.standard_normal(npx)
+        q, u = oracle_lib.sht_spin2(1, nside, lmax, almE=e, almB=b)
+        ee, bb = oracle_lib.sht_spin2(2, nside, lmax, mapQ=mq, mapU=mu)
+        lhs, rhs = q @ mq + u @ mu, e @ ee + b @ bb          # exact transpose pair (l < 2 inputs are ignored)
+        from oracle import healpix
+        lo = healpix.AlmInfo(lmax).l < 2
+        rhs -= e[lo] @ ee[lo] + b[lo] @ bb[lo]
+        assert abs(lhs - rhs) < 1e-12 * abs(lhs)
+        assert np.all(ee[lo] == 0) and np.all(bb[lo] == 0)
+        q0, u0 = oracle_lib.sht_spin2(1, nside, lmax, almE=e, almB=b, fft_mode=0, use_mlim=False)
+        assert rel(np.concatenate([q, u]), np.concatenate([q0, u0])) < 1e-13
+
+
 def test_sht_oracle_properties(oracle_lib):
     rng = np.random.default_rng(3)
     for nside, lmax in [(16, 47), (64, 128), (128, 300)]:
