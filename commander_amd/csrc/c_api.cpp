@@ -80,6 +80,68 @@ int cmdr_sht_plan_create(int nside, int lmax, int nrings, const int* rings, cons
     });
 }
 
+int cmdr_sht_plan_create_pol(int nside, int lmax, int nrings, const int* rings, const double* wring, int max_maps,
+                             cmdr_sht_plan** out) {
+    return guarded([&] {
+        CMDR_REQUIRE(out != nullptr, "out is NULL");
+        CMDR_REQUIRE(cmdr_device_count() > 0, "no HIP device available: libcmdr_hip has no CPU path");
+        std::vector<int> r;
+        if (rings && nrings > 0) r.assign(rings, rings + nrings);
+        auto* h = new cmdr_sht_plan;
+        try {
+            h->p = std::make_unique<cmdr::ShtPlan>(nside, lmax, r, wring, std::max(2, max_maps), true);
+        } catch (...) {
+            delete h;
+            throw;
+        }
+        *out = h;
+    });
+}
+
+int cmdr_sht_execute_spin2_dev(cmdr_sht_plan* plan, int job, double* almE_dev, double* almB_dev, double* mapQ_dev,
+                               double* mapU_dev) {
+    return guarded([&] {
+        CMDR_REQUIRE(plan && almE_dev && almB_dev && mapQ_dev && mapU_dev, "bad arguments");
+        cmdr::ShtPlan& P = *plan->p;
+        switch (job) {
+            case CMDR_Y: P.alm2map_spin2(almE_dev, almB_dev, mapQ_dev, mapU_dev, false, nullptr); break;
+            case CMDR_WY: P.alm2map_spin2(almE_dev, almB_dev, mapQ_dev, mapU_dev, true, nullptr); break;
+            case CMDR_Yt: P.map2alm_spin2(mapQ_dev, mapU_dev, almE_dev, almB_dev, false, nullptr); break;
+            case CMDR_YtW: P.map2alm_spin2(mapQ_dev, mapU_dev, almE_dev, almB_dev, true, nullptr); break;
+            default: throw cmdr::Error("unknown SHT job type " + std::to_string(job));
+        }
+        CMDR_HIP_CHECK(hipGetLastError());
+        CMDR_HIP_CHECK(hipStreamSynchronize(nullptr));
+    });
+}
+
+int cmdr_sht_execute_spin2(cmdr_sht_plan* plan, int job, double* almE, double* almB, double* mapQ, double* mapU) {
+    return guarded([&] {
+        CMDR_REQUIRE(plan && almE && almB && mapQ && mapU, "bad arguments");
+        cmdr::ShtPlan& P = *plan->p;
+        const int64_t na = P.nalm(), np = P.npix_local();
+        plan->alm.ensure((size_t)na * 2);
+        plan->map.ensure((size_t)np * 2);
+        const bool synth = (job == CMDR_Y || job == CMDR_WY);
+        double *dE = plan->alm.get(), *dB = dE + na, *dQ = plan->map.get(), *dU = dQ + np;
+        if (synth) {
+            CMDR_HIP_CHECK(hipMemcpy(dE, almE, na * sizeof(double), hipMemcpyHostToDevice));
+            CMDR_HIP_CHECK(hipMemcpy(dB, almB, na * sizeof(double), hipMemcpyHostToDevice));
+        } else {
+            CMDR_HIP_CHECK(hipMemcpy(dQ, mapQ, np * sizeof(double), hipMemcpyHostToDevice));
+            CMDR_HIP_CHECK(hipMemcpy(dU, mapU, np * sizeof(double), hipMemcpyHostToDevice));
+        }
+        if (cmdr_sht_execute_spin2_dev(plan, job, dE, dB, dQ, dU) != 0) throw cmdr::Error(g_err);
+        if (synth) {
+            CMDR_HIP_CHECK(hipMemcpy(mapQ, dQ, np * sizeof(double), hipMemcpyDeviceToHost));
+            CMDR_HIP_CHECK(hipMemcpy(mapU, dU, np * sizeof(double), hipMemcpyDeviceToHost));
+        } else {
+            CMDR_HIP_CHECK(hipMemcpy(almE, dE, na * sizeof(double), hipMemcpyDeviceToHost));
+            CMDR_HIP_CHECK(hipMemcpy(almB, dB, na * sizeof(double), hipMemcpyDeviceToHost));
+        }
+    });
+}
+
 int cmdr_sht_plan_destroy(cmdr_sht_plan* plan) {
     return guarded([&] { delete plan; });
 }

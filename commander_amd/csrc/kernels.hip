@@ -154,6 +154,116 @@ void launch_leg_adj(const LegArgs& A, const WaveTask* tasks, int ntasks, const d
     }
 }
 
+// ---- spin-2 (Q,U <-> E,B): same task / wave structure; one polarisation pair per launch slice
+template <int R>
+__global__ void __launch_bounds__(256) k_leg2_synth(Leg2Args A, const WaveTask* __restrict__ tasks, int ntasks,
+                                                    const double* __restrict__ st, int npol, int ip,
+                                                    double* __restrict__ ph, int64_t ph_stride, int kq) {
+    const int wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int t = blockIdx.x * 4 + wid;
+    if (t >= ntasks) return;
+    const WaveTask T = tasks[t];
+    if (T.chunk < 0) return;
+    leg2_synth_lane<R>(A, st, npol, ip, ph, ph_stride, kq, __builtin_amdgcn_readfirstlane(T.m),
+                       __builtin_amdgcn_readfirstlane(T.chunk), __builtin_amdgcn_readfirstlane(T.lw),
+                       __builtin_amdgcn_readfirstlane(T.lAend), threadIdx.x & 63);
+}
+
+template <int R>
+__global__ void __launch_bounds__(256) k_leg2_adj(Leg2Args A, const WaveTask* __restrict__ tasks, int ntasks,
+                                                  const double* __restrict__ ph, int64_t ph_stride, int kq,
+                                                  double* __restrict__ part, int64_t part_chunk_stride) {
+    __shared__ double lds[4][16 * 65];
+    const int wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    const int t = blockIdx.x * 4 + wid;
+    if (t >= ntasks) return;
+    const WaveTask T = tasks[t];
+    if (T.chunk < 0) return;
+    const int m = __builtin_amdgcn_readfirstlane(T.m);
+    const int chunk = __builtin_amdgcn_readfirstlane(T.chunk);
+    const int lw = __builtin_amdgcn_readfirstlane(T.lw);
+    const int lAend = __builtin_amdgcn_readfirstlane(T.lAend);
+    const int lmax = A.lmax;
+    Leg2State<R> S;
+    Adj2G<R> G;
+    leg2_load_state<R>(A, m, chunk, lane, S);
+    leg2_adj_load<R>(A, ph, ph_stride, kq, m, chunk, lane, G);
+#pragma unroll
+    for (int r = 0; r < R; ++r)
+        if (S.ls[r] == lw) { S.pc[r] = S.sd[r][0]; S.pp[r] = S.sd[r][1]; S.mc[r] = S.sd[r][2]; S.mp[r] = S.sd[r][3]; }
+    const int64_t mo = d_moffp(lmax, m);
+    const double* __restrict__ al = A.alpha + (mo - m);
+    const double* __restrict__ be = A.beta + (mo - m);
+    double* __restrict__ out = part + chunk * part_chunk_stride + 4 * (mo - m);   // 4 doubles per l
+    double* wl = lds[wid];
+    const int col = lane & 15, qtr = lane >> 4;
+    for (int l0 = lw; l0 <= lmax; l0 += 4) {
+        double v[16];
+        if (l0 < lAend) leg2_adj_group<R, true>(A, al, be, l0, S, G, v);
+        else            leg2_adj_group<R, false>(A, al, be, l0, S, G, v);
+#pragma unroll
+        for (int j = 0; j < 16; ++j) wl[j * 65 + lane] = v[j];
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        double sacc = 0.0;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) sacc += wl[col * 65 + qtr * 16 + i];
+        sacc += __shfl_xor(sacc, 16);
+        sacc += __shfl_xor(sacc, 32);
+        const int l = l0 + (col >> 2);
+        if (qtr == 0 && l <= lmax) out[4 * l + (col & 3)] = sacc;
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    }
+}
+
+void launch_leg2_synth(const Leg2Args& A, const WaveTask* tasks, int ntasks, const double* st, int npol, double* ph,
+                       int64_t ph_stride, int kq0, hipStream_t s) {
+    if (ntasks == 0) return;
+    for (int ip = 0; ip < npol; ++ip) {
+        if (A.R == 1) hipLaunchKernelGGL(k_leg2_synth<1>, dim3(ntasks / 4), dim3(256), 0, s, A, tasks, ntasks, st, npol, ip, ph, ph_stride, kq0 + 2 * ip);
+        else hipLaunchKernelGGL(k_leg2_synth<2>, dim3(ntasks / 4), dim3(256), 0, s, A, tasks, ntasks, st, npol, ip, ph, ph_stride, kq0 + 2 * ip);
+    }
+}
+void launch_leg2_adj(const Leg2Args& A, const WaveTask* tasks, int ntasks, const double* ph, int64_t ph_stride,
+                     int kq0, double* part, int64_t part_pol_stride, int64_t part_chunk_stride, int npol,
+                     hipStream_t s) {
+    if (ntasks == 0) return;
+    for (int ip = 0; ip < npol; ++ip) {
+        if (A.R == 1) hipLaunchKernelGGL(k_leg2_adj<1>, dim3(ntasks / 4), dim3(256), 0, s, A, tasks, ntasks, ph, ph_stride, kq0 + 2 * ip, part + ip * part_pol_stride, part_chunk_stride);
+        else hipLaunchKernelGGL(k_leg2_adj<2>, dim3(ntasks / 4), dim3(256), 0, s, A, tasks, ntasks, ph, ph_stride, kq0 + 2 * ip, part + ip * part_pol_stride, part_chunk_stride);
+    }
+}
+
+__global__ void k_alm2_to_stream(const double* __restrict__ aE, const double* __restrict__ aB, int64_t pol_stride,
+                                 double* __restrict__ st, int npol, const double* __restrict__ cnorm, int lmax) {
+    const int m = blockIdx.y, l = m + blockIdx.x * 256 + threadIdx.x;
+    if (l > lmax + 1) return;
+    alm2_to_stream_elem(aE + blockIdx.z * pol_stride, aB + blockIdx.z * pol_stride, st, npol, blockIdx.z, cnorm, lmax, m, l);
+}
+void launch_alm2_to_stream(const double* aE, const double* aB, int64_t pol_stride, double* st, int npol,
+                           const double* cnorm, int lmax, hipStream_t s) {
+    dim3 grid((lmax + 2 + 255) / 256, lmax + 1, npol);
+    hipLaunchKernelGGL(k_alm2_to_stream, grid, dim3(256), 0, s, aE, aB, pol_stride, st, npol, cnorm, lmax);
+}
+__global__ void k_part2_to_alm(const double* __restrict__ part, int64_t part_pol_stride, int64_t pcs, int nchunk,
+                               double* __restrict__ aE, double* __restrict__ aB, int64_t pol_stride,
+                               const double* __restrict__ cnorm, int lmax) {
+    const int m = blockIdx.y, l = m + blockIdx.x * 256 + threadIdx.x;
+    if (l > lmax) return;
+    part2_to_alm_elem(part + blockIdx.z * part_pol_stride, pcs, nchunk, aE + blockIdx.z * pol_stride,
+                      aB + blockIdx.z * pol_stride, cnorm, lmax, m, l);
+}
+void launch_part2_to_alm(const double* part, int64_t part_pol_stride, int64_t pcs, int nchunk, double* aE, double* aB,
+                         int64_t pol_stride, const double* cnorm, int lmax, int npol, hipStream_t s) {
+    dim3 grid((lmax + 1 + 255) / 256, lmax + 1, npol);
+    hipLaunchKernelGGL(k_part2_to_alm, grid, dim3(256), 0, s, part, part_pol_stride, pcs, nchunk, aE, aB, pol_stride,
+                       cnorm, lmax);
+}
+
 // ===================================================================================== ring stage
 // One workgroup = one ring pair of one map; the packed complex spectrum / pixels live in dynamic LDS.
 //   MODE 0: phases -> pixels (alm2map tail)         out map = y * (mul ? mul[pix] : 1) * (weighted ? wgt : 1)

@@ -26,6 +26,18 @@ void launch_alm_to_stream(const double* alm, int64_t alm_stride, double* ast, co
 void launch_part_to_alm(const double* part, int64_t pms, int64_t pcs, int nchunk, double* alm, int64_t alm_stride,
                         const double* cnorm, int lmax, int nmaps, hipStream_t s);
 
+// ---- spin-2 Legendre stage: npol polarisation pairs; pair ip uses phase maps kq0 + 2 ip (Q) and kq0 + 2 ip + 1 (U);
+// stream st[((t * npol) + ip) * 4 + {E'r,E'i,B'r,B'i}]; partials part[ip][chunk][4 * padded triangle]
+void launch_leg2_synth(const Leg2Args& A, const WaveTask* tasks, int ntasks, const double* st, int npol, double* ph,
+                       int64_t ph_stride, int kq0, hipStream_t s);
+void launch_leg2_adj(const Leg2Args& A, const WaveTask* tasks, int ntasks, const double* ph, int64_t ph_stride,
+                     int kq0, double* part, int64_t part_pol_stride, int64_t part_chunk_stride, int npol,
+                     hipStream_t s);
+void launch_alm2_to_stream(const double* aE, const double* aB, int64_t pol_stride, double* st, int npol,
+                           const double* cnorm, int lmax, hipStream_t s);
+void launch_part2_to_alm(const double* part, int64_t part_pol_stride, int64_t pcs, int nchunk, double* aE, double* aB,
+                         int64_t pol_stride, const double* cnorm, int lmax, int npol, hipStream_t s);
+
 // ---- CR solver streams (cr_kernels.hip)
 void launch_sqrtS(const CompDev* comps, int ncomp, int lmax_max, const double* smat, int kind, const double* in,
                   const double* add, double* out, bool pass_inactive, hipStream_t s);

@@ -32,6 +32,11 @@ CMDR_HD cd csub(cd a, cd b) { return {a.x - b.x, a.y - b.y}; }
 CMDR_HD cd cconj(cd a) { return {a.x, -a.y}; }
 
 CMDR_HD int64_t d_moffp(int lmax, int m) { return (int64_t)m * (lmax + 2) - (int64_t)m * (m - 1) / 2; }
+// Commander real-packed index of (l, +m) for a full (P=1) layout: comm_map_mod.f90:228-261, :1213-1246.
+CMDR_HD int64_t d_packed_index(int lmax, int l, int m) {
+    if (m == 0) return l;
+    return 2 * ((int64_t)m * (lmax + 1) - (int64_t)m * (m - 1) / 2) - (lmax + 1) + 2 * (l - m);
+}
 
 struct LegArgs {
     int lmax;
@@ -238,6 +243,221 @@ CMDR_HD void leg_adj_products(const AdjLane<R, NB>& S, const double (*w)[R], int
         v[2 * j + 2] = ur;
         v[2 * j + 3] = ui;
     }
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// Spin-2 Legendre stage: (E,B) stream -> phases of the Q and U maps (and its transpose).  Two spin-weighted
+// chains mu+ / mu- per ring pair; W = mu+ + mu-, X = mu+ - mu- (the 1/2 and the minus signs of
+//   F^Q = -sum_l (E W + i B X),   F^U = -sum_l (B W - i E X)
+// are folded into the stream: it carries E' = -E cnorm kappa / 2, B' likewise).  W has parity (-1)^{l+m} under
+// theta -> pi - theta, X the opposite, so each l feeds a "keep" and a "flip" accumulator: F_N = k + f, F_S = k - f.
+struct Leg2Args {
+    int lmax;
+    int npair_pad;
+    int R;
+    const double* x;       // [npair_pad]
+    const int* ls;         // [(lmax+1) * npair_pad]
+    const double* seed;    // [(lmax+1) * npair_pad * 4]
+    const double* alpha;   // [ntrip]
+    const double* beta;    // [ntrip]
+};
+
+template <int R>
+struct Leg2State {
+    double x[R], pc[R], pp[R], mc[R], mp[R];   // mu+ (current, previous), mu- (current, previous)
+    double sd[R][4];
+    int ls[R];
+};
+
+template <int R>
+CMDR_HD void leg2_load_state(const Leg2Args& A, int m, int chunk, int lane, Leg2State<R>& S) {
+    const int base = chunk * 64 * R + lane;
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        const int p = base + r * 64;
+        const int64_t idx = (int64_t)m * A.npair_pad + p;
+        S.x[r] = A.x[p];
+        S.ls[r] = A.ls[idx];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) S.sd[r][k] = A.seed[idx * 4 + k];
+        S.pc[r] = S.pp[r] = S.mc[r] = S.mp[r] = 0.0;
+    }
+}
+
+template <int R, bool INJECT>
+CMDR_HD void leg2_advance(Leg2State<R>& S, int r, int l, double al, double be) {
+    // on entry the state is at l; on exit at l+1 (al, be are alpha_{l+1}, beta_{l+1})
+    const double tp = al * S.x[r] + be, tm = al * S.x[r] - be;
+    double n = tp * S.pc[r] - S.pp[r];
+    S.pp[r] = S.pc[r];
+    S.pc[r] = n;
+    n = tm * S.mc[r] - S.mp[r];
+    S.mp[r] = S.mc[r];
+    S.mc[r] = n;
+    if (INJECT) if (S.ls[r] == l + 1) { S.pc[r] = S.sd[r][0]; S.pp[r] = S.sd[r][1]; S.mc[r] = S.sd[r][2]; S.mp[r] = S.sd[r][3]; }
+}
+
+// st : (E,B) stream of this polarisation pair set: st[((t * npol) + ip) * 4 + {E'r, E'i, B'r, B'i}]
+// ph : phase arrays; map kq = Q, kq + 1 = U
+template <int R>
+CMDR_HD void leg2_synth_lane(const Leg2Args& A, const double* __restrict__ st, int npol, int ip,
+                             double* __restrict__ ph, int64_t ph_stride, int kq, int m, int chunk, int lw,
+                             int lAend, int lane) {
+    const int lmax = A.lmax;
+    const int64_t mo = d_moffp(lmax, m);
+    const double* __restrict__ al = A.alpha + (mo - m);
+    const double* __restrict__ be = A.beta + (mo - m);
+    const double* __restrict__ as = st + 4 * ((int64_t)npol * (mo - m) + ip);
+    const int64_t ls4 = 4 * (int64_t)npol;
+    Leg2State<R> S;
+    leg2_load_state<R>(A, m, chunk, lane, S);
+    // accumulators: [0] = Q keep, [1] = Q flip, [2] = U keep, [3] = U flip ; (re, im)
+    double ar[R][4], ai[R][4];
+#pragma unroll
+    for (int r = 0; r < R; ++r)
+#pragma unroll
+        for (int k = 0; k < 4; ++k) ar[r][k] = ai[r][k] = 0.0;
+#pragma unroll
+    for (int r = 0; r < R; ++r)
+        if (S.ls[r] == lw) { S.pc[r] = S.sd[r][0]; S.pp[r] = S.sd[r][1]; S.mc[r] = S.sd[r][2]; S.mp[r] = S.sd[r][3]; }
+    for (int l = lw; l <= lmax; l += 2) {
+        const double* __restrict__ c0 = as + ls4 * l;
+        const double* __restrict__ c1 = c0 + ls4;
+        const double e0r = c0[0], e0i = c0[1], b0r = c0[2], b0i = c0[3];
+        const double e1r = c1[0], e1i = c1[1], b1r = c1[2], b1i = c1[3];
+        const double al1 = al[l + 1], be1 = be[l + 1], al2 = al[l + 2], be2 = be[l + 2];
+        const bool inj = l < lAend;
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            double W = S.pc[r] + S.mc[r], X = S.pc[r] - S.mc[r];
+            // first of the pair: W-terms keep, X-terms flip
+            ar[r][0] += e0r * W;  ai[r][0] += e0i * W;      // Q keep  += E' W
+            ar[r][1] -= b0i * X;  ai[r][1] += b0r * X;      // Q flip  += i B' X
+            ar[r][2] += b0r * W;  ai[r][2] += b0i * W;      // U keep  += B' W
+            ar[r][3] += e0i * X;  ai[r][3] -= e0r * X;      // U flip  += -i E' X
+            if (inj) leg2_advance<R, true>(S, r, l, al1, be1); else leg2_advance<R, false>(S, r, l, al1, be1);
+            W = S.pc[r] + S.mc[r];
+            X = S.pc[r] - S.mc[r];
+            // second of the pair: W-terms flip, X-terms keep
+            ar[r][1] += e1r * W;  ai[r][1] += e1i * W;
+            ar[r][0] -= b1i * X;  ai[r][0] += b1r * X;
+            ar[r][3] += b1r * W;  ai[r][3] += b1i * W;
+            ar[r][2] += e1i * X;  ai[r][2] -= e1r * X;
+            if (inj) leg2_advance<R, true>(S, r, l + 1, al2, be2); else leg2_advance<R, false>(S, r, l + 1, al2, be2);
+        }
+    }
+    const int l0 = m > 2 ? m : 2;
+    const bool swap = ((l0 + m) & 1) != 0;   // first-of-pair has odd l+m: keep <-> flip
+    const int base = chunk * 64 * R + lane;
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        const int p = base + r * 64;
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            const double kr = swap ? ar[r][2 * q + 1] : ar[r][2 * q], ki = swap ? ai[r][2 * q + 1] : ai[r][2 * q];
+            const double fr = swap ? ar[r][2 * q] : ar[r][2 * q + 1], fi = swap ? ai[r][2 * q] : ai[r][2 * q + 1];
+            double* o = ph + (kq + q) * ph_stride + ((int64_t)m * A.npair_pad + p) * 4;
+            o[0] = kr + fr;
+            o[1] = ki + fi;
+            o[2] = kr - fr;
+            o[3] = ki - fi;
+        }
+    }
+}
+
+// Adjoint lane state: G combinations of the Q and U phases
+template <int R>
+struct Adj2G {
+    double qk_r[R], qk_i[R], qf_r[R], qf_i[R], uk_r[R], uk_i[R], uf_r[R], uf_i[R];
+};
+
+template <int R>
+CMDR_HD void leg2_adj_load(const Leg2Args& A, const double* __restrict__ ph, int64_t ph_stride, int kq, int m,
+                           int chunk, int lane, Adj2G<R>& G) {
+    const int l0 = m > 2 ? m : 2;
+    const bool swap = ((l0 + m) & 1) != 0;
+    const int base = chunk * 64 * R + lane;
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        const int64_t idx = (int64_t)m * A.npair_pad + base + r * 64;
+        const double* q = ph + kq * ph_stride + idx * 4;
+        const double* u = ph + (kq + 1) * ph_stride + idx * 4;
+        // "keep" pairs with (N + S), "flip" with (N - S); for odd first-of-pair parity the roles swap
+        const double qpr = q[0] + q[2], qpi = q[1] + q[3], qmr = q[0] - q[2], qmi = q[1] - q[3];
+        const double upr = u[0] + u[2], upi = u[1] + u[3], umr = u[0] - u[2], umi = u[1] - u[3];
+        G.qk_r[r] = swap ? qmr : qpr; G.qk_i[r] = swap ? qmi : qpi;
+        G.qf_r[r] = swap ? qpr : qmr; G.qf_i[r] = swap ? qpi : qmi;
+        G.uk_r[r] = swap ? umr : upr; G.uk_i[r] = swap ? umi : upi;
+        G.uf_r[r] = swap ? upr : umr; G.uf_i[r] = swap ? upi : umi;
+    }
+}
+
+// one group of 4 l (two pairs): v[4*j + {0..3}] = partial (E'r, E'i, B'r, B'i) of this lane for l = l0g + j
+// transpose of leg2_synth_lane's accumulations:
+//   first of pair : E' += W Gq_keep - i X Gu_flip... written out per component below
+template <int R, bool INJECT>
+CMDR_HD void leg2_adj_group(const Leg2Args& A, const double* __restrict__ al, const double* __restrict__ be, int l0g,
+                            Leg2State<R>& S, const Adj2G<R>& G, double* v) {
+#pragma unroll
+    for (int j = 0; j < 4; j += 2) {
+        const int l = l0g + j;
+        double er = 0, ei = 0, br = 0, bi = 0, er2 = 0, ei2 = 0, br2 = 0, bi2 = 0;
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            double W = S.pc[r] + S.mc[r], X = S.pc[r] - S.mc[r];
+            // synthesis (first of pair): Qk += E' W ; Qf += i B' X ; Uk += B' W ; Uf += -i E' X
+            er += W * G.qk_r[r] - X * G.uf_i[r];
+            ei += W * G.qk_i[r] + X * G.uf_r[r];
+            br += W * G.uk_r[r] + X * G.qf_i[r];
+            bi += W * G.uk_i[r] - X * G.qf_r[r];
+            leg2_advance<R, INJECT>(S, r, l, al[l + 1], be[l + 1]);
+            W = S.pc[r] + S.mc[r];
+            X = S.pc[r] - S.mc[r];
+            // second of pair: Qf += E' W ; Qk += i B' X ; Uf += B' W ; Uk += -i E' X
+            er2 += W * G.qf_r[r] - X * G.uk_i[r];
+            ei2 += W * G.qf_i[r] + X * G.uk_r[r];
+            br2 += W * G.uf_r[r] + X * G.qk_i[r];
+            bi2 += W * G.uf_i[r] - X * G.qk_r[r];
+            leg2_advance<R, INJECT>(S, r, l + 1, al[l + 2], be[l + 2]);
+        }
+        v[4 * j + 0] = er;  v[4 * j + 1] = ei;  v[4 * j + 2] = br;  v[4 * j + 3] = bi;
+        v[4 * j + 4] = er2; v[4 * j + 5] = ei2; v[4 * j + 6] = br2; v[4 * j + 7] = bi2;
+    }
+}
+
+// packed (E, B) a_lm -> spin-2 stream entry: E' = -E cnorm kappa_m / 2 (kappa = 1/sqrt2 for m > 0), l >= 2 only
+CMDR_HD void alm2_to_stream_elem(const double* __restrict__ aE, const double* __restrict__ aB,
+                                 double* __restrict__ st, int npol, int ip, const double* __restrict__ cnorm,
+                                 int lmax, int m, int l) {
+    const int64_t t = d_moffp(lmax, m) + (l - m);
+    double v[4] = {0.0, 0.0, 0.0, 0.0};
+    if (l <= lmax && l >= 2) {
+        const int64_t i = d_packed_index(lmax, l, m);
+        const double f = -0.5 * cnorm[t] * (m == 0 ? 1.0 : 0.70710678118654752440);
+        v[0] = aE[i] * f;
+        v[2] = aB[i] * f;
+        if (m > 0) { v[1] = aE[i + 1] * f; v[3] = aB[i + 1] * f; }
+    }
+    double* o = st + 4 * (t * npol + ip);
+    o[0] = v[0]; o[1] = v[1]; o[2] = v[2]; o[3] = v[3];
+}
+
+// spin-2 adjoint partial columns (4 doubles per l: E'r, E'i, B'r, B'i) -> packed E, B:
+//   E = -cnorm kappa'_m / 2 * sum_chunks part ; kappa' = sqrt2 for m > 0 ; l < 2 -> 0
+CMDR_HD void part2_to_alm_elem(const double* __restrict__ p, int64_t part_chunk_stride, int nchunk,
+                               double* __restrict__ aE, double* __restrict__ aB, const double* __restrict__ cnorm,
+                               int lmax, int m, int l) {
+    const int64_t t = d_moffp(lmax, m) + (l - m);
+    double s[4] = {0.0, 0.0, 0.0, 0.0};
+    if (l >= 2)
+        for (int c = 0; c < nchunk; ++c)
+#pragma unroll
+            for (int k = 0; k < 4; ++k) s[k] += p[c * part_chunk_stride + 4 * t + k];
+    const double f = -0.5 * cnorm[t] * (m == 0 ? 1.0 : 1.41421356237309504880);
+    const int64_t i = d_packed_index(lmax, l, m);
+    aE[i] = s[0] * f;
+    aB[i] = s[2] * f;
+    if (m > 0) { aE[i + 1] = s[1] * f; aB[i + 1] = s[3] * f; }
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -529,12 +749,6 @@ CMDR_HD void ring_store_phases(const cd* buf, const RingDev& d, double* __restri
 
 // ---------------------------------------------------------------------------------------------------------
 // a_lm layout conversion elements (one (l, m) each).
-// Commander real-packed index of (l, +m) for a full (P=1) layout: comm_map_mod.f90:228-261, :1213-1246.
-CMDR_HD int64_t d_packed_index(int lmax, int l, int m) {
-    if (m == 0) return l;
-    return 2 * ((int64_t)m * (lmax + 1) - (int64_t)m * (m - 1) / 2) - (lmax + 1) + 2 * (l - m);
-}
-
 // packed a_lm -> padded-triangle complex stream entry, times cnorm * kappa_m; kappa = 1/sqrt2 for m > 0
 // (the ring stage builds X[m] += G, X[-m] += conj G), 1 for m = 0.  l = lmax+1 is the zero pad entry.
 CMDR_HD void alm_to_stream_elem(const double* __restrict__ a, double* __restrict__ ast, int nbs, int k,

@@ -147,6 +147,164 @@ void LegendreTables::build(int lmax_, const std::vector<double>& x_, const std::
     while (tasks_s.size() % 4) { WaveTask t; t.m = 0; t.chunk = -1; t.lw = lmax + 1; t.lAend = lmax + 1; tasks_s.push_back(t); }
 }
 
+// --------------------------------------------------------------------------------------------- spin-2 tables
+void Legendre2Tables::build(int lmax_, const std::vector<double>& x, const std::vector<double>& sth, int npair_pad_,
+                            int R_, int nthreads) {
+    lmax = lmax_;
+    npair_pad = npair_pad_;
+    R = R_;
+    const int npair = (int)x.size();
+    const int per = kWave * R;
+    nchunk = npair_pad / per;
+    const int nm = lmax + 1;
+    mlim.assign(npair_pad, -1);
+    for (int p = 0; p < npair; ++p) mlim[p] = mlim_spin2(lmax, sth[p], x[p]);
+    alpha.assign(ntrip(lmax), 0.0);
+    beta.assign(ntrip(lmax), 0.0);
+    cnorm.assign(ntrip(lmax), 0.0);
+    ls.assign((size_t)nm * npair_pad, kLsNever);
+    seed.assign((size_t)nm * npair_pad * 4, 0.0);
+    host_parallel_for(nm, [&](int mi) {
+        const int m = (mi & 1) ? lmax - mi / 2 : mi / 2;
+        const int l0 = std::max(m, 2);
+        if (l0 > lmax) return;
+        const int64_t mo = moffp(lmax, m);
+        double* al = alpha.data() + mo - m;   // al[l], l = m..lmax+1
+        double* be = beta.data() + mo - m;
+        double* cn = cnorm.data() + mo - m;
+        auto C = [&](int l) {
+            const double dl = l, dm = m;
+            return std::sqrt((dl * dl - dm * dm) * (dl * dl - 4.0) / (dl * dl * (4.0 * dl * dl - 1.0)));
+        };
+        // c_{l0} = c_{l0+1} = 1 ; c_{l+1} = c_{l-1} C_l / C_{l+1} ; alpha_{l+1} = c_l / (C_{l+1} c_{l+1}) ;
+        // beta_{l+1} = 2 alpha_{l+1} m / (l (l+1))
+        std::vector<double> c(lmax + 3, 0.0);
+        c[l0] = 1.0;
+        if (l0 + 1 <= lmax + 1) c[l0 + 1] = 1.0;
+        for (int l = l0 + 1; l <= lmax; ++l) c[l + 1] = c[l - 1] * C(l) / C(l + 1);
+        for (int l = l0; l <= lmax; ++l) {
+            const double a = c[l] / (C(l + 1) * c[l + 1]);
+            al[l + 1] = a;
+            be[l + 1] = 2.0 * a * (double)m / ((double)l * (l + 1.0));
+        }
+        for (int l = l0; l <= lmax; ++l) cn[l] = c[l];
+        // seeds: both chains from their closed-form start, scaled recursion until either exceeds the threshold
+        int* lsm = ls.data() + (size_t)m * npair_pad;
+        double* sd = seed.data() + (size_t)m * npair_pad * 4;
+        for (int p = 0; p < npair; ++p) {
+            if (m > mlim[p]) continue;
+            const double th = std::atan2(sth[p], x[p]), c2 = std::cos(0.5 * th), s2 = std::sin(0.5 * th);
+            double lc[2], lp[2] = {0.0, 0.0};
+            long e[2];
+            for (int ch = 0; ch < 2; ++ch) {
+                const int s = ch == 0 ? 2 : -2;
+                double l2, sign;
+                if (m >= 2) {
+                    double lg = 0.5 * (std::log(2.0 * m + 1.0) - std::log(4.0 * kPi) + std::lgamma(2.0 * m + 1.0) -
+                                       std::lgamma(m + s + 1.0) - std::lgamma(m - s + 1.0));
+                    lg += (m - s) * std::log(c2) + (m + s) * std::log(s2);
+                    l2 = lg / M_LN2;
+                    sign = (m & 1) ? -1.0 : 1.0;
+                } else {   // m = 0, 1: Goldberg sum at l = 2
+                    static const double fact[8] = {1, 1, 2, 6, 24, 120, 720, 5040};
+                    const int l = 2;
+                    const double pref = ((m & 1) ? -1.0 : 1.0) *
+                                        std::sqrt(5.0 / (4 * kPi) * fact[l + m] * fact[l - m] / (fact[l + s] * fact[l - s]));
+                    double acc = 0;
+                    for (int r = 0; r <= l - s; ++r) {
+                        const int k = r + s - m;
+                        if (k < 0 || k > l + s) continue;
+                        const double c1 = fact[l - s] / (fact[r] * fact[l - s - r]), cc2 = fact[l + s] / (fact[k] * fact[l + s - k]);
+                        acc += c1 * cc2 * (((l - r - s) & 1) ? -1.0 : 1.0) * std::pow(s2, 2 * l - 2 * r - s + m) *
+                               std::pow(c2, 2 * r + s - m);
+                    }
+                    const double v = pref * acc;
+                    l2 = v == 0.0 ? -1e30 : std::log2(std::fabs(v));
+                    sign = v < 0 ? -1.0 : 1.0;
+                }
+                if (l2 < -1e20) { lc[ch] = 0.0; e[ch] = 0; }
+                else {
+                    const double fl = std::floor(l2);
+                    e[ch] = (long)fl;
+                    lc[ch] = sign * std::exp2(l2 - fl);
+                }
+            }
+            // bring both chains to the common (larger) exponent
+            auto align = [&]() {
+                const long E = std::max(e[0], e[1]);
+                for (int ch = 0; ch < 2; ++ch) {
+                    const long d = E - e[ch];
+                    if (d > 0) {
+                        const double f = d > 2000 ? 0.0 : std::ldexp(1.0, (int)-d);
+                        lc[ch] *= f;
+                        lp[ch] *= f;
+                        e[ch] = E;
+                    }
+                }
+            };
+            align();
+            int l = l0;
+            for (;;) {
+                int ex;
+                (void)std::frexp(std::max(std::max(std::fabs(lc[0]), std::fabs(lp[0])),
+                                          std::max(std::fabs(lc[1]), std::fabs(lp[1]))), &ex);
+                if (e[0] + ex >= -280) {
+                    lsm[p] = l;
+                    sd[4 * p + 0] = std::ldexp(lc[0], (int)e[0]);
+                    sd[4 * p + 1] = std::ldexp(lp[0], (int)e[0]);
+                    sd[4 * p + 2] = std::ldexp(lc[1], (int)e[0]);
+                    sd[4 * p + 3] = std::ldexp(lp[1], (int)e[0]);
+                    break;
+                }
+                if (l == lmax) break;
+                for (int ch = 0; ch < 2; ++ch) {
+                    const double t = al[l + 1] * x[p] + (ch == 0 ? be[l + 1] : -be[l + 1]);
+                    const double ln = t * lc[ch] - lp[ch];
+                    lp[ch] = lc[ch];
+                    lc[ch] = ln;
+                }
+                ++l;
+                if (std::max(std::fabs(lc[0]), std::fabs(lc[1])) > 0x1p+300) {
+                    for (int ch = 0; ch < 2; ++ch) { lc[ch] *= 0x1p-300; lp[ch] *= 0x1p-300; e[ch] += 300; }
+                }
+            }
+        }
+    }, nthreads);
+    tasks.clear();
+    for (int m = 0; m < nm; ++m) {
+        const int l0 = std::max(m, 2);
+        const int* lsm = ls.data() + (size_t)m * npair_pad;
+        for (int ch = 0; ch < nchunk; ++ch) {
+            int lo = kLsNever, hi = -1;
+            for (int p = ch * per; p < (ch + 1) * per; ++p) {
+                const int v = lsm[p];
+                if (v == kLsNever) continue;
+                lo = std::min(lo, v);
+                hi = std::max(hi, v);
+            }
+            if (hi < 0) continue;
+            WaveTask t;
+            t.m = m;
+            t.chunk = ch;
+            t.lw = lo - ((lo - l0) & 1);           // pairs (l, l+1) start at l0-parity
+            int a = hi + 1;
+            a += (a - l0) & 1;
+            t.lAend = a;
+            tasks.push_back(t);
+        }
+    }
+    std::stable_sort(tasks.begin(), tasks.end(), [](const WaveTask& a, const WaveTask& b) { return a.lw < b.lw; });
+    while (tasks.size() % 4) { WaveTask t; t.m = 0; t.chunk = -1; t.lw = lmax + 1; t.lAend = lmax + 1; tasks.push_back(t); }
+}
+
+void ShtTables::build_spin2(int nthreads) {
+    if (leg2.lmax == lmax) return;
+    std::vector<double> x(leg.x.begin(), leg.x.begin() + leg.npair), sth(leg.sth.begin(), leg.sth.begin() + leg.npair);
+    int R2 = 2;
+    while (R2 > 1 && leg.npair_pad % (kWave * R2) != 0) R2 >>= 1;
+    leg2.build(lmax, x, sth, leg.npair_pad, R2, nthreads);
+}
+
 static int bitrev(int v, int bits) {
     int r = 0;
     for (int i = 0; i < bits; ++i) { r = (r << 1) | (v & 1); v >>= 1; }
@@ -261,7 +419,7 @@ void RingTables::build(int nside_, int lmax_, const std::vector<int>& rings, con
 }
 
 void ShtTables::build(int nside_, int lmax_, const std::vector<int>& rings_in, const double* wring, int max_maps,
-                      int nthreads) {
+                      bool pol, int nthreads) {
     nside = nside_;
     lmax = lmax_;
     std::vector<int> rings = rings_in;
@@ -284,7 +442,12 @@ void ShtTables::build(int nside_, int lmax_, const std::vector<int>& rings_in, c
     if (const char* e = std::getenv("CMDR_LEG_RS")) { const int v = std::atoi(e); if (v == 1 || v == 2 || v == 4) Rs = v; }
     (void)max_maps;
     leg.build(lmax, x, sth, R, Rs, nthreads);
-    ring.build(nside, lmax, rings, wring, leg.mlim);
+    std::vector<int> ml = leg.mlim;
+    if (pol) {   // the ring stage must carry every m either spin needs
+        build_spin2(nthreads);
+        for (size_t p = 0; p < ml.size(); ++p) ml[p] = std::max(ml[p], leg2.mlim[p]);
+    }
+    ring.build(nside, lmax, rings, wring, ml);
 }
 
 void gauss_legendre(int n, std::vector<double>& x, std::vector<double>& w) {

@@ -42,6 +42,34 @@ struct LegendreTables {
                int nthreads = 0);
 };
 
+// Spin-2 Legendre tables: the two spin-weighted chains (+2, -2) share alpha / cnorm and differ by the sign of beta:
+//   mu+-_{l+1} = (alpha_{l+1} x +- beta_{l+1}) mu+-_l - mu+-_{l-1},   (+-2)lambda_lm = cnorm_l mu+-_l,   l >= l0 = max(m, 2)
+// from (pinned against the Goldberg closed form, oracle/bruteforce.py):
+//   s_lam_{l+1} = [(x + s m/(l(l+1))) s_lam_l - C_l s_lam_{l-1}] / C_{l+1},  C_l = sqrt((l^2-m^2)(l^2-4)/(l^2(4l^2-1)))
+struct Legendre2Tables {
+    int lmax = -1, npair_pad = 0, R = 2, nchunk = 0;
+    std::vector<int> mlim;               // [npair_pad] spin-2 cut
+    std::vector<double> alpha, beta, cnorm;   // [ntrip]
+    std::vector<int> ls;                 // [(lmax+1) * npair_pad]
+    std::vector<double> seed;            // [(lmax+1) * npair_pad * 4]: mu+_ls, mu+_{ls-1}, mu-_ls, mu-_{ls-1}
+    std::vector<WaveTask> tasks;         // R pairs per lane, 4 tasks per workgroup, longest first
+    void build(int lmax, const std::vector<double>& x, const std::vector<double>& sth, int npair_pad, int R,
+               int nthreads = 0);
+};
+
+inline int mlim_spin2(int lmax, double sth, double cth) {   // libsharp's cut with spin = 2
+    double ofs = lmax * 0.01;
+    if (ofs < 100.) ofs = 100.;
+    const double b = -4.0 * std::fabs(cth);
+    const double t1 = lmax * sth + ofs;
+    const double c = 4.0 - t1 * t1;
+    const double discr = b * b - 4 * c;
+    if (discr <= 0) return lmax;
+    double res = (-b + std::sqrt(discr)) / 2.;
+    if (res > lmax) res = lmax;
+    return (int)(res + 0.5);
+}
+
 struct RingPairDesc {   // one north/south ring pair (or the equator alone: startS = -1)
     int nphi;           // pixels per ring
     int log2M;          // FFT size class: nphi if power of two, else Bluestein M >= 2 nphi - 1
@@ -70,12 +98,14 @@ struct RingTables {
 struct ShtTables {
     int nside = 0, lmax = -1;
     LegendreTables leg;
+    Legendre2Tables leg2;     // built on demand (polarised plans)
+    void build_spin2(int nthreads = 0);
     RingTables ring;
     // rings: northern ring numbers (1..2*nside) this plan owns; empty = all (single GPU)
     // max_maps: how many maps one call transforms at once; picks the ring pairs per lane R (more maps per wave ->
     // fewer ring pairs per lane, same register budget)
     void build(int nside, int lmax, const std::vector<int>& rings, const double* wring, int max_maps = 1,
-               int nthreads = 0);
+               bool pol = false, int nthreads = 0);
 };
 
 // Gauss-Legendre nodes/weights on (-1,1), descending x (north first).

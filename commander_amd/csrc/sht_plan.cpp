@@ -39,12 +39,26 @@ LegArgs LegendreDev::args_synth() const {
     return A;
 }
 
-ShtPlan::ShtPlan(int nside, int lmax, const std::vector<int>& rings, const double* wring, int max_maps)
-    : max_maps_(max_maps) {
+void Legendre2Dev::upload(const Legendre2Tables& T) {
+    lmax = T.lmax;
+    npair_pad = T.npair_pad;
+    R = T.R;
+    nchunk = T.nchunk;
+    ntasks = (int)T.tasks.size();
+    seed.upload(T.seed);
+    ls.upload(T.ls);
+    alpha.upload(T.alpha);
+    beta.upload(T.beta);
+    cnorm.upload(T.cnorm);
+    tasks.upload(T.tasks);
+}
+
+ShtPlan::ShtPlan(int nside, int lmax, const std::vector<int>& rings, const double* wring, int max_maps, bool pol)
+    : max_maps_(max_maps), pol_(pol) {
     CMDR_REQUIRE(nside >= 1 && (nside & (nside - 1)) == 0, "nside must be a power of two");
     CMDR_REQUIRE(lmax >= 0, "lmax must be >= 0");
     CMDR_REQUIRE(max_maps >= 1, "max_maps must be >= 1");
-    T_.build(nside, lmax, rings, wring, max_maps);
+    T_.build(nside, lmax, rings, wring, max_maps, pol);
     CMDR_REQUIRE(T_.ring.log2Mmax <= 13, "ring FFT larger than 8192 points (nside > 1024) is not supported yet");
     leg_.upload(T_.leg);
     std::vector<RingDev> rd(T_.ring.npair);
@@ -75,6 +89,15 @@ ShtPlan::ShtPlan(int nside, int lmax, const std::vector<int>& rings, const doubl
     ast_.alloc((size_t)max_maps * leg_.tri_elems());
     ph_.alloc((size_t)max_maps * leg_.ph_elems());
     part_.alloc((size_t)max_maps * part_map_stride());
+    if (pol) {
+        CMDR_REQUIRE(max_maps >= 2, "a polarised plan needs max_maps >= 2 (Q and U phases)");
+        leg2_.upload(T_.leg2);
+        const int npol = max_maps / 2;
+        st2_.alloc((size_t)npol * leg2_.tri4());
+        part2_.alloc((size_t)npol * part2_pol_stride());
+        st2_.zero();
+        part2_.zero();
+    }
     // never-written entries ((m, pair) beyond mlim, l below a task's start) must read as zero forever
     ast_.zero();
     ph_.zero();
@@ -122,6 +145,49 @@ void ShtPlan::map2alm(const double* d_map, int64_t map_stride, double* d_alm, in
         launch_part_to_alm(part_.get(), part_map_stride(), leg_.tri_elems(), leg_.nchunk, d_alm + i0 * alm_stride,
                            alm_stride, leg_.cnorm.get(), T_.lmax, nb, s);
     }
+}
+
+Leg2Args ShtPlan_leg2_args(const Legendre2Dev& L, const double* x) {
+    Leg2Args A;
+    A.lmax = L.lmax;
+    A.npair_pad = L.npair_pad;
+    A.R = L.R;
+    A.x = x;
+    A.ls = L.ls.get();
+    A.seed = L.seed.get();
+    A.alpha = L.alpha.get();
+    A.beta = L.beta.get();
+    return A;
+}
+
+void ShtPlan::synth2_from_stream(int npol, int kq0, hipStream_t s) {
+    CMDR_REQUIRE(pol_, "plan was created without polarisation");
+    launch_leg2_synth(ShtPlan_leg2_args(leg2_, leg_.x.get()), leg2_.tasks.get(), leg2_.ntasks, st2_.get(), npol, ph_.get(),
+                      leg_.ph_elems(), kq0, s);
+}
+
+void ShtPlan::adjoint2_to_partials(int npol, int kq0, hipStream_t s) {
+    CMDR_REQUIRE(pol_, "plan was created without polarisation");
+    launch_leg2_adj(ShtPlan_leg2_args(leg2_, leg_.x.get()), leg2_.tasks.get(), leg2_.ntasks, ph_.get(), leg_.ph_elems(), kq0,
+                    part2_.get(), part2_pol_stride(), leg2_.tri4(), npol, s);
+}
+
+void ShtPlan::alm2map_spin2(const double* d_E, const double* d_B, double* d_Q, double* d_U, bool weighted,
+                            hipStream_t s) {
+    CMDR_REQUIRE(pol_, "plan was created without polarisation");
+    launch_alm2_to_stream(d_E, d_B, 0, st2_.get(), 1, leg2_.cnorm.get(), T_.lmax, s);
+    synth2_from_stream(1, 0, s);
+    // Q and U are two scalar-like maps for the ring stage (phase maps 0 and 1)
+    rings(0, d_Q, d_U - d_Q, nullptr, weighted, 2, s);
+}
+
+void ShtPlan::map2alm_spin2(const double* d_Q, const double* d_U, double* d_E, double* d_B, bool weighted,
+                            hipStream_t s) {
+    CMDR_REQUIRE(pol_, "plan was created without polarisation");
+    rings(1, const_cast<double*>(d_Q), d_U - d_Q, nullptr, weighted, 2, s);
+    adjoint2_to_partials(1, 0, s);
+    launch_part2_to_alm(part2_.get(), part2_pol_stride(), leg2_.tri4(), leg2_.nchunk, d_E, d_B, 0, leg2_.cnorm.get(),
+                        T_.lmax, 1, s);
 }
 
 }  // namespace cmdr

@@ -24,9 +24,30 @@ class LegendreDev {  // device mirror of LegendreTables
     int64_t tri_elems() const { return 2 * ntrip(lmax); }                          // doubles per map
 };
 
+class Legendre2Dev {  // device mirror of Legendre2Tables
+  public:
+    void upload(const Legendre2Tables& T);
+    Leg2Args args() const;
+    int lmax = -1, npair_pad = 0, R = 2, nchunk = 0, ntasks = 0;
+    DevBuf<double> x, seed, alpha, beta, cnorm;
+    DevBuf<int> ls;
+    DevBuf<WaveTask> tasks;
+    int64_t tri4() const { return 4 * ntrip(lmax); }   // doubles per polarisation pair (stream / one partial chunk)
+};
+
 class ShtPlan {
   public:
-    ShtPlan(int nside, int lmax, const std::vector<int>& rings, const double* wring, int max_maps);
+    ShtPlan(int nside, int lmax, const std::vector<int>& rings, const double* wring, int max_maps, bool pol = false);
+    bool pol() const { return pol_; }
+    // (Q,U) <-> (E,B): Commander's spin-2 call on columns 2:3 (comm_map_mod.f90:446-449, 519-523, 549-553)
+    void alm2map_spin2(const double* d_E, const double* d_B, double* d_Q, double* d_U, bool weighted, hipStream_t s);
+    void map2alm_spin2(const double* d_Q, const double* d_U, double* d_E, double* d_B, bool weighted, hipStream_t s);
+    double* stream2() { return st2_.get(); }               // [4 * ntrip][npol interleaved]
+    double* partials2() { return part2_.get(); }           // [npol][nchunk2][4 * ntrip]
+    int64_t part2_pol_stride() const { return (int64_t)leg2_.nchunk * leg2_.tri4(); }
+    void synth2_from_stream(int npol, int kq0, hipStream_t s);     // stream2 -> phases of maps kq0 ..
+    void adjoint2_to_partials(int npol, int kq0, hipStream_t s);
+    const Legendre2Dev& leg2() const { return leg2_; }
     int nside() const { return T_.nside; }
     int lmax() const { return T_.lmax; }
     int64_t npix_local() const { return T_.ring.npix_local; }
@@ -55,7 +76,10 @@ class ShtPlan {
   private:
     ShtTables T_;
     LegendreDev leg_;
+    Legendre2Dev leg2_;
     int max_maps_;
+    bool pol_ = false;
+    DevBuf<double> st2_, part2_;
     DevBuf<RingDev> rings_;
     std::vector<DevBuf<int>> cls_;
     std::vector<int> ncls_;

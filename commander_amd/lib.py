@@ -34,6 +34,9 @@ def _sig(L):
     L.cmdr_memcpy_h2d.argtypes = [c_vp, c_vp, c_sz]
     L.cmdr_memcpy_d2h.argtypes = [c_vp, c_vp, c_sz]
     L.cmdr_sht_plan_create.argtypes = [c_int, c_int, c_int, ip, dp, c_int, ctypes.POINTER(c_vp)]
+    L.cmdr_sht_plan_create_pol.argtypes = [c_int, c_int, c_int, ip, dp, c_int, ctypes.POINTER(c_vp)]
+    L.cmdr_sht_execute_spin2.argtypes = [c_vp, c_int, dp, dp, dp, dp]
+    L.cmdr_sht_execute_spin2_dev.argtypes = [c_vp, c_int, c_vp, c_vp, c_vp, c_vp]
     L.cmdr_sht_plan_destroy.argtypes = [c_vp]
     L.cmdr_sht_nalm.argtypes = [c_vp]
     L.cmdr_sht_nalm.restype = c_i64

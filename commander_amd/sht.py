@@ -13,7 +13,7 @@ _dp = ctypes.POINTER(ctypes.c_double)
 class ShtPlan:
     """One (nside, lmax, ring subset) transform plan, cf. ``comm_mapinfo`` (comm_map_mod.f90:134-305)."""
 
-    def __init__(self, nside, lmax, rings=None, wring=None, max_maps=1):
+    def __init__(self, nside, lmax, rings=None, wring=None, max_maps=1, pol=False):
         self.nside, self.lmax = int(nside), int(lmax)
         h = ctypes.c_void_p()
         rp, nr = None, 0
@@ -25,7 +25,9 @@ class ShtPlan:
             self._w = np.ascontiguousarray(wring, dtype=np.float64)
             assert self._w.shape == (2 * nside,)
             wp = self._w.ctypes.data_as(_dp)
-        check(lib().cmdr_sht_plan_create(self.nside, self.lmax, nr, rp, wp, int(max_maps), ctypes.byref(h)))
+        create = lib().cmdr_sht_plan_create_pol if pol else lib().cmdr_sht_plan_create
+        check(create(self.nside, self.lmax, nr, rp, wp, int(max_maps), ctypes.byref(h)))
+        self.pol = bool(pol)
         self._h = h
         self.nalm = lib().cmdr_sht_nalm(h)
         self.npix = lib().cmdr_sht_npix(h)
@@ -72,3 +74,17 @@ class ShtPlan:
 
     def WY(self, alm):
         return self.execute(JOB_WY, alm=alm)
+
+    def execute_spin2(self, job, almE=None, almB=None, mapQ=None, mapU=None):
+        """(Q,U) <-> (E,B), Commander's spin-2 call (comm_map_mod.f90:446-449).  Returns (Q,U) or (E,B)."""
+        synth = job in (JOB_Y, JOB_WY)
+        if synth:
+            e, b = np.ascontiguousarray(almE, dtype=np.float64), np.ascontiguousarray(almB, dtype=np.float64)
+            q, u = np.zeros(self.npix), np.zeros(self.npix)
+        else:
+            q, u = np.ascontiguousarray(mapQ, dtype=np.float64), np.ascontiguousarray(mapU, dtype=np.float64)
+            e, b = np.zeros(self.nalm), np.zeros(self.nalm)
+        assert e.shape == b.shape == (self.nalm,) and q.shape == u.shape == (self.npix,)
+        check(lib().cmdr_sht_execute_spin2(self._h, job, e.ctypes.data_as(_dp), b.ctypes.data_as(_dp),
+                                            q.ctypes.data_as(_dp), u.ctypes.data_as(_dp)))
+        return (q, u) if synth else (e, b)

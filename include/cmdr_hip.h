@@ -53,6 +53,10 @@ int cmdr_memcpy_d2h(void* dst_host, const void* src_dev, size_t nbytes);
  */
 int cmdr_sht_plan_create(int nside, int lmax, int nrings, const int* rings, const double* wring, int max_maps,
                          cmdr_sht_plan** out);
+/* same, with the spin-2 tables for the polarisation columns (comm_mapinfo with pol = .true.,
+ * comm_map_mod.f90:134-137, geom_info_P :279-282) */
+int cmdr_sht_plan_create_pol(int nside, int lmax, int nrings, const int* rings, const double* wring, int max_maps,
+                             cmdr_sht_plan** out);
 int cmdr_sht_plan_destroy(cmdr_sht_plan* plan);
 int64_t cmdr_sht_nalm(const cmdr_sht_plan* plan);   /* sharp_alm_count  (sharp.f90:52-56) */
 int64_t cmdr_sht_npix(const cmdr_sht_plan* plan);   /* sharp_map_size   (sharp.f90:78-82) */
@@ -61,6 +65,11 @@ int64_t cmdr_sht_npix(const cmdr_sht_plan* plan);   /* sharp_map_size   (sharp.f
 int cmdr_sht_execute(cmdr_sht_plan* plan, int job, int nmaps, double* const* alm, double* const* map);
 int cmdr_sht_execute_dev(cmdr_sht_plan* plan, int job, int nmaps, double* alm_dev, int64_t alm_stride,
                          double* map_dev, int64_t map_stride);
+/* The spin-2 call Commander issues on columns 2:3, (Q,U) <-> (E,B) (comm_map_mod.f90:446-449, 519-523, 549-553):
+ * alm = (E, B), map = (Q, U), HEALPix "COSMO" convention a_{+-2,lm} = -(E_lm +- i B_lm).  Needs a _pol plan. */
+int cmdr_sht_execute_spin2(cmdr_sht_plan* plan, int job, double* almE, double* almB, double* mapQ, double* mapU);
+int cmdr_sht_execute_spin2_dev(cmdr_sht_plan* plan, int job, double* almE_dev, double* almB_dev, double* mapQ_dev,
+                               double* mapU_dev);
 
 /* ------------------------------------------------------------------------------------------------
  * CR level: the constrained-realization system of commander3/src/comm_cr_mod.f90 for diffuse components with

@@ -106,6 +106,86 @@ void launch_leg_adj(const LegArgs& A, const WaveTask* tasks, int ntasks, const d
     }
 }
 
+template <int R>
+static void synth2_R(const Leg2Args& A, const WaveTask* tasks, int ntasks, const double* st, int npol, int ip, double* ph,
+                     int64_t ph_stride, int kq) {
+    for (int t = 0; t < ntasks; ++t)
+        for (int lane = 0; lane < 64 && tasks[t].chunk >= 0; ++lane)
+            leg2_synth_lane<R>(A, st, npol, ip, ph, ph_stride, kq, tasks[t].m, tasks[t].chunk, tasks[t].lw, tasks[t].lAend, lane);
+}
+void launch_leg2_synth(const Leg2Args& A, const WaveTask* tasks, int ntasks, const double* st, int npol, double* ph,
+                       int64_t ph_stride, int kq0, hipStream_t) {
+    for (int ip = 0; ip < npol; ++ip) {
+        if (A.R == 1) synth2_R<1>(A, tasks, ntasks, st, npol, ip, ph, ph_stride, kq0 + 2 * ip);
+        else synth2_R<2>(A, tasks, ntasks, st, npol, ip, ph, ph_stride, kq0 + 2 * ip);
+    }
+}
+template <int R>
+static void adj2_R(const Leg2Args& A, const WaveTask* tasks, int ntasks, const double* ph, int64_t ph_stride, int kq,
+                   double* part, int64_t pcs) {
+    const int lmax = A.lmax;
+    for (int ti = 0; ti < ntasks; ++ti) {
+        const WaveTask t = tasks[ti];
+        if (t.chunk < 0) continue;
+        std::vector<Leg2State<R>> S(64);
+        std::vector<Adj2G<R>> G(64);
+        for (int lane = 0; lane < 64; ++lane) {
+            leg2_load_state<R>(A, t.m, t.chunk, lane, S[lane]);
+            leg2_adj_load<R>(A, ph, ph_stride, kq, t.m, t.chunk, lane, G[lane]);
+            for (int r = 0; r < R; ++r)
+                if (S[lane].ls[r] == t.lw) {
+                    S[lane].pc[r] = S[lane].sd[r][0]; S[lane].pp[r] = S[lane].sd[r][1];
+                    S[lane].mc[r] = S[lane].sd[r][2]; S[lane].mp[r] = S[lane].sd[r][3];
+                }
+        }
+        const int64_t mo = d_moffp(lmax, t.m);
+        const double* al = A.alpha + (mo - t.m);
+        const double* be = A.beta + (mo - t.m);
+        double* out = part + t.chunk * pcs + 4 * (mo - t.m);
+        for (int l0 = t.lw; l0 <= lmax; l0 += 4) {
+            double wl[16 * 65];
+            for (int lane = 0; lane < 64; ++lane) {
+                double v[16];
+                if (l0 < t.lAend) leg2_adj_group<R, true>(A, al, be, l0, S[lane], G[lane], v);
+                else leg2_adj_group<R, false>(A, al, be, l0, S[lane], G[lane], v);
+                for (int j = 0; j < 16; ++j) wl[j * 65 + lane] = v[j];
+            }
+            for (int col = 0; col < 16; ++col) {
+                double q[4];
+                for (int qt = 0; qt < 4; ++qt) {
+                    double sacc = 0.0;
+                    for (int i = 0; i < 16; ++i) sacc += wl[col * 65 + qt * 16 + i];
+                    q[qt] = sacc;
+                }
+                const int l = l0 + (col >> 2);
+                if (l <= lmax) out[4 * l + (col & 3)] = (q[0] + q[1]) + (q[2] + q[3]);
+            }
+        }
+    }
+}
+void launch_leg2_adj(const Leg2Args& A, const WaveTask* tasks, int ntasks, const double* ph, int64_t ph_stride,
+                     int kq0, double* part, int64_t part_pol_stride, int64_t pcs, int npol, hipStream_t) {
+    for (int ip = 0; ip < npol; ++ip) {
+        if (A.R == 1) adj2_R<1>(A, tasks, ntasks, ph, ph_stride, kq0 + 2 * ip, part + ip * part_pol_stride, pcs);
+        else adj2_R<2>(A, tasks, ntasks, ph, ph_stride, kq0 + 2 * ip, part + ip * part_pol_stride, pcs);
+    }
+}
+void launch_alm2_to_stream(const double* aE, const double* aB, int64_t pol_stride, double* st, int npol,
+                           const double* cnorm, int lmax, hipStream_t) {
+    for (int ip = 0; ip < npol; ++ip)
+        for (int m = 0; m <= lmax; ++m)
+            for (int l = m; l <= lmax + 1; ++l)
+                alm2_to_stream_elem(aE + ip * pol_stride, aB + ip * pol_stride, st, npol, ip, cnorm, lmax, m, l);
+}
+void launch_part2_to_alm(const double* part, int64_t part_pol_stride, int64_t pcs, int nchunk, double* aE, double* aB,
+                         int64_t pol_stride, const double* cnorm, int lmax, int npol, hipStream_t) {
+    for (int ip = 0; ip < npol; ++ip)
+        for (int m = 0; m <= lmax; ++m)
+            for (int l = m; l <= lmax; ++l)
+                part2_to_alm_elem(part + ip * part_pol_stride, pcs, nchunk, aE + ip * pol_stride, aB + ip * pol_stride,
+                                  cnorm, lmax, m, l);
+}
+
 void launch_ring(int mode, const RingDev* rings, const int* cls, int ncls, int log2M, double* ph,
                  int64_t ph_stride, int64_t npair_pad, double* map, int64_t map_stride, const double* const* mul,
                  int weighted, const cd* tw, int log2Mmax, const cd* chirp, int nmaps, hipStream_t) {

@@ -117,3 +117,28 @@ def test_emul_sigma_l(EL):
     for lmax, nmaps in [(12, 1), (20, 3)]:
         a = rng.standard_normal(((lmax + 1) ** 2, nmaps))
         assert rel(getSigmaL(a, lmax, _lib=EL), cr_oracle.getSigmaL(a, lmax)) < 1e-13
+
+
+@pytest.mark.parametrize("nside,lmax", [(4, 8), (8, 23), (32, 64)])
+def test_emul_sht_spin2_vs_oracle(nside, lmax, EL, oracle_lib):
+    import commander_amd.sht as shtmod
+    from commander_amd.sht import ShtPlan
+    rng = np.random.default_rng(31 + nside)
+    w = 1.0 + 0.05 * rng.standard_normal(2 * nside)
+    old = shtmod.lib
+    shtmod.lib = lambda: EL
+    try:
+        plan = ShtPlan(nside, lmax, wring=w, max_maps=2, pol=True)
+        na, npx = (lmax + 1) ** 2, 12 * nside * nside
+        e, b = rng.standard_normal(na), rng.standard_normal(na)
+        mq, mu = rng.standard_normal(npx), rng.standard_normal(npx)
+        res = [plan.execute_spin2(1, almE=e, almB=b), plan.execute_spin2(3, almE=e, almB=b),
+               plan.execute_spin2(2, mapQ=mq, mapU=mu), plan.execute_spin2(0, mapQ=mq, mapU=mu)]
+        t = plan.Y(e)   # the scalar path of a polarised plan (T column)
+    finally:
+        shtmod.lib = old
+    ref = [oracle_lib.sht_spin2(1, nside, lmax, almE=e, almB=b), oracle_lib.sht_spin2(3, nside, lmax, almE=e, almB=b, wring=w),
+           oracle_lib.sht_spin2(2, nside, lmax, mapQ=mq, mapU=mu), oracle_lib.sht_spin2(0, nside, lmax, mapQ=mq, mapU=mu, wring=w)]
+    for a, r in zip(res, ref):
+        assert rel(np.concatenate(a), np.concatenate(r)) < 1e-12
+    assert rel(t, oracle_lib.Y(nside, lmax, e)) < 1e-12

@@ -63,3 +63,39 @@ def test_sht_ring_subset_matches_full(oracle_lib):
         assert rel(plan.Y(a), ref[idx]) < TOL
         acc += plan.Yt(mfull[idx])
     assert rel(acc, oracle_lib.Yt(nside, lmax, mfull)) < TOL
+
+
+@pytest.mark.parametrize("nside,lmax", [(4, 8), (16, 47), (64, 128), (256, 512)])
+def test_sht_spin2_vs_oracle(nside, lmax, oracle_lib):
+    """(Q,U) <-> (E,B): Commander's polarisation call (comm_map_mod.f90:446-449)."""
+    from commander_amd import ShtPlan
+    rng = np.random.default_rng(77 + nside)
+    w = 1.0 + 0.05 * rng.standard_normal(2 * nside)
+    plan = ShtPlan(nside, lmax, wring=w, max_maps=2, pol=True)
+    na, npx = (lmax + 1) ** 2, 12 * nside * nside
+    e, b = rng.standard_normal(na), rng.standard_normal(na)
+    mq, mu = rng.standard_normal(npx), rng.standard_normal(npx)
+    q, u = plan.execute_spin2(1, almE=e, almB=b)
+    assert rel(np.concatenate([q, u]), np.concatenate(oracle_lib.sht_spin2(1, nside, lmax, almE=e, almB=b))) < TOL
+    ee, bb = plan.execute_spin2(2, mapQ=mq, mapU=mu)
+    assert rel(np.concatenate([ee, bb]), np.concatenate(oracle_lib.sht_spin2(2, nside, lmax, mapQ=mq, mapU=mu))) < TOL
+    ee, bb = plan.execute_spin2(0, mapQ=mq, mapU=mu)
+    assert rel(np.concatenate([ee, bb]), np.concatenate(oracle_lib.sht_spin2(0, nside, lmax, mapQ=mq, mapU=mu, wring=w))) < TOL
+    q, u = plan.execute_spin2(3, almE=e, almB=b)
+    assert rel(np.concatenate([q, u]), np.concatenate(oracle_lib.sht_spin2(3, nside, lmax, almE=e, almB=b, wring=w))) < TOL
+
+
+def test_sht_spin2_adjointness_full_size():
+    from commander_amd import ShtPlan
+    nside, lmax = 1024, 2000
+    rng = np.random.default_rng(8)
+    plan = ShtPlan(nside, lmax, max_maps=2, pol=True)
+    na, npx = (lmax + 1) ** 2, 12 * nside * nside
+    e, b = rng.standard_normal(na), rng.standard_normal(na)
+    e[:2] = 0.0; b[:2] = 0.0   # (l < 2, m = 0)
+    e[lmax + 1:lmax + 3] = 0.0; b[lmax + 1:lmax + 3] = 0.0   # (l = 1, m = +-1)
+    mq, mu = rng.standard_normal(npx), rng.standard_normal(npx)
+    q, u = plan.execute_spin2(1, almE=e, almB=b)
+    ee, bb = plan.execute_spin2(2, mapQ=mq, mapU=mu)
+    lhs, rhs = q @ mq + u @ mu, e @ ee + b @ bb
+    assert abs(lhs - rhs) <= 1e-10 * max(abs(lhs), abs(rhs))
