@@ -119,6 +119,58 @@ CMDR_HD void band_post_elem(const CompDev& C, int c, int ncomp, const double* __
     }
 }
 
+// Polarisation pair ip of a band: (E, B) stream entry from the components' Stokes columns 2 and 3 (0-based 1, 2):
+//   E' = -cnorm2 kappa_m / 2 * sum_c wE[c][l] sx_{c,E}(l,m),  B' likewise (comm_map_mod.f90:446-449 spin-2 call on 2:3)
+CMDR_HD void band_prep2_elem(const CompDev* __restrict__ comps, int ncomp, const double* __restrict__ sx,
+                             const double* __restrict__ wE, const double* __restrict__ wB, double* __restrict__ st,
+                             int npol, int ip, const double* __restrict__ cnorm2, int lmax_g, int m, int l) {
+    const int64_t t = d_moffp(lmax_g, m) + (l - m);
+    double v[4] = {0.0, 0.0, 0.0, 0.0};
+    if (l <= lmax_g && l >= 2) {
+        for (int c = 0; c < ncomp; ++c) {
+            const CompDev C = comps[c];
+            if (l > C.lmax || C.nmaps < 3) continue;
+            const int64_t i = d_packed_index(C.lmax, l, m);
+            const double we = wE[(int64_t)c * (lmax_g + 1) + l], wb = wB[(int64_t)c * (lmax_g + 1) + l];
+            const double* e = sx + C.pos + 1 * C.nalm + i;
+            const double* b = sx + C.pos + 2 * C.nalm + i;
+            v[0] += we * e[0];
+            v[2] += wb * b[0];
+            if (m > 0) { v[1] += we * e[1]; v[3] += wb * b[1]; }
+        }
+        const double f = -0.5 * cnorm2[t] * (m == 0 ? 1.0 : 0.70710678118654752440);
+        for (int k = 0; k < 4; ++k) v[k] *= f;
+    }
+    double* o = st + 4 * (t * npol + ip);
+    o[0] = v[0]; o[1] = v[1]; o[2] = v[2]; o[3] = v[3];
+}
+
+// Transpose of band_prep2_elem: component c, Stokes E and B, accumulated into yc (always +=)
+CMDR_HD void band_post2_elem(const CompDev& C, int c, int ncomp, const double* __restrict__ part2,
+                             int64_t part_pol_stride, int64_t part_chunk_stride, int nchunk, int npol,
+                             const double* __restrict__ w /* [nbm][ncomp][lmax_g+1] */, int nT,
+                             const double* __restrict__ cnorm2, int lmax_g, double* __restrict__ yc, int m, int l) {
+    if (C.nmaps < 3 || !C.active || l > lmax_g || l < 2) return;
+    const int64_t t = d_moffp(lmax_g, m) + (l - m);
+    double s[4] = {0.0, 0.0, 0.0, 0.0};
+    for (int ip = 0; ip < npol; ++ip) {
+        const double we = w[((int64_t)(nT + 2 * ip) * ncomp + c) * (lmax_g + 1) + l];
+        const double wb = w[((int64_t)(nT + 2 * ip + 1) * ncomp + c) * (lmax_g + 1) + l];
+        const double* p = part2 + ip * part_pol_stride + 4 * t;
+        double a[4] = {0.0, 0.0, 0.0, 0.0};
+        for (int ch = 0; ch < nchunk; ++ch)
+            for (int k = 0; k < 4; ++k) a[k] += p[ch * part_chunk_stride + k];
+        s[0] += we * a[0]; s[1] += we * a[1]; s[2] += wb * a[2]; s[3] += wb * a[3];
+    }
+    const double f = -0.5 * cnorm2[t] * (m == 0 ? 1.0 : 1.41421356237309504880);
+    const int64_t i = d_packed_index(C.lmax, l, m);
+    double* e = yc + C.pos + 1 * C.nalm + i;
+    double* b = yc + C.pos + 2 * C.nalm + i;
+    e[0] += s[0] * f;
+    b[0] += s[2] * f;
+    if (m > 0) { e[1] += s[1] * f; b[1] += s[3] * f; }
+}
+
 // Diagonal preconditioner (applyDiffPrecond_diagonal, comm_diffuse_comp_mod.f90:2186-2235): per (l, m, stokes)
 // a dense npre x npre block (same for +m and -m).  P layout: [stokes][k1][k2][ntri(lmax_pre)] (unpadded triangle).
 CMDR_HD int64_t d_moff(int lmax, int m) { return (int64_t)m * (lmax + 1) - (int64_t)m * (m - 1) / 2; }

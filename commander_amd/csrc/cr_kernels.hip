@@ -58,6 +58,38 @@ void launch_band_post(const CompDev* comps, int ncomp, int lmax_max, const doubl
                        cnorm, lmax_g, yc, accumulate ? 1 : 0);
 }
 
+__global__ void k_band_prep2(const CompDev* __restrict__ comps, int ncomp, const double* __restrict__ sx,
+                             const double* __restrict__ w, int nT, double* __restrict__ st, int npol,
+                             const double* __restrict__ cnorm2, int lmax_g) {
+    const int m = blockIdx.y, l = m + blockIdx.x * 256 + threadIdx.x;
+    if (l > lmax_g + 1) return;
+    const int ip = blockIdx.z;
+    const int64_t ws = (int64_t)ncomp * (lmax_g + 1);
+    band_prep2_elem(comps, ncomp, sx, w + (nT + 2 * ip) * ws, w + (nT + 2 * ip + 1) * ws, st, npol, ip, cnorm2, lmax_g,
+                    m, l);
+}
+void launch_band_prep2(const CompDev* comps, int ncomp, const double* sx, const double* w, int nT, double* st, int npol,
+                       const double* cnorm2, int lmax_g, hipStream_t s) {
+    dim3 grid((lmax_g + 2 + 255) / 256, lmax_g + 1, npol);
+    hipLaunchKernelGGL(k_band_prep2, grid, dim3(256), 0, s, comps, ncomp, sx, w, nT, st, npol, cnorm2, lmax_g);
+}
+__global__ void k_band_post2(const CompDev* __restrict__ comps, int ncomp, const double* __restrict__ part2,
+                             int64_t pps, int64_t pcs, int nchunk, int npol, const double* __restrict__ w, int nT,
+                             const double* __restrict__ cnorm2, int lmax_g, double* __restrict__ yc) {
+    const int c = blockIdx.z;
+    const CompDev C = comps[c];
+    const int m = blockIdx.y, l = m + blockIdx.x * 256 + threadIdx.x;
+    if (m > C.lmax || l > C.lmax) return;
+    band_post2_elem(C, c, ncomp, part2, pps, pcs, nchunk, npol, w, nT, cnorm2, lmax_g, yc, m, l);
+}
+void launch_band_post2(const CompDev* comps, int ncomp, int lmax_max, const double* part2, int64_t pps, int64_t pcs,
+                       int nchunk, int npol, const double* w, int nT, const double* cnorm2, int lmax_g, double* yc,
+                       hipStream_t s) {
+    dim3 grid((lmax_max + 1 + 255) / 256, lmax_max + 1, ncomp);
+    hipLaunchKernelGGL(k_band_post2, grid, dim3(256), 0, s, comps, ncomp, part2, pps, pcs, nchunk, npol, w, nT, cnorm2,
+                       lmax_g, yc);
+}
+
 __global__ void k_precond_diag(const CompDev* __restrict__ comps, int ncomp, const double* __restrict__ P,
                                int lmax_pre, int nmaps_pre, const double* __restrict__ in,
                                double* __restrict__ out) {

@@ -184,17 +184,27 @@ void CrSystem::finalize() {
         }
         Group& G = groups_[g];
         B.group = -1;  // assigned after the plan exists (band_npix uses it)
-        B.bm0 = G.nbm;
         G.bands.push_back(b);
-        for (int j = 0; j < B.nmaps; ++j) { G.bm_band.push_back(b); G.bm_stokes.push_back(j); }
-        G.nbm += B.nmaps;
+        CMDR_REQUIRE(B.nmaps == 1 || B.nmaps == 3, "bands must have nmaps = 1 (T) or 3 (T,Q,U)");
+    }
+    for (Group& G : groups_) {   // map order: T of every band, then (Q,U) of every polarised band
+        for (int b : G.bands) { G.bm_band.push_back(b); G.bm_stokes.push_back(0); }
+        G.nT = (int)G.bands.size();
+        for (int b : G.bands)
+            if (bands_[b].nmaps == 3) {
+                G.bm_band.push_back(b); G.bm_stokes.push_back(1);
+                G.bm_band.push_back(b); G.bm_stokes.push_back(2);
+                G.npol += 1;
+            }
+        G.nbm = G.nT + 2 * G.npol;
     }
     for (int g = 0; g < (int)groups_.size(); ++g) {
         Group& G = groups_[g];
         std::vector<int> rings;
         for (auto& rs : ring_sets_) if (rs.first == G.nside) rings = rs.second;
         const Band& B0 = bands_[G.bands[0]];
-        G.plan = std::make_unique<ShtPlan>(G.nside, G.lmax, rings, B0.has_wring ? B0.wring.data() : nullptr, G.nbm);
+        G.plan = std::make_unique<ShtPlan>(G.nside, G.lmax, rings, B0.has_wring ? B0.wring.data() : nullptr, G.nbm,
+                                           G.npol > 0);
         const int64_t np = G.plan->npix_local();
         std::vector<double> w((size_t)G.nbm * ncomp * (G.lmax + 1), 0.0);
         std::vector<const double*> mp(G.nbm);
@@ -237,11 +247,16 @@ void CrSystem::adjoint_groups_to_yc(bool /*from_maps*/) {
         Group& G = groups_[g];
         ShtPlan& P = *G.plan;
         span_begin(2);
-        P.adjoint_to_partials(G.nbm, false, stream_);
+        P.adjoint_to_partials(G.nT, false, stream_);
+        if (G.npol) P.adjoint2_to_partials(G.npol, G.nT, stream_);
         span_end();
         launch_band_post(comps_dev_.get(), ncomp, lmax_max_, P.partials(), P.part_map_stride(), P.leg().tri_elems(),
-                         P.leg().nchunk, G.nbm, G.bm_stokes_dev.get(), G.w.get(), P.leg().cnorm.get(), G.lmax,
+                         P.leg().nchunk, G.nT, G.bm_stokes_dev.get(), G.w.get(), P.leg().cnorm.get(), G.lmax,
                          yc_.get(), g > 0, stream_);
+        if (G.npol)
+            launch_band_post2(comps_dev_.get(), ncomp, lmax_max_, P.partials2(), P.part2_pol_stride(), P.leg2().tri4(),
+                              P.leg2().nchunk, G.npol, G.w.get(), G.nT, P.leg2().cnorm.get(), G.lmax, yc_.get(),
+                              stream_);
     }
     reduce(yc_.get(), ncr_);
 }
@@ -255,9 +270,13 @@ void CrSystem::matmulA(const double* x, double* y) {
     for (Group& G : groups_) {   // per-band loop :843-954, all bands of a geometry batched
         ShtPlan& P = *G.plan;
         launch_band_prep(comps_dev_.get(), ncomp, sx_.get(), G.w.get(), G.bm_stokes_dev.get(), P.stream(),
-                         P.leg().cnorm.get(), G.lmax, G.nbm, stream_);
+                         P.leg().cnorm.get(), G.lmax, G.nT, stream_);
+        if (G.npol)
+            launch_band_prep2(comps_dev_.get(), ncomp, sx_.get(), G.w.get(), G.nT, P.stream2(), G.npol,
+                              P.leg2().cnorm.get(), G.lmax, stream_);
         span_begin(0);
-        P.synth_from_stream(G.nbm, stream_);                                         // Y        :891
+        P.synth_from_stream(G.nT, stream_);                                          // Y        :891 (T: spin 0)
+        if (G.npol) P.synth2_from_stream(G.npol, G.nT, stream_);                     // (Q,U): spin 2, comm_map_mod.f90:446
         span_end();
         span_begin(1);
         P.rings(2, nullptr, 0, G.mul_ptrs.get(), false, G.nbm, stream_);             // N^-1 :905 fused with both FFTs

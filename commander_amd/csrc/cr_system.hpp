@@ -88,6 +88,7 @@ class CrSystem {
     };
     struct Group {
         int nside, lmax, nbm = 0;
+        int nT = 0, npol = 0;              // maps ordered [T of every band][(Q,U) of every polarised band]
         std::vector<int> bands, bm_band, bm_stokes;
         std::unique_ptr<ShtPlan> plan;
         DevBuf<double> w;                   // [nbm][ncomp][lmax+1]

@@ -46,6 +46,11 @@ void launch_band_prep(const CompDev* comps, int ncomp, const double* sx, const d
 void launch_band_post(const CompDev* comps, int ncomp, int lmax_max, const double* part, int64_t pms, int64_t pcs,
                       int nchunk, int nbm, const int* bm_stokes, const double* w, const double* cnorm, int lmax_g,
                       double* yc, bool accumulate, hipStream_t s);
+void launch_band_prep2(const CompDev* comps, int ncomp, const double* sx, const double* w, int nT, double* st, int npol,
+                       const double* cnorm2, int lmax_g, hipStream_t s);
+void launch_band_post2(const CompDev* comps, int ncomp, int lmax_max, const double* part2, int64_t pps, int64_t pcs,
+                       int nchunk, int npol, const double* w, int nT, const double* cnorm2, int lmax_g, double* yc,
+                       hipStream_t s);
 void launch_precond_diag(const CompDev* comps, int ncomp, const double* P, int lmax_pre, int nmaps_pre,
                          const double* in, double* out, hipStream_t s);
 void launch_fill_gl(double* ph, const double* wn, const double* ws, int npair_pad, int lmax, hipStream_t s);

@@ -44,7 +44,7 @@ struct LegendreTables {
 
 // Spin-2 Legendre tables: the two spin-weighted chains (+2, -2) share alpha / cnorm and differ by the sign of beta:
 //   mu+-_{l+1} = (alpha_{l+1} x +- beta_{l+1}) mu+-_l - mu+-_{l-1},   (+-2)lambda_lm = cnorm_l mu+-_l,   l >= l0 = max(m, 2)
-// from (pinned against the Goldberg closed form, oracle/bruteforce.py):
+// from (pinned in the tests against the Goldberg closed form of the spin-weighted harmonics):
 //   s_lam_{l+1} = [(x + s m/(l(l+1))) s_lam_l - C_l s_lam_{l-1}] / C_{l+1},  C_l = sqrt((l^2-m^2)(l^2-4)/(l^2(4l^2-1)))
 struct Legendre2Tables {
     int lmax = -1, npair_pad = 0, R = 2, nchunk = 0;

@@ -20,7 +20,7 @@ struct sharp_geom_info {
     std::vector<int> north;          // northern ring numbers owned (mirror implied)
     std::vector<double> weight;      // [2*nside] or empty
     ptrdiff_t npix;
-    mutable std::map<int, cmdr_sht_plan*> plans;  // by lmax
+    mutable std::map<int, cmdr_sht_plan*> plans;  // by 2 * lmax + pol
 };
 
 namespace {
@@ -88,23 +88,32 @@ void sharp_destroy_geom_info(sharp_geom_info* info) {
 
 void sharp_execute(int type, int spin, void* alm, void* map, const sharp_geom_info* g, const sharp_alm_info* a,
                    int flags, double* time, unsigned long long* opcnt) {
-    if (spin != 0) die("spin != 0 is not implemented yet (spin-2 kernels: next round)");
+    if (spin != 0 && spin != 2) die("only spin 0 and spin 2 are supported (what Commander issues)");
     if (!(flags & SHARP_DP)) die("single precision is not supported (Commander always sets SHARP_DP)");
     if (flags & SHARP_ADD) die("SHARP_ADD is not supported (never set by Commander)");
     if (type < SHARP_YtW || type > SHARP_WY) die("unsupported job type");
     if ((int)a->ms.size() != a->lmax + 1) die("every m must be local: use one MPI rank per chain/GPU");
     for (int i = 0; i <= a->lmax; ++i) if (a->ms[i] != i) die("ms must be 0..lmax in order");
-    auto it = g->plans.find(a->lmax);
+    const int key = 2 * a->lmax + (spin == 2 ? 1 : 0);
+    auto it = g->plans.find(key);
     if (it == g->plans.end()) {
         cmdr_sht_plan* p = nullptr;
-        if (cmdr_sht_plan_create(g->nside, a->lmax, (int)g->north.size(), g->north.data(),
-                                 g->weight.empty() ? nullptr : g->weight.data(), 1, &p) != 0)
-            die(cmdr_last_error());
-        it = g->plans.emplace(a->lmax, p).first;
+        const int rc = spin == 2 ? cmdr_sht_plan_create_pol(g->nside, a->lmax, (int)g->north.size(), g->north.data(),
+                                                            g->weight.empty() ? nullptr : g->weight.data(), 2, &p)
+                                 : cmdr_sht_plan_create(g->nside, a->lmax, (int)g->north.size(), g->north.data(),
+                                                        g->weight.empty() ? nullptr : g->weight.data(), 1, &p);
+        if (rc != 0) die(cmdr_last_error());
+        it = g->plans.emplace(key, p).first;
     }
     const auto t0 = std::chrono::steady_clock::now();
-    if (cmdr_sht_execute(it->second, type, 1, static_cast<double* const*>(alm), static_cast<double* const*>(map)) != 0)
+    if (spin == 2) {   // alm = (E, B), map = (Q, U): sharp.f90:203-224 with nmaps = 2
+        double* const* pa = static_cast<double* const*>(alm);
+        double* const* pm = static_cast<double* const*>(map);
+        if (cmdr_sht_execute_spin2(it->second, type, pa[0], pa[1], pm[0], pm[1]) != 0) die(cmdr_last_error());
+    } else if (cmdr_sht_execute(it->second, type, 1, static_cast<double* const*>(alm),
+                                static_cast<double* const*>(map)) != 0) {
         die(cmdr_last_error());
+    }
     if (time) *time = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
     if (opcnt) *opcnt = 0;
 }

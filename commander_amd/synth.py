@@ -48,7 +48,7 @@ def comp_Dl(name, lmax):
     return D
 
 
-def make_problem(cfg, nside=None, lmax=None, comp_lmax=None, pixels=None):
+def make_problem(cfg, nside=None, lmax=None, comp_lmax=None, pixels=None, pol=False):
     """Problem spec dict consumed by ``commander_amd.cr.build_context`` (and by the tests' oracle builder).
 
     pixels: optional full-sky RING indices of a rank's local map (ring sharding); maps are then local."""
@@ -72,17 +72,27 @@ def make_problem(cfg, nside=None, lmax=None, comp_lmax=None, pixels=None):
         siN[np.abs(z) < np.sin(np.radians(12.0))] = 0.0
         if pixels is not None:
             siN = siN[pixels]
+        if pol:   # T, Q, U: polarisation noise sqrt(2) higher, same beam (read_beam default, comm_utils.f90:103-107)
+            siN = np.stack([siN, siN / np.sqrt(2.0), siN / np.sqrt(2.0)], axis=1)
+            b_l = np.stack([b_l, b_l, b_l], axis=1)
         bands.append(dict(nside=nside, lmax=lmax, nu=nu, fwhm=fwhm, siN=siN, b_l=b_l, mb_eff=1.0, sigma0=sigma0))
     comps = []
     for k, name in enumerate(c["comps"]):
         cl_lmax = lmax if comp_lmax is None else int(comp_lmax[k])
-        sq, isq, S = _cl.update_S(comp_Dl(name, cl_lmax)[:, None], 1)
+        nm = 3 if pol else 1
+        Dl = comp_Dl(name, cl_lmax)[:, None]
+        if pol:   # (TT, TE, TB, EE, EB, BB): EE = 1e-3 TT, BB = 1e-4 TT for l >= 2, a small TE to exercise the 3x3 roots
+            lv = np.arange(cl_lmax + 1)
+            pm = (lv >= 2).astype(np.float64)          # Dl(0:1, 2:) = 0 (comm_Cl_mod.f90:217)
+            tt = Dl[:, 0]
+            Dl = np.stack([tt, 0.01 * tt * pm, 0.0 * tt, 1e-3 * tt * pm, 0.0 * tt, 1e-4 * tt * pm], axis=1)
+        sq, isq, S = _cl.update_S(Dl, nm)
         if name == "cmb":
-            F = np.ones(len(bands))
+            F = np.ones((len(bands), nm))
         else:
-            F = np.array([(b["nu"] / 30.0) ** -3.1 for b in bands])
-        comps.append(dict(name=name, lmax=cl_lmax, nmaps=1, F_mean=F, sqrtS_mat=sq, sqrtInvS_mat=isq, S_mat=S,
-                          Dl=comp_Dl(name, cl_lmax), active=True))
+            F = np.repeat(np.array([(b["nu"] / 30.0) ** -3.1 for b in bands])[:, None], nm, axis=1)
+        comps.append(dict(name=name, lmax=cl_lmax, nmaps=nm, F_mean=F, sqrtS_mat=sq, sqrtInvS_mat=isq, S_mat=S,
+                          Dl=Dl if pol else Dl[:, 0], active=True))
     return dict(bands=bands, comps=comps, nside=nside, lmax=lmax, pixels=pixels)
 
 
@@ -103,6 +113,10 @@ def draw_inputs(spec):
         rms = b["sigma0"] * (1.0 + 0.5 * z)
         d = rms * g
         x = rng(2, i).standard_normal(npix)
+        nm = np.ndim(b["siN"]) > 1 and b["siN"].shape[1] or 1
+        if nm > 1:
+            d = np.stack([d] + [np.sqrt(2.0) * rms * rng(4 + j, i).standard_normal(npix) for j in range(1, nm)], axis=1)
+            x = np.stack([x] + [rng(6 + j, i).standard_normal(npix) for j in range(1, nm)], axis=1)
         if pix is not None:
             d, x = d[pix], x[pix]
         resid.append(d)

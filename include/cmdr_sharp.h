@@ -5,7 +5,8 @@
  * Supported subset = exactly what Commander issues on this path: real-packed m-major a_lm
  * (sharp_make_mmajor_real_packed_alm_info, sharp.f90:44-50,128), HEALPix ring subsets with optional ring weights
  * (sharp_make_subset_healpix_geom_info, sharp.f90:64-71,158), double precision (SHARP_DP always set, sharp.f90:206),
- * job types YtW/Y/Yt/WY (sharp.f90:8-14), one column per call (sharp.f90:211-216), spin 0.  SHARP_ADD is never set by
+ * job types YtW/Y/Yt/WY (sharp.f90:8-14), one transform per call (sharp.f90:211-216), spin 0 (one column) and
+ * spin 2 (alm = E,B ; map = Q,U ; comm_map_mod.f90:446-449).  SHARP_ADD is never set by
  * any caller and is rejected.  Like libsharp2 the functions return void; on an unsupported request or a HIP failure
  * they print the reason and abort() -- libsharp2's own convention ("library aborts internally").
  *

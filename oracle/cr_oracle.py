@@ -213,10 +213,18 @@ class CRSystem:
     # ---- SHT on (n, nmaps) column blocks; polarised (spin-2) columns are a later round
     @staticmethod
     def _Y(band, alm, lmax):
+        """exec_sharp_Y (comm_map_mod.f90:437-455): info%pol (nmaps == 3) -> T spin 0 + (Q,U) one spin-2 call."""
+        if alm.shape[1] == 3:
+            q, u = sht.sht_spin2(sht.JOB_Y, band.nside, lmax, almE=alm[:, 1], almB=alm[:, 2])
+            return np.stack([sht.Y(band.nside, lmax, alm[:, 0]), q, u], axis=1)
         return np.stack([sht.Y(band.nside, lmax, alm[:, j]) for j in range(alm.shape[1])], axis=1)
 
     @staticmethod
     def _Yt(band, m, lmax):
+        """exec_sharp_Yt (comm_map_mod.f90:511-529)."""
+        if m.shape[1] == 3:
+            e, b = sht.sht_spin2(sht.JOB_Yt, band.nside, lmax, mapQ=m[:, 1], mapU=m[:, 2])
+            return np.stack([sht.Yt(band.nside, lmax, m[:, 0]), e, b], axis=1)
         return np.stack([sht.Yt(band.nside, lmax, m[:, j]) for j in range(m.shape[1])], axis=1)
 
     def _lmax_all(self):

@@ -131,3 +131,22 @@ def test_sigma_l_gpu():
     for lmax, nmaps in [(300, 1), (257, 3)]:
         a = rng.standard_normal(((lmax + 1) ** 2, nmaps))
         assert rel(getSigmaL(a, lmax), cr_oracle.getSigmaL(a, lmax)) < 1e-12
+
+
+def test_polarised_cr_path_gpu():
+    """T,Q,U: 3 bands, CMB+synch with 3x3 S (TE != 0), Nside=64, lmax=128."""
+    from commander_amd import synth
+    from commander_amd.cr import build_context
+    spec = synth.make_problem("cfg2", nside=64, lmax=128, comp_lmax=[128, 96], pol=True)
+    S = oracle_system(spec)
+    ctx = build_context(spec)
+    x = np.random.default_rng(21).standard_normal(ctx.ncr)
+    assert rel(ctx.cr_matmulA(x), S.matmulA(x)) < 1e-11
+    ctx.initPrecond(); ctx.update_precond(); S.init_precond_diag(); S.update_precond_diag()
+    assert rel(ctx.cr_invM(x), S.invM(x)) < 1e-11
+    resid, xi, eta = synth.draw_inputs(spec)
+    rhso = S.computeRHS(resid, "sample", xi, eta)
+    assert rel(ctx.cr_computeRHS("sample", resid, xi, eta), rhso) < 1e-11
+    xs, n, st, res = ctx.solve_cr_eqn_by_CG(rhso, "fixed_iter", 1e-8, 5, 20, 1)
+    xo, no, so = S.solve(rhso, "fixed_iter", 1e-8, 5, 20, 1)
+    assert n == no == 20 and rel(xs, xo) < 1e-8

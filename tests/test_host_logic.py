@@ -142,3 +142,23 @@ def test_emul_sht_spin2_vs_oracle(nside, lmax, EL, oracle_lib):
     for a, r in zip(res, ref):
         assert rel(np.concatenate(a), np.concatenate(r)) < 1e-12
     assert rel(t, oracle_lib.Y(nside, lmax, e)) < 1e-12
+
+
+def test_emul_polarised_cr_path_vs_oracle(EL):
+    """T,Q,U bands and components (3x3 S with a TE term): T through spin 0, (Q,U) through one spin-2 call."""
+    from commander_amd import synth
+    from commander_amd.cr import build_context
+    spec = synth.make_problem("cfg2", nside=16, lmax=32, comp_lmax=[32, 24], pol=True)
+    S = oracle_system(spec)
+    ctx = build_context(spec, _lib=EL)
+    assert ctx.ncr == S.ncr == 3 * (33 ** 2 + 25 ** 2)
+    x = np.random.default_rng(0).standard_normal(ctx.ncr)
+    assert rel(ctx.cr_matmulA(x), S.matmulA(x)) < 1e-12
+    ctx.initPrecond(); ctx.update_precond(); S.init_precond_diag(); S.update_precond_diag()
+    assert rel(ctx.cr_invM(x), S.invM(x)) < 1e-12
+    resid, xi, eta = synth.draw_inputs(spec)
+    rhso = S.computeRHS(resid, "sample", xi, eta)
+    assert rel(ctx.cr_computeRHS("sample", resid, xi, eta), rhso) < 1e-12
+    xs, n, st, res = ctx.solve_cr_eqn_by_CG(rhso, "fixed_iter", 1e-8, 5, 12, 1)
+    xo, no, so = S.solve(rhso, "fixed_iter", 1e-8, 5, 12, 1)
+    assert n == no and rel(xs, xo) < 1e-10

@@ -49,6 +49,14 @@ def run_sharp(L, oracle_lib, nside, lmax, P=1, rank=0):
         pm = (dp * 1)(m2.ctypes.data_as(dp))
         L.sharp_execute_mpi_fortran(0, 0, 0, pa, pm, ginfo, ainfo, SHARP_DP, None, None)            # SHARP_YtW
         assert rel(out, oracle_lib.YtW(nside, lmax, m2, wring=w)) < 1e-11
+        # spin 2: alm = (E, B), map = (Q, U)  (comm_map_mod.f90:446-449)
+        e, b = rng.standard_normal((lmax + 1) ** 2), rng.standard_normal((lmax + 1) ** 2)
+        q, u = np.zeros(idx.size), np.zeros(idx.size)
+        pa = (dp * 2)(e.ctypes.data_as(dp), b.ctypes.data_as(dp))
+        pm = (dp * 2)(q.ctypes.data_as(dp), u.ctypes.data_as(dp))
+        L.sharp_execute_mpi_fortran(0, 1, 2, pa, pm, ginfo, ainfo, SHARP_DP, None, None)
+        qo, uo = oracle_lib.sht_spin2(1, nside, lmax, almE=e, almB=b)
+        assert rel(np.concatenate([q, u]), np.concatenate([qo, uo])) < 1e-11
     L.sharp_destroy_alm_info(ainfo)
     L.sharp_destroy_geom_info(ginfo)
 
