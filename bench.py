@@ -74,6 +74,44 @@ def cpu_baseline(spec, nthreads):
                       "extrapolated x %.1f pairs per solve" % (reps, nside, lmax, t_pair, pairs_per_solve)}
 
 
+def sht_pairs(L, nside, lmax, reps=10):
+    import ctypes as C
+    from commander_amd.lib import check
+    res = {}
+    for pol in (False, True):
+        h = C.c_void_p()
+        create = L.cmdr_sht_plan_create_pol if pol else L.cmdr_sht_plan_create
+        check(create(nside, lmax, 0, None, None, 2 if pol else 1, C.byref(h)), L)
+        na, npx = L.cmdr_sht_nalm(h), L.cmdr_sht_npix(h)
+        bufs = []
+        for n in (na, na, npx, npx):
+            p = C.c_void_p()
+            check(L.cmdr_dev_alloc(n * 8, C.byref(p)), L)
+            a = np.random.default_rng(n).standard_normal(n)
+            check(L.cmdr_memcpy_h2d(p, a.ctypes.data_as(C.c_void_p), a.nbytes), L)
+            bufs.append(p)
+        dE, dB, dQ, dU = bufs
+
+        def pair():
+            if pol:
+                check(L.cmdr_sht_execute_spin2_dev(h, 2, dE, dB, dQ, dU), L)   # Yt
+                check(L.cmdr_sht_execute_spin2_dev(h, 1, dE, dB, dQ, dU), L)   # Y
+            else:
+                check(L.cmdr_sht_execute_dev(h, 2, 1, dE, na, dQ, npx), L)
+                check(L.cmdr_sht_execute_dev(h, 1, 1, dE, na, dQ, npx), L)
+        pair()
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            pair()
+        dt = (time.perf_counter() - t0) / reps
+        res["spin2_QU" if pol else "spin0"] = 1.0 / dt
+        for p in bufs:
+            L.cmdr_dev_free(p)
+        L.cmdr_sht_plan_destroy(h)
+    res["geometry"] = "Nside=%d lmax=%d" % (nside, lmax)
+    return res
+
+
 def main():
     args = parse()
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -184,6 +222,12 @@ def main():
                                 "leg_adjoint": ms[2] / max(int(cnt[2]), 1), "matvec": ms[3] / max(int(cnt[3]), 1)}},
             "solve": {"niter": niter, "stat": stat, "res": res[0], "delta0": res[1]},
         }
+        # second half of the headline metric: SHT pairs/s/GPU, the unit of commander3/src/sharp_test.f90:65-71
+        # (one Yt followed by one Y), scalar and polarised, at the benchmark geometry, data resident in HBM
+        try:
+            out["sht_pairs_per_sec_per_gpu"] = sht_pairs(L, nside, lmax) if world == 1 else None
+        except Exception as e:
+            out["sht_pairs_per_sec_per_gpu"] = {"error": repr(e)}
         if world == 1 and not args.no_cpu_baseline:
             try:
                 out["cpu_baseline"] = cpu_baseline(spec, min(os.cpu_count() or 1, 16))
