@@ -74,11 +74,11 @@ def cpu_baseline(spec, nthreads):
                       "extrapolated x %.1f pairs per solve" % (reps, nside, lmax, t_pair, pairs_per_solve)}
 
 
-def sht_pairs(L, nside, lmax, reps=10):
+def sht_pairs(L, nside, lmax, reps=10, pols=(False, True)):
     import ctypes as C
     from commander_amd.lib import check
     res = {}
-    for pol in (False, True):
+    for pol in pols:
         h = C.c_void_p()
         create = L.cmdr_sht_plan_create_pol if pol else L.cmdr_sht_plan_create
         check(create(nside, lmax, 0, None, None, 2 if pol else 1, C.byref(h)), L)
@@ -226,6 +226,8 @@ def main():
         # (one Yt followed by one Y), scalar and polarised, at the benchmark geometry, data resident in HBM
         try:
             out["sht_pairs_per_sec_per_gpu"] = sht_pairs(L, nside, lmax) if world == 1 else None
+            if world == 1:   # the reference's own SHT benchmark geometry, commander3/src/sharp_test.f90:31-33
+                out["sht_pairs_per_sec_per_gpu"]["sharp_test"] = sht_pairs(L, 2048, 3 * 2048, reps=5, pols=(False,))
         except Exception as e:
             out["sht_pairs_per_sec_per_gpu"] = {"error": repr(e)}
         if world == 1 and not args.no_cpu_baseline:

@@ -275,62 +275,23 @@ __global__ void __launch_bounds__(1024) k_ring(const RingDev* __restrict__ rings
                                               double* __restrict__ map, int64_t map_stride,
                                               const double* const* __restrict__ mul, int weighted,
                                               const cd* __restrict__ tw, int log2Mmax,
-                                              const cd* __restrict__ chirp) {
+                                              const cd* __restrict__ chirp, cd* __restrict__ scratch,
+                                              int64_t scratch_map_stride, int scratch_line) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     cd* buf = reinterpret_cast<cd*>(smem);
     const int pair = cls[blockIdx.x];
     const int imap = blockIdx.y;
     const RingDev d = rings[pair];
     const FftCtx c{(int)threadIdx.x, (int)blockDim.x};
-    double* php = ph + imap * ph_stride;
-    double* mp = map ? map + imap * map_stride : nullptr;
-    const double* mu = mul ? mul[imap] : nullptr;
-    const int n = d.nphi;
-    const double wg = weighted ? d.wgt : 1.0;
-    if (MODE == 0 || MODE == 2) {
-        ring_synth_lds(buf, d, php, npair_pad, pair, tw, log2Mmax, chirp, c);
-        // (every exit path of ring_synth_lds ends with a barrier)
-    }
-    if (MODE == 0) {
-        for (int k = c.tid; k < n; k += c.nthr) {
-            const cd v = buf[lds_pad(k)];
-            const double fn = wg * (mu ? mu[d.startN + k] : 1.0);
-            mp[d.startN + k] = v.x * fn;
-            if (d.startS >= 0) {
-                const double fs = wg * (mu ? mu[d.startS + k] : 1.0);
-                mp[d.startS + k] = v.y * fs;
-            }
-        }
-        return;
-    }
-    if (MODE == 1) {
-        for (int k = c.tid; k < n; k += c.nthr) {
-            const double fn = wg * (mu ? mu[d.startN + k] : 1.0);
-            cd v = {mp[d.startN + k] * fn, 0.0};
-            if (d.startS >= 0) {
-                const double fs = wg * (mu ? mu[d.startS + k] : 1.0);
-                v.y = mp[d.startS + k] * fs;
-            }
-            buf[lds_pad(k)] = v;
-        }
-        __syncthreads();
-    }
-    if (MODE == 2) {
-        for (int k = c.tid; k < n; k += c.nthr) {
-            cd v = buf[lds_pad(k)];
-            v.x *= mu[d.startN + k];
-            v.y = d.startS >= 0 ? v.y * mu[d.startS + k] : 0.0;
-            buf[lds_pad(k)] = v;
-        }
-        __syncthreads();
-    }
-    ring_anal_lds(buf, d, tw, log2Mmax, chirp, c);
-    ring_store_phases(buf, d, php, npair_pad, pair, chirp, c);
+    cd* sc = d.split ? scratch + imap * scratch_map_stride + (int64_t)(d.split - 1) * scratch_line : nullptr;
+    ring_block<MODE>(buf, d, pair, ph + imap * ph_stride, npair_pad, map ? map + imap * map_stride : nullptr,
+                     mul ? mul[imap] : nullptr, weighted ? d.wgt : 1.0, tw, log2Mmax, chirp, sc, c);
 }
 
 void launch_ring(int mode, const RingDev* rings, const int* cls, int ncls, int log2M, double* ph,
                  int64_t ph_stride, int64_t npair_pad, double* map, int64_t map_stride, const double* const* mul,
-                 int weighted, const cd* tw, int log2Mmax, const cd* chirp, int nmaps, hipStream_t s) {
+                 int weighted, const cd* tw, int log2Mmax, const cd* chirp, cd* scratch, int64_t scratch_map_stride,
+                 int scratch_line, int nmaps, hipStream_t s) {
     if (ncls == 0 || nmaps == 0) return;
     const size_t lds = sizeof(cd) * (size_t)lds_elems(log2M);
     int nthr = 512;   // measured: 512 > 256 threads per ring pair (more waves to cover LDS / global latency)
@@ -346,7 +307,8 @@ void launch_ring(int mode, const RingDev* rings, const int* cls, int ncls, int l
             attr_set = true;                                                                                     \
         }                                                                                                        \
         hipLaunchKernelGGL(k_ring<MM>, grid, dim3(nthr), lds, s, rings, cls, ph, ph_stride, npair_pad, map,      \
-                           map_stride, mul, weighted, tw, log2Mmax, chirp);                                      \
+                           map_stride, mul, weighted, tw, log2Mmax, chirp, scratch, scratch_map_stride,          \
+                           scratch_line);                                                                        \
     } while (0)
     if (mode == 0) CMDR_RING(0);
     else if (mode == 1) CMDR_RING(1);

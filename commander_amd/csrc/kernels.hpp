@@ -20,7 +20,8 @@ void launch_leg_adj(const LegArgs& A, const WaveTask* tasks, int ntasks, const d
 // mode 0: phases->map, 1: map->phases, 2: phases -> *mul -> phases (in place)
 void launch_ring(int mode, const RingDev* rings, const int* cls, int ncls, int log2M, double* ph,
                  int64_t ph_stride, int64_t npair_pad, double* map, int64_t map_stride, const double* const* mul,
-                 int weighted, const cd* tw, int log2Mmax, const cd* chirp, int nmaps, hipStream_t s);
+                 int weighted, const cd* tw, int log2Mmax, const cd* chirp, cd* scratch, int64_t scratch_map_stride,
+                 int scratch_line, int nmaps, hipStream_t s);
 void launch_alm_to_stream(const double* alm, int64_t alm_stride, double* ast, const double* cnorm, int lmax,
                           int nmaps, hipStream_t s);
 void launch_part_to_alm(const double* part, int64_t pms, int64_t pcs, int nchunk, double* alm, int64_t alm_stride,

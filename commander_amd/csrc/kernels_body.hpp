@@ -568,8 +568,9 @@ struct RingDev {  // device mirror of RingPairDesc
     int nphi, log2M, bluestein, mmax_eff;
     long long startN, startS;
     double phi0, wgt;
-    long long chirp_off;   // per-length table: rot[n] (, w[n], chat[M] for Bluestein)
-    int ring, pad;
+    long long chirp_off;   // per-length table: rot[n] (, w[nt], chat[M] for Bluestein; nt = n or n/2 if split)
+    int ring;
+    int split;             // 0, or 1 + index of this pair's scratch line (ring transformed as two half-length pieces)
 };
 
 // HEALPix rings have n*phi0 = pi (phi0 = pi/(4i), n = 4i; belt: pi/(4N), n = 4N) or phi0 = 0, hence
@@ -637,103 +638,119 @@ CMDR_HD void ring_scatter(cd* buf, const RingDev& d, const double* __restrict__ 
     CMDR_BLOCK_SYNC();
 }
 
+// One length-n DFT inside the LDS image: n a power of two (log2M = log2 n) or Bluestein (M >= 2n-1) with the chirp
+// w_j = e^{i pi j^2/n} (j < n) and chat = bit-reversed FFT_M^- of the conjugate chirp.
+struct FftSub {
+    int n, log2M, bluestein;
+    const cd* w;
+    const cd* chat;
+};
+
+// Where / in which form the inverse transform wants spectrum slot j:
+//   power of two: value at the bit-reversed position; Bluestein: conj(value * w_j) at the natural position
+//   (positions n..M-1 must hold zeros).
+CMDR_HD void idft_put(cd* buf, const FftSub& f, int j, cd v) {
+    if (f.bluestein) buf[lds_pad(j)] = cconj(cmul(v, f.w[j]));
+    else buf[lds_pad(d_bitrev(j, f.log2M))] = v;
+}
+
+// Inverse DFT y_k = sum_j Z_j e^{+2 pi i jk/n} of slots placed with idft_put(); result in buf[lds_pad(k)], k < n.
+CMDR_HD void idft_core(cd* buf, const FftSub& f, const cd* __restrict__ tw, int log2Mmax, FftCtx c) {
+    if (!f.bluestein) {
+        fft_dit_plus(buf, f.log2M, tw, log2Mmax, c);
+        return;
+    }
+    // a_j = Z_j w_j ; F^-(a) = conj(F^+(conj a))
+    const int M = 1 << f.log2M;
+    fft_dif_plus(buf, f.log2M, tw, log2Mmax, c);
+    for (int p = c.tid; p < M; p += c.nthr) buf[lds_pad(p)] = cmul(cconj(buf[lds_pad(p)]), f.chat[p]);
+    CMDR_BLOCK_SYNC();
+    fft_dit_plus(buf, f.log2M, tw, log2Mmax, c);
+    const double inv = 1.0 / (double)M;
+    for (int k = c.tid; k < f.n; k += c.nthr) {
+        const cd v = cmul(buf[lds_pad(k)], f.w[k]);
+        buf[lds_pad(k)] = {v.x * inv, v.y * inv};
+    }
+    CMDR_BLOCK_SYNC();
+}
+
+// Forward DFT Z_j = sum_k z_k e^{-2 pi i jk/n} of z_k = buf[lds_pad(k)], k < n; read the result with dft_at().
+CMDR_HD void dft_core(cd* buf, const FftSub& f, const cd* __restrict__ tw, int log2Mmax, FftCtx c) {
+    const int n = f.n, M = 1 << f.log2M;
+    if (!f.bluestein) {
+        // Z = conj(F^+(conj z)); DIF leaves it bit-reversed
+        for (int k = c.tid; k < n; k += c.nthr) buf[lds_pad(k)] = cconj(buf[lds_pad(k)]);
+        CMDR_BLOCK_SYNC();
+        fft_dif_plus(buf, f.log2M, tw, log2Mmax, c);
+    } else {
+        // conj(Z)_j = w_j sum_k (conj(z_k) w_k) conj(w_{j-k})  (same chirp machinery)
+        for (int k = c.tid; k < M; k += c.nthr) {
+            cd v = {0.0, 0.0};
+            if (k < n) v = cconj(cmul(cconj(buf[lds_pad(k)]), f.w[k]));   // conj(a_k), a_k = conj(z_k) w_k
+            buf[lds_pad(k)] = v;
+        }
+        CMDR_BLOCK_SYNC();
+        fft_dif_plus(buf, f.log2M, tw, log2Mmax, c);
+        for (int p = c.tid; p < M; p += c.nthr) buf[lds_pad(p)] = cmul(cconj(buf[lds_pad(p)]), f.chat[p]);
+        CMDR_BLOCK_SYNC();
+        fft_dit_plus(buf, f.log2M, tw, log2Mmax, c);
+        const double inv = 1.0 / (double)M;
+        for (int j = c.tid; j < n; j += c.nthr) {
+            const cd v = cmul(buf[lds_pad(j)], f.w[j]);      // conj(Z_j) * M
+            buf[lds_pad(j)] = {v.x * inv, -v.y * inv};       // Z_j, natural order
+        }
+        CMDR_BLOCK_SYNC();
+    }
+}
+
+CMDR_HD cd dft_at(const cd* buf, const FftSub& f, int j) {
+    if (!f.bluestein) return cconj(buf[lds_pad(d_bitrev(j, f.log2M))]);
+    return buf[lds_pad(j)];
+}
+
+CMDR_HD FftSub ring_fft_desc(const RingDev& d, const cd* __restrict__ chirp) {
+    // per-length table: rot[n], then for the transform length nt (= n, or n/2 for split rings): w[nt], chat[M]
+    const cd* w = chirp + d.chirp_off + d.nphi;
+    const int nt = d.split ? d.nphi / 2 : d.nphi;
+    return FftSub{nt, d.log2M, d.bluestein, w, w + nt};
+}
+
 // Full inverse (synthesis) ring transform in LDS: on return buf[lds_pad(k)], k<n holds y^N_k + i y^S_k.
 CMDR_HD void ring_synth_lds(cd* buf, const RingDev& d, const double* __restrict__ ph, int64_t npair_pad, int pair,
                             const cd* __restrict__ tw, int log2Mmax, const cd* __restrict__ chirp, FftCtx c) {
     const int n = d.nphi, M = 1 << d.log2M;
     const bool flip = d.phi0 != 0.0;
     const cd* rot = chirp + d.chirp_off;   // rot_j, j < n
-    const bool noalias = n > 2 * d.mmax_eff;
-    if (!d.bluestein) {
-        if (noalias) {
-            ring_scatter<false>(buf, d, ph, npair_pad, pair, rot, nullptr, c);
-        } else {
-            for (int j = c.tid; j < n; j += c.nthr) {
+    const FftSub f = ring_fft_desc(d, chirp);
+    if (n > 2 * d.mmax_eff) {
+        if (d.bluestein) ring_scatter<true>(buf, d, ph, npair_pad, pair, rot, f.w, c);
+        else ring_scatter<false>(buf, d, ph, npair_pad, pair, rot, nullptr, c);
+    } else {
+        for (int j = c.tid; j < (d.bluestein ? M : n); j += c.nthr) {
+            if (j < n) {
                 const cd r = flip ? rot[j] : cd{1.0, 0.0};
-                buf[lds_pad(d_bitrev(j, d.log2M))] = ring_gather_slot(ph, npair_pad, pair, n, d.mmax_eff, r, flip, j);
+                idft_put(buf, f, j, ring_gather_slot(ph, npair_pad, pair, n, d.mmax_eff, r, flip, j));
+            } else {
+                buf[lds_pad(j)] = {0.0, 0.0};
             }
-            CMDR_BLOCK_SYNC();
-        }
-        fft_dit_plus(buf, d.log2M, tw, log2Mmax, c);
-    } else {
-        const cd* w = rot + n;               // chirp w_j = e^{i pi j^2 / n}
-        const cd* chat = w + n;              // bit-reversed FFT_M^- of the conj chirp
-        // a_j = Z_j w_j ; we need F^-(a) = conj(F^+(conj a))
-        if (noalias) {
-            ring_scatter<true>(buf, d, ph, npair_pad, pair, rot, w, c);
-        } else {
-            for (int j = c.tid; j < M; j += c.nthr) {
-                cd v = {0.0, 0.0};
-                if (j < n) {
-                    const cd r = flip ? rot[j] : cd{1.0, 0.0};
-                    v = cconj(cmul(ring_gather_slot(ph, npair_pad, pair, n, d.mmax_eff, r, flip, j), w[j]));
-                }
-                buf[lds_pad(j)] = v;
-            }
-            CMDR_BLOCK_SYNC();
-        }
-        fft_dif_plus(buf, d.log2M, tw, log2Mmax, c);
-        for (int p = c.tid; p < M; p += c.nthr) buf[lds_pad(p)] = cmul(cconj(buf[lds_pad(p)]), chat[p]);
-        CMDR_BLOCK_SYNC();
-        fft_dit_plus(buf, d.log2M, tw, log2Mmax, c);
-        const double inv = 1.0 / (double)M;
-        for (int k = c.tid; k < n; k += c.nthr) {
-            const cd v = cmul(buf[lds_pad(k)], w[k]);
-            buf[lds_pad(k)] = {v.x * inv, v.y * inv};
         }
         CMDR_BLOCK_SYNC();
     }
+    idft_core(buf, f, tw, log2Mmax, c);
 }
 
-// Forward (analysis) ring transform in LDS.  On entry buf[lds_pad(k)], k<n holds z_k = y^N_k + i y^S_k.
-// On return the spectrum Z_j = sum_k z_k e^{-2 pi i jk/n} is available through ring_spec_at().
-CMDR_HD void ring_anal_lds(cd* buf, const RingDev& d, const cd* __restrict__ tw, int log2Mmax,
-                           const cd* __restrict__ chirp, FftCtx c) {
-    const int n = d.nphi, M = 1 << d.log2M;
-    if (!d.bluestein) {
-        // Z = conj(F^+(conj z)); DIF leaves it bit-reversed
-        for (int k = c.tid; k < n; k += c.nthr) buf[lds_pad(k)] = cconj(buf[lds_pad(k)]);
-        CMDR_BLOCK_SYNC();
-        fft_dif_plus(buf, d.log2M, tw, log2Mmax, c);
-    } else {
-        // conj(Z)_j = sum_k conj(z_k) e^{+...} = w_j sum_k (conj(z_k) w_k) conj(w_{j-k})  (same chirp machinery)
-        const cd* w = chirp + d.chirp_off + n;
-        const cd* chat = w + n;
-        for (int k = c.tid; k < M; k += c.nthr) {
-            cd v = {0.0, 0.0};
-            if (k < n) v = cconj(cmul(cconj(buf[lds_pad(k)]), w[k]));   // conj(a_k), a_k = conj(z_k) w_k
-            buf[lds_pad(k)] = v;
-        }
-        CMDR_BLOCK_SYNC();
-        fft_dif_plus(buf, d.log2M, tw, log2Mmax, c);
-        for (int p = c.tid; p < M; p += c.nthr) buf[lds_pad(p)] = cmul(cconj(buf[lds_pad(p)]), chat[p]);
-        CMDR_BLOCK_SYNC();
-        fft_dit_plus(buf, d.log2M, tw, log2Mmax, c);
-        const double inv = 1.0 / (double)M;
-        for (int j = c.tid; j < n; j += c.nthr) {
-            const cd v = cmul(buf[lds_pad(j)], w[j]);      // conj(Z_j) * M
-            buf[lds_pad(j)] = {v.x * inv, -v.y * inv};     // Z_j, natural order
-        }
-        CMDR_BLOCK_SYNC();
-    }
-}
-
-CMDR_HD cd ring_spec_at(const cd* buf, const RingDev& d, int j) {
-    if (!d.bluestein) return cconj(buf[lds_pad(d_bitrev(j, d.log2M))]);
-    return buf[lds_pad(j)];
-}
-
-// Extract G^N_m, G^S_m (m <= mmax_eff) from the packed spectrum and store them as phases for the adjoint
-// Legendre stage: X^N_j = (Z_j + conj Z_{n-j})/2, X^S_j = (Z_j - conj Z_{n-j})/(2i);
+// Extract G^N_m, G^S_m (m <= mmax_eff) from the packed spectrum Z_j = spec(j) and store them as phases for the
+// adjoint Legendre stage: X^N_j = (Z_j + conj Z_{n-j})/2, X^S_j = (Z_j - conj Z_{n-j})/(2i);
 // G_{j+kn} = X_j e^{-i m phi0} = X_j s^k conj(rot_j).
-CMDR_HD void ring_store_phases(const cd* buf, const RingDev& d, double* __restrict__ ph, int64_t npair_pad,
+template <class Spec>
+CMDR_HD void ring_store_phases(const Spec& spec, const RingDev& d, double* __restrict__ ph, int64_t npair_pad,
                                int pair, const cd* __restrict__ chirp, FftCtx c) {
     const int n = d.nphi;
     const bool flip = d.phi0 != 0.0;
     const cd* rot = chirp + d.chirp_off;
     const int jmax = d.mmax_eff < n - 1 ? d.mmax_eff : n - 1;
     for (int j = c.tid; j <= jmax; j += c.nthr) {
-        const cd a = ring_spec_at(buf, d, j), b = cconj(ring_spec_at(buf, d, j == 0 ? 0 : n - j));
+        const cd a = spec(j), b = cconj(spec(j == 0 ? 0 : n - j));
         const cd xn = {0.5 * (a.x + b.x), 0.5 * (a.y + b.y)};
         const cd dm = {0.5 * (a.x - b.x), 0.5 * (a.y - b.y)};
         const cd xs = {dm.y, -dm.x};  // dm / i
@@ -745,6 +762,140 @@ CMDR_HD void ring_store_phases(const cd* buf, const RingDev& d, double* __restri
             if (flip) { gn.x = -gn.x; gn.y = -gn.y; gs.x = -gs.x; gs.y = -gs.y; }
         }
     }
+}
+
+struct SpecDirect {   // spectrum of a ring transformed in one piece
+    const cd* buf;
+    FftSub f;
+    CMDR_HD cd operator()(int j) const { return dft_at(buf, f, j); }
+};
+
+// e^{+2 pi i j / n} from rot_t = e^{i pi t / n}, t < n
+CMDR_HD cd ring_unit(const cd* __restrict__ rot, int n, int j) {
+    const int t = 2 * j;
+    if (t < n) return rot[t];
+    const cd r = rot[t - n];
+    return {-r.x, -r.y};
+}
+
+// Split rings (n even, too long for one LDS image): radix-2 decimation in pixel space,
+//   y_{k1+2k2} = sum_{j2<h} e^{2 pi i j2 k2/h} V_{k1}[j2],  V_{k1}[j2] = e^{2 pi i j2 k1/n} (Z_{j2} + (-1)^{k1} Z_{h+j2})
+//   Z_j = A_0[j mod h] + e^{-2 pi i j/n} A_1[j mod h],       A_{k1}[j'] = sum_{k2} z_{k1+2k2} e^{-2 pi i j' k2/h}
+// with h = n/2: two half-length transforms run one after the other in the same LDS image; A_0 waits in a
+// per-workgroup global scratch line (h complex) until A_1 exists.
+struct SpecSplit {
+    const cd* buf;
+    FftSub f;
+    const cd* a0;
+    const cd* rot;
+    int n;
+    CMDR_HD cd operator()(int j) const {
+        const int h = n >> 1, jj = j < h ? j : j - h;
+        const cd e = cconj(ring_unit(rot, n, j));
+        const cd t = cmul(e, dft_at(buf, f, jj));
+        const cd a = a0[jj];
+        return {a.x + t.x, a.y + t.y};
+    }
+};
+
+CMDR_HD cd ring_split_input(const double* __restrict__ ph, int64_t npair_pad, int pair, const RingDev& d,
+                            const cd* __restrict__ rot, bool flip, int k1, int j2) {
+    const int n = d.nphi, h = n >> 1;
+    const cd one = {1.0, 0.0};
+    const cd a = ring_gather_slot(ph, npair_pad, pair, n, d.mmax_eff, flip ? rot[j2] : one, flip, j2);
+    const cd b = ring_gather_slot(ph, npair_pad, pair, n, d.mmax_eff, flip ? rot[h + j2] : one, flip, h + j2);
+    if (k1 == 0) return cadd(a, b);
+    return cmul(csub(a, b), rot[2 * j2]);
+}
+
+// Whole ring-pair job of one workgroup.  MODE 0: phases -> map (* mul * weight); 1: map (* mul * weight) -> phases;
+// 2: phases -> pixels * mul -> phases (the fused Y^t N^-1 Y core of the matvec; the map never exists in HBM).
+template <int MODE>
+CMDR_HD void ring_block(cd* buf, const RingDev& d, int pair, double* __restrict__ php, int64_t npair_pad,
+                        double* __restrict__ mp, const double* __restrict__ mu, double wg,
+                        const cd* __restrict__ tw, int log2Mmax, const cd* __restrict__ chirp,
+                        cd* __restrict__ scratch, FftCtx c) {
+    const int n = d.nphi;
+    const FftSub f = ring_fft_desc(d, chirp);
+    if (!d.split) {
+        if (MODE == 0 || MODE == 2) ring_synth_lds(buf, d, php, npair_pad, pair, tw, log2Mmax, chirp, c);
+        if (MODE == 0) {
+            for (int k = c.tid; k < n; k += c.nthr) {
+                const cd v = buf[lds_pad(k)];
+                mp[d.startN + k] = v.x * (wg * (mu ? mu[d.startN + k] : 1.0));
+                if (d.startS >= 0) mp[d.startS + k] = v.y * (wg * (mu ? mu[d.startS + k] : 1.0));
+            }
+            return;
+        }
+        if (MODE == 1) {
+            for (int k = c.tid; k < n; k += c.nthr) {
+                cd v = {mp[d.startN + k] * (wg * (mu ? mu[d.startN + k] : 1.0)), 0.0};
+                if (d.startS >= 0) v.y = mp[d.startS + k] * (wg * (mu ? mu[d.startS + k] : 1.0));
+                buf[lds_pad(k)] = v;
+            }
+            CMDR_BLOCK_SYNC();
+        }
+        if (MODE == 2) {
+            for (int k = c.tid; k < n; k += c.nthr) {
+                cd v = buf[lds_pad(k)];
+                v.x *= mu[d.startN + k];
+                v.y = d.startS >= 0 ? v.y * mu[d.startS + k] : 0.0;
+                buf[lds_pad(k)] = v;
+            }
+            CMDR_BLOCK_SYNC();
+        }
+        dft_core(buf, f, tw, log2Mmax, c);
+        ring_store_phases(SpecDirect{buf, f}, d, php, npair_pad, pair, chirp, c);
+        return;
+    }
+    const int h = n >> 1, M = 1 << d.log2M;
+    const bool flip = d.phi0 != 0.0;
+    const cd* rot = chirp + d.chirp_off;
+    for (int k1 = 0; k1 < 2; ++k1) {
+        if (MODE == 0 || MODE == 2) {
+            for (int j = c.tid; j < (f.bluestein ? M : h); j += c.nthr) {
+                if (j < h) idft_put(buf, f, j, ring_split_input(php, npair_pad, pair, d, rot, flip, k1, j));
+                else buf[lds_pad(j)] = {0.0, 0.0};
+            }
+            CMDR_BLOCK_SYNC();
+            idft_core(buf, f, tw, log2Mmax, c);
+        }
+        if (MODE == 0) {
+            for (int k2 = c.tid; k2 < h; k2 += c.nthr) {
+                const int k = k1 + 2 * k2;
+                const cd v = buf[lds_pad(k2)];
+                mp[d.startN + k] = v.x * (wg * (mu ? mu[d.startN + k] : 1.0));
+                if (d.startS >= 0) mp[d.startS + k] = v.y * (wg * (mu ? mu[d.startS + k] : 1.0));
+            }
+            CMDR_BLOCK_SYNC();
+            continue;
+        }
+        if (MODE == 1) {
+            for (int k2 = c.tid; k2 < h; k2 += c.nthr) {
+                const int k = k1 + 2 * k2;
+                cd v = {mp[d.startN + k] * (wg * (mu ? mu[d.startN + k] : 1.0)), 0.0};
+                if (d.startS >= 0) v.y = mp[d.startS + k] * (wg * (mu ? mu[d.startS + k] : 1.0));
+                buf[lds_pad(k2)] = v;
+            }
+            CMDR_BLOCK_SYNC();
+        }
+        if (MODE == 2) {
+            for (int k2 = c.tid; k2 < h; k2 += c.nthr) {
+                const int k = k1 + 2 * k2;
+                cd v = buf[lds_pad(k2)];
+                v.x *= mu[d.startN + k];
+                v.y = d.startS >= 0 ? v.y * mu[d.startS + k] : 0.0;
+                buf[lds_pad(k2)] = v;
+            }
+            CMDR_BLOCK_SYNC();
+        }
+        dft_core(buf, f, tw, log2Mmax, c);
+        if (k1 == 0) {
+            for (int j = c.tid; j < h; j += c.nthr) scratch[j] = dft_at(buf, f, j);
+            CMDR_BLOCK_SYNC();
+        }
+    }
+    ring_store_phases(SpecSplit{buf, f, scratch, rot, n}, d, php, npair_pad, pair, chirp, c);
 }
 
 // ---------------------------------------------------------------------------------------------------------

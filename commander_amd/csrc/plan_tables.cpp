@@ -4,6 +4,7 @@
 #include <algorithm>
 #include <cmath>
 #include <complex>
+#include <cstdio>
 #include <cstdlib>
 #include <map>
 
@@ -355,6 +356,11 @@ void RingTables::build(int nside_, int lmax_, const std::vector<int>& rings, con
     }
     npix_local = off;
     log2Mmax = 1;
+    nsplit = 0;
+    split_line = 0;
+    constexpr int kMaxLog2M = 13;   // 8192 complex + padding = 147 KB of the 160 KB LDS
+    int split_min_n = 1 << 30;      // test hook: split every ring at least this long
+    if (const char* e = std::getenv("CMDR_RING_SPLIT_MIN_N")) { const int v = std::atoi(e); if (v >= 4) split_min_n = v; }
     std::map<int, int64_t> chirp_of;  // nphi -> offset (in complex units)
     chirp.clear();
     for (int p = 0; p < npair; ++p) {
@@ -366,16 +372,31 @@ void RingTables::build(int nside_, int lmax_, const std::vector<int>& rings, con
         d.mmax_eff = std::min(mlim[p], lmax);
         d.wgt = (wring ? wring[rings[p] - 1] : 1.0) * 4.0 * kPi / npix_full;
         const int n = r.nphi;
-        const bool pow2 = (n & (n - 1)) == 0;
-        int lg = 0;
-        if (pow2) { while ((1 << lg) < n) ++lg; }
-        else      { while ((1 << lg) < 2 * n - 1) ++lg; }
+        // transform length: the whole ring, or (rings whose LDS image would exceed 2^kMaxLog2M complex, i.e. the
+        // long cap rings of Nside 2048) two half-length pieces
+        auto size_class = [](int nt, bool& p2) {
+            p2 = (nt & (nt - 1)) == 0;
+            int lg = 0;
+            while ((1 << lg) < (p2 ? nt : 2 * nt - 1)) ++lg;
+            return lg;
+        };
+        bool pow2;
+        int nt = n, lg = size_class(n, pow2);
+        d.split = 0;
+        if (lg > kMaxLog2M || n >= split_min_n) {
+            CMDR_REQUIRE(n % 2 == 0, "cannot split an odd-length ring");
+            nt = n / 2;
+            lg = size_class(nt, pow2);
+            CMDR_REQUIRE(lg <= kMaxLog2M, "ring FFT too long (nside > 2048 is not supported)");
+            d.split = ++nsplit;
+            split_line = std::max(split_line, nt);
+        }
         d.bluestein = pow2 ? 0 : 1;
         d.log2M = lg;
         auto it = chirp_of.find(n);
         if (it == chirp_of.end()) {
-            // per-length table: rot_j = e^{i pi j/n} (j<n); Bluestein lengths add the chirp w_j = e^{i pi j^2/n} (j<n)
-            // and the FFT_M^- of the conjugate chirp in bit-reversed order (M entries)
+            // per-length table: rot_j = e^{i pi j/n} (j<n); Bluestein lengths add the chirp w_j = e^{i pi j^2/nt}
+            // (j<nt) and the FFT_M^- of the conjugate chirp in bit-reversed order (M entries)
             const int64_t o = (int64_t)chirp.size() / 2;
             chirp_of[n] = o;
             for (int j = 0; j < n; ++j) {
@@ -385,16 +406,16 @@ void RingTables::build(int nside_, int lmax_, const std::vector<int>& rings, con
             }
             if (!pow2) {
                 const int M = 1 << lg;
-                std::vector<std::complex<double>> w(n), c(M, 0.0);
-                for (int j = 0; j < n; ++j) {
-                    const int64_t q = ((int64_t)j * j) % (2 * (int64_t)n);
-                    const double ang = kPi * (double)q / (double)n;
+                std::vector<std::complex<double>> w(nt), c(M, 0.0);
+                for (int j = 0; j < nt; ++j) {
+                    const int64_t q = ((int64_t)j * j) % (2 * (int64_t)nt);
+                    const double ang = kPi * (double)q / (double)nt;
                     w[j] = {std::cos(ang), std::sin(ang)};
                 }
                 c[0] = std::conj(w[0]);
-                for (int j = 1; j < n; ++j) { c[j] = std::conj(w[j]); c[M - j] = std::conj(w[j]); }
+                for (int j = 1; j < nt; ++j) { c[j] = std::conj(w[j]); c[M - j] = std::conj(w[j]); }
                 host_fft_pow2(c, -1);
-                for (int j = 0; j < n; ++j) { chirp.push_back(w[j].real()); chirp.push_back(w[j].imag()); }
+                for (int j = 0; j < nt; ++j) { chirp.push_back(w[j].real()); chirp.push_back(w[j].imag()); }
                 for (int q = 0; q < M; ++q) {
                     const auto v = c[bitrev(q, lg)];
                     chirp.push_back(v.real());
@@ -407,6 +428,7 @@ void RingTables::build(int nside_, int lmax_, const std::vector<int>& rings, con
         }
         log2Mmax = std::max(log2Mmax, d.log2M);
     }
+    if (std::getenv("CMDR_DEBUG_PLAN")) std::fprintf(stderr, "[cmdr] ring plan nside=%d: %d pairs, %d split (line %d), log2Mmax %d\n", nside, npair, nsplit, split_line, log2Mmax);
     classes.assign(log2Mmax + 1, {});
     for (int p = 0; p < npair; ++p) classes[pairs[p].log2M].push_back(p);
     const int Mmax = 1 << log2Mmax;

@@ -72,8 +72,9 @@ inline int mlim_spin2(int lmax, double sth, double cth) {   // libsharp's cut wi
 
 struct RingPairDesc {   // one north/south ring pair (or the equator alone: startS = -1)
     int nphi;           // pixels per ring
-    int log2M;          // FFT size class: nphi if power of two, else Bluestein M >= 2 nphi - 1
+    int log2M;          // FFT size class: nt if power of two, else Bluestein M >= 2 nt - 1 (nt = nphi, or nphi/2 if split)
     int bluestein;      // 0/1
+    int split;          // 0, or 1 + scratch line index: ring done as two half-length transforms (kernels_body.hpp)
     int mmax_eff;       // = mlim of the pair
     int64_t startN, startS;  // offsets of the two rings in the *local* map (startS = -1: no southern ring)
     double phi0;
@@ -88,6 +89,7 @@ struct RingTables {
     std::vector<RingPairDesc> pairs;          // [npair]
     std::vector<std::vector<int>> classes;    // classes[log2M] = pair indices
     int log2Mmax = 0;
+    int nsplit = 0, split_line = 0;           // number of split pairs, complex elements per scratch line (max n/2)
     std::vector<double> twiddle;              // [2 * Mmax/2]  exp(2 pi i k / Mmax), k < Mmax/2 (re,im)
     // Bluestein tables, per distinct nphi: w_j = exp(i pi j^2 / n) (j<n), then chat in bit-reversed order (M)
     std::vector<double> chirp;                // (re,im) pairs

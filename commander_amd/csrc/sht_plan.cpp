@@ -59,7 +59,6 @@ ShtPlan::ShtPlan(int nside, int lmax, const std::vector<int>& rings, const doubl
     CMDR_REQUIRE(lmax >= 0, "lmax must be >= 0");
     CMDR_REQUIRE(max_maps >= 1, "max_maps must be >= 1");
     T_.build(nside, lmax, rings, wring, max_maps, pol);
-    CMDR_REQUIRE(T_.ring.log2Mmax <= 13, "ring FFT larger than 8192 points (nside > 1024) is not supported yet");
     leg_.upload(T_.leg);
     std::vector<RingDev> rd(T_.ring.npair);
     for (int p = 0; p < T_.ring.npair; ++p) {
@@ -75,7 +74,7 @@ ShtPlan::ShtPlan(int nside, int lmax, const std::vector<int>& rings, const doubl
         r.wgt = d.wgt;
         r.chirp_off = d.chirp_off;
         r.ring = d.ring;
-        r.pad = 0;
+        r.split = d.split;
     }
     rings_.upload(rd);
     cls_.resize(T_.ring.classes.size());
@@ -89,6 +88,7 @@ ShtPlan::ShtPlan(int nside, int lmax, const std::vector<int>& rings, const doubl
     ast_.alloc((size_t)max_maps * leg_.tri_elems());
     ph_.alloc((size_t)max_maps * leg_.ph_elems());
     part_.alloc((size_t)max_maps * part_map_stride());
+    if (T_.ring.nsplit) ring_scratch_.alloc((size_t)max_maps * T_.ring.nsplit * T_.ring.split_line * 2);
     if (pol) {
         CMDR_REQUIRE(max_maps >= 2, "a polarised plan needs max_maps >= 2 (Q and U phases)");
         leg2_.upload(T_.leg2);
@@ -117,7 +117,8 @@ void ShtPlan::rings(int mode, double* d_map, int64_t map_stride, const double* c
         launch_ring(mode, rings_.get(), cls_[c].get(), ncls_[c], (int)c, ph_.get(), leg_.ph_elems(),
                     leg_.npair_pad, d_map, map_stride, d_mul, weighted ? 1 : 0,
                     reinterpret_cast<const cd*>(tw_.get()), T_.ring.log2Mmax,
-                    reinterpret_cast<const cd*>(chirp_.get()), nmaps, s);
+                    reinterpret_cast<const cd*>(chirp_.get()), reinterpret_cast<cd*>(ring_scratch_.get()),
+                    (int64_t)T_.ring.nsplit * T_.ring.split_line, T_.ring.split_line, nmaps, s);
     }
 }
 

@@ -83,7 +83,7 @@ class ShtPlan {
     DevBuf<RingDev> rings_;
     std::vector<DevBuf<int>> cls_;
     std::vector<int> ncls_;
-    DevBuf<double> tw_, chirp_;
+    DevBuf<double> tw_, chirp_, ring_scratch_;   // ring_scratch_: one line of n/2 complex per split ring pair and map
     DevBuf<double> ast_, ph_, part_;
 };
 

@@ -188,7 +188,8 @@ void launch_part2_to_alm(const double* part, int64_t part_pol_stride, int64_t pc
 
 void launch_ring(int mode, const RingDev* rings, const int* cls, int ncls, int log2M, double* ph,
                  int64_t ph_stride, int64_t npair_pad, double* map, int64_t map_stride, const double* const* mul,
-                 int weighted, const cd* tw, int log2Mmax, const cd* chirp, int nmaps, hipStream_t) {
+                 int weighted, const cd* tw, int log2Mmax, const cd* chirp, cd* scratch, int64_t scratch_map_stride,
+                 int scratch_line, int nmaps, hipStream_t) {
     std::vector<cd> bufv((size_t)lds_elems(log2M));
     cd* buf = bufv.data();
     const FftCtx c{0, 1};
@@ -199,28 +200,11 @@ void launch_ring(int mode, const RingDev* rings, const int* cls, int ncls, int l
             double* php = ph + imap * ph_stride;
             double* mp = map ? map + imap * map_stride : nullptr;
             const double* mu = mul ? mul[imap] : nullptr;
-            const int n = d.nphi;
             const double wg = weighted ? d.wgt : 1.0;
-            if (mode == 0 || mode == 2) ring_synth_lds(buf, d, php, npair_pad, pair, tw, log2Mmax, chirp, c);
-            if (mode == 0) {
-                for (int k = 0; k < n; ++k) {
-                    mp[d.startN + k] = buf[lds_pad(k)].x * wg * (mu ? mu[d.startN + k] : 1.0);
-                    if (d.startS >= 0) mp[d.startS + k] = buf[lds_pad(k)].y * wg * (mu ? mu[d.startS + k] : 1.0);
-                }
-                continue;
-            }
-            if (mode == 1)
-                for (int k = 0; k < n; ++k) {
-                    buf[lds_pad(k)].x = mp[d.startN + k] * wg * (mu ? mu[d.startN + k] : 1.0);
-                    buf[lds_pad(k)].y = d.startS >= 0 ? mp[d.startS + k] * wg * (mu ? mu[d.startS + k] : 1.0) : 0.0;
-                }
-            if (mode == 2)
-                for (int k = 0; k < n; ++k) {
-                    buf[lds_pad(k)].x *= mu[d.startN + k];
-                    buf[lds_pad(k)].y = d.startS >= 0 ? buf[lds_pad(k)].y * mu[d.startS + k] : 0.0;
-                }
-            ring_anal_lds(buf, d, tw, log2Mmax, chirp, c);
-            ring_store_phases(buf, d, php, npair_pad, pair, chirp, c);
+            cd* sc = d.split ? scratch + imap * scratch_map_stride + (int64_t)(d.split - 1) * scratch_line : nullptr;
+            if (mode == 0) ring_block<0>(buf, d, pair, php, npair_pad, mp, mu, wg, tw, log2Mmax, chirp, sc, c);
+            else if (mode == 1) ring_block<1>(buf, d, pair, php, npair_pad, mp, mu, wg, tw, log2Mmax, chirp, sc, c);
+            else ring_block<2>(buf, d, pair, php, npair_pad, mp, mu, wg, tw, log2Mmax, chirp, sc, c);
         }
 }
 

@@ -162,3 +162,34 @@ def test_emul_polarised_cr_path_vs_oracle(EL):
     xs, n, st, res = ctx.solve_cr_eqn_by_CG(rhso, "fixed_iter", 1e-8, 5, 12, 1)
     xo, no, so = S.solve(rhso, "fixed_iter", 1e-8, 5, 12, 1)
     assert n == no and rel(xs, xo) < 1e-10
+
+
+@pytest.mark.parametrize("nside,lmax,min_n", [(8, 16, 20), (8, 30, 12), (16, 40, 36)])
+def test_emul_split_rings_vs_oracle(nside, lmax, min_n, EL, oracle_lib, monkeypatch):
+    """Rings too long for one LDS image (Nside 2048 caps) run as two half-length transforms; CMDR_RING_SPLIT_MIN_N
+    forces that code path onto small rings (power-of-two and Bluestein halves, with and without m-aliasing)."""
+    import commander_amd.sht as shtmod
+    from commander_amd.sht import ShtPlan
+    monkeypatch.setenv("CMDR_RING_SPLIT_MIN_N", str(min_n))
+    monkeypatch.setattr(shtmod, "lib", lambda: EL)
+    rng = np.random.default_rng(nside + lmax)
+    w = 1.0 + 0.05 * rng.standard_normal(2 * nside)
+    plan = ShtPlan(nside, lmax, wring=w, max_maps=2)
+    a = rng.standard_normal(((lmax + 1) ** 2, 2))
+    m = rng.standard_normal((12 * nside * nside, 2))
+    y, yt, ytw = plan.Y(a), plan.Yt(m), plan.YtW(m)
+    for k in range(2):
+        assert rel(y[:, k], oracle_lib.Y(nside, lmax, a[:, k])) < 1e-12
+        assert rel(yt[:, k], oracle_lib.Yt(nside, lmax, m[:, k])) < 1e-12
+        assert rel(ytw[:, k], oracle_lib.YtW(nside, lmax, m[:, k], wring=w)) < 1e-12
+
+
+def test_emul_split_rings_fused_matvec(EL, monkeypatch):
+    from commander_amd import synth
+    from commander_amd.cr import build_context
+    monkeypatch.setenv("CMDR_RING_SPLIT_MIN_N", "20")
+    spec = synth.make_problem("cfg2", nside=8, lmax=16)
+    S = oracle_system(spec)
+    ctx = build_context(spec, _lib=EL)
+    x = np.random.default_rng(4).standard_normal(ctx.ncr)
+    assert rel(ctx.cr_matmulA(x), S.matmulA(x)) < 1e-12
