@@ -23,6 +23,8 @@ CONFIGS = {
     "cfg1": dict(nside=64, lmax=128, nu=[70.0], fwhm=[60.0], comps=["cmb"]),
     "cfg2": dict(nside=256, lmax=512, nu=[30.0, 70.0, 143.0], fwhm=[32.3, 13.2, 7.3], comps=["cmb", "synch"]),
     "cfg3": dict(nside=1024, lmax=2000, nu=PLANCK_NU, fwhm=PLANCK_FWHM, comps=["cmb"]),
+    # configs[3]: polarised T/E/B CMB-only at the SHT-roofline geometry
+    "cfg4": dict(nside=2048, lmax=4000, nu=[143.0], fwhm=[7.3], comps=["cmb"], pol=True),
 }
 
 
@@ -48,13 +50,14 @@ def comp_Dl(name, lmax):
     return D
 
 
-def make_problem(cfg, nside=None, lmax=None, comp_lmax=None, pixels=None, pol=False):
+def make_problem(cfg, nside=None, lmax=None, comp_lmax=None, pixels=None, pol=None):
     """Problem spec dict consumed by ``commander_amd.cr.build_context`` (and by the tests' oracle builder).
 
     pixels: optional full-sky RING indices of a rank's local map (ring sharding); maps are then local."""
     c = dict(CONFIGS[cfg]) if isinstance(cfg, str) else dict(cfg)
     nside = int(nside or c["nside"])
     lmax = int(lmax or c["lmax"])
+    pol = bool(c.get("pol", False)) if pol is None else bool(pol)
     npix = 12 * nside * nside
     z = healpix.pix_z(nside)
     Dl_cmb = comp_Dl("cmb", lmax)

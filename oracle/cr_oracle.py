@@ -160,6 +160,12 @@ class Cl:
             out = np.where(ok[:, None], np.einsum("nij,nj->ni", Ml, alm), 0.0)
         return out
 
+    def getCl(self, l, p):
+        """comm_Cl_mod.f90:1440-1456 (p: 0-based Stokes index; f_apod = 1)."""
+        n = self.nmaps
+        j = p * n - p * (p - 1) // 2          # diagonal spectrum index of Stokes p (0-based)
+        return self.Dl[l, j] if l == 0 else self.Dl[l, j] / (l * (l + 1) / (2.0 * np.pi))
+
     def sqrtS(self, alm, info, diag=False):
         return self._apply(self.sqrtS_mat, alm, info, diag)
 
@@ -170,10 +176,14 @@ class Cl:
 class DiffuseComp:
     """``comm_diffuse_comp`` reduced to what the CR system reads (constant mixing)."""
 
-    def __init__(self, lmax_amp, nmaps, cl, F_mean, active=True, mu=None, nside=None):
+    def __init__(self, lmax_amp, nmaps, cl, F_mean, active=True, mu=None, nside=None, F_map=None):
         self.lmax_amp, self.nmaps, self.Cl = int(lmax_amp), int(nmaps), cl
         self.F_mean = np.asarray(F_mean, dtype=np.float64).reshape(-1, nmaps)  # (numband, nmaps); det=0
         self.F_null = np.all(self.F_mean == 0.0, axis=1)
+        # spatially varying mixing (lmax_ind_mix /= 0): F(band,0)%p%map, {band index: (npix, nmaps)}; bands of this
+        # component then take the Y . F . YtW branch (comm_diffuse_comp_mod.f90:2082-2084, 2155-2157)
+        self.F_map = {} if F_map is None else {int(k): np.asarray(v, dtype=np.float64).reshape(len(v), -1)
+                                               for k, v in F_map.items()}
         self.active = active
         self.info = healpix.AlmInfo(lmax_amp)
         self.mu = mu
@@ -227,6 +237,29 @@ class CRSystem:
             return np.stack([sht.Yt(band.nside, lmax, m[:, 0]), e, b], axis=1)
         return np.stack([sht.Yt(band.nside, lmax, m[:, j]) for j in range(m.shape[1])], axis=1)
 
+    @staticmethod
+    def _YtW(band, m, lmax):
+        """exec_sharp_YtW (comm_map_mod.f90:531-555): analysis with ring weights W * 4pi/Npix."""
+        if m.shape[1] == 3:
+            e, b = sht.sht_spin2(sht.JOB_YtW, band.nside, lmax, mapQ=m[:, 1], mapU=m[:, 2], wring=band.wring)
+            return np.stack([sht.YtW(band.nside, lmax, m[:, 0], wring=band.wring), e, b], axis=1)
+        return np.stack([sht.YtW(band.nside, lmax, m[:, j], wring=band.wring) for j in range(m.shape[1])], axis=1)
+
+    @staticmethod
+    def _WY(band, alm, lmax):
+        """exec_sharp_WY (comm_map_mod.f90:457-480): adjoint of the analysis."""
+        if alm.shape[1] == 3:
+            q, u = sht.sht_spin2(sht.JOB_WY, band.nside, lmax, almE=alm[:, 1], almB=alm[:, 2], wring=band.wring)
+            return np.stack([sht.WY(band.nside, lmax, alm[:, 0], wring=band.wring), q, u], axis=1)
+        return np.stack([sht.WY(band.nside, lmax, alm[:, j], wring=band.wring) for j in range(alm.shape[1])], axis=1)
+
+    def _mix_map(self, c, ib, alm, lmax):
+        """Y -> multiply by F(band)%map -> YtW on (nalm(lmax), nmaps) columns (nmaps = 1 or 3)."""
+        b = self.bands[ib]
+        mp = self._Y(b, alm, lmax)
+        mp = mp * c.F_map[ib][:, : alm.shape[1]]
+        return self._YtW(b, mp, lmax)
+
     def _lmax_all(self):
         lm = -1
         for c in self.comps:
@@ -242,7 +275,10 @@ class CRSystem:
         if c.F_null[ib]:
             return out
         nmaps = min(b.nmaps, c.nmaps)
-        m = amp_in[:, :nmaps] * c.F_mean[ib, :nmaps]
+        if ib in c.F_map:
+            m = self._mix_map(c, ib, amp_in[:, :nmaps], b.lmax)      # :2082-2084
+        else:
+            m = amp_in[:, :nmaps] * c.F_mean[ib, :nmaps]             # :2077-2080
         m = b.conv(m, b.info)
         out[:, :nmaps] = m
         return out
@@ -254,7 +290,10 @@ class CRSystem:
             return np.zeros((c.info.nalm, c.nmaps))
         nmaps = min(c.nmaps, b.nmaps)
         m = b.conv(alm_band[:, :nmaps], b.info)
-        m = m * c.F_mean[ib, :nmaps]
+        if ib in c.F_map:
+            m = self._mix_map(c, ib, m, b.lmax)                      # :2155-2157
+        else:
+            m = m * c.F_mean[ib, :nmaps]
         return healpix.alm_equal(m, b.info, c.info, nmaps_dst=c.nmaps)
 
     # ------------------------------------------------------------------ cr_matmulA
@@ -329,7 +368,14 @@ class CRSystem:
                     Tm = np.zeros((c.info.nalm, c.nmaps))            # :631-632
                 else:
                     Tm = healpix.alm_equal(alm, b.info, c.info, nmaps_dst=c.nmaps)  # :634
-                    Tm = Tm * c.F_mean[ib, :]                        # :636-639
+                    if ib in c.F_map:                                # :640-650 (at the component's lmax)
+                        Fm = np.zeros((b.npix, c.nmaps))
+                        nm = min(c.nmaps, b.nmaps)
+                        Fm[:, :nm] = c.F_map[ib][:, :nm]
+                        mp = self._Y(b, Tm, c.lmax_amp) * Fm
+                        Tm = self._YtW(b, mp, c.lmax_amp)
+                    else:
+                        Tm = Tm * c.F_mean[ib, :]                    # :636-639
                 Tm = c.Cl.sqrtS(Tm, c.info)                          # :652
                 Tm[c.info.l > b.lmax, :] = 0.0                       # :655-657
                 self.insert(k, True, Tm, rhs)                        # :659
@@ -434,9 +480,94 @@ class CRSystem:
         P["present"] = present
         return invM
 
+    # ------------------------------------------------------------------ pseudo-inverse preconditioner
+    def init_precond_pseudoinv(self):
+        """alpha_nu per band and Stokes group (comm_N_rms_mod.f90:217-246): tau = Y Yt siN^2,
+        alpha = sqrt(sum tau^2 / sum tau); Q and U share one value."""
+        for b in self.bands:
+            tau = self._Y(b, self._Yt(b, b.siN ** 2, b.lmax), b.lmax)
+            al = np.zeros(b.nmaps)
+            st, st2 = tau[:, 0].sum(), (tau[:, 0] ** 2).sum()
+            al[0] = np.sqrt(st2 / st) if st > 0 else 0.0
+            if b.nmaps == 3:
+                st, st2 = tau[:, 1:3].sum(), (tau[:, 1:3] ** 2).sum()
+                al[1:3] = np.sqrt(st2 / st) if st > 0 else 0.0
+            b.alpha_nu = al
+        lmax_pre = max(c.lmax_amp for c in self.comps)
+        nmaps_pre = max(c.nmaps for c in self.comps)
+        self.precond = dict(type="pseudoinv", info=healpix.AlmInfo(lmax_pre), nmaps=nmaps_pre, npre=len(self.comps))
+        return self.precond
+
+    def update_precond_pseudoinv(self):
+        """updateDiffPrecond_pseudoinv (comm_diffuse_comp_mod.f90:1560-1658): per (l, Stokes) the pseudo-inverse
+        (SVD, relative threshold 1e-12: math_tools.f90:234-292) of U = [alpha_nu b_l F_mean sqrt(C_l) ; prior 1]."""
+        P = self.precond
+        npre, nb = P["npre"], len(self.bands)
+        lmax_pre = P["info"].lmax
+        pinv = np.zeros((lmax_pre + 1, P["nmaps"], npre, nb + npre))
+        for j in range(P["nmaps"]):
+            for l in range(lmax_pre + 1):
+                mat = np.zeros((nb + npre, npre))
+                for q, b in enumerate(self.bands):
+                    if l > b.lmax or j >= b.nmaps:
+                        continue
+                    for k, c in enumerate(self.comps):
+                        if l > c.lmax_amp or j >= c.nmaps or not c.active:
+                            continue
+                        v = b.alpha_nu[j] * b.b_l[l, min(j, b.b_l.shape[1] - 1)] * c.F_mean[q, j]
+                        if c.cltype != "none":
+                            v *= np.sqrt(c.Cl.getCl(l, j))
+                        mat[q, k] = v
+                for k, c in enumerate(self.comps):
+                    if c.cltype == "none" or l > c.lmax_amp or not c.active:
+                        continue
+                    mat[nb + k, k] = 1.0
+                pinv[l, j] = np.linalg.pinv(mat, rcond=1e-12)
+        P["pinv"] = pinv
+        P["ind_pre"] = [k for k, c in enumerate(self.comps) if c.active]
+        return pinv
+
+    def _invM_pseudoinv(self, x):
+        """applyDiffPrecond_pseudoinv (comm_diffuse_comp_mod.f90:2238-2380)."""
+        P = self.precond
+        info_pre, nmaps_pre, ind = P["info"], P["nmaps"], P["ind_pre"]
+        pinv, nb = P["pinv"], len(self.bands)
+        res = np.asarray(x, dtype=np.float64).copy()
+        if not ind:
+            return res
+        yv = np.zeros((len(ind), info_pre.nalm, nmaps_pre))
+        for i, k in enumerate(ind):
+            c = self.comps[k]
+            yv[i][info_pre.lm2i_vec(c.info.l, c.info.m), : c.nmaps] = self.extract(k, x)
+        z = np.zeros_like(yv)
+        for q, b in enumerate(self.bands):
+            sel = b.info.l <= info_pre.lmax
+            jpre = info_pre.lm2i_vec(b.info.l[sel], b.info.m[sel])
+            lb = b.info.l[sel]
+            a = np.zeros((b.info.nalm, b.nmaps))
+            for i, k in enumerate(ind):                                  # (U^+)^t
+                for p in range(b.nmaps):
+                    a[sel, p] += pinv[lb, p, k, q] * yv[i][jpre, p]
+            mp = self._WY(b, a, b.lmax)                                  # :2295
+            mp = b.N(mp)                                                 # :2297
+            a = self._YtW(b, mp, b.lmax) * b.alpha_nu[None, :] ** 2      # :2299-2305
+            for i, k in enumerate(ind):                                  # U^+
+                for p in range(b.nmaps):
+                    z[i][jpre, p] += pinv[lb, p, k, q] * a[sel, p]
+        for p in range(nmaps_pre):                                       # prior terms :2328-2352
+            Pp = pinv[info_pre.l, p][:, ind][:, :, [nb + k for k in ind]]   # (nalm, n, n): M(ind(a), numband+ind(b))
+            w2 = np.einsum("nkj,kn->jn", Pp, yv[:, :, p])                # w2(j) = sum_k M(ind k, nb+ind j) w(k)
+            z[:, :, p] += np.einsum("njk,kn->jn", Pp, w2)                # w(j)  = sum_k M(ind j, nb+ind k) w2(k)
+        for i, k in enumerate(ind):
+            c = self.comps[k]
+            self.insert(k, False, z[i][info_pre.lm2i_vec(c.info.l, c.info.m), : c.nmaps], res)
+        return res
+
     def invM(self, x):
         """cr_invM (comm_cr_mod.f90:1026-1077) -> applyDiffPrecond_diagonal (comm_diffuse_comp_mod.f90:2186-2235)."""
         P = self.precond
+        if P.get("type") == "pseudoinv":
+            return self._invM_pseudoinv(x)
         info_pre, nmaps_pre, npre = P["info"], P["nmaps"], P["npre"]
         yv = np.zeros((npre, info_pre.nalm, nmaps_pre))
         for k, c in enumerate(self.comps):

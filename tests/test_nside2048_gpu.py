@@ -49,3 +49,25 @@ def test_spin2_full_size_vs_oracle(plan, oracle_lib):
     lhs = float(et @ e + bt @ b)
     rhs = float(mq @ q + mu @ u)
     assert abs(lhs - rhs) <= 1e-10 * np.sqrt((mq @ mq + mu @ mu) * (q @ q + u @ u))
+
+
+def test_cfg4_polarised_cr_full_size_properties():
+    """BASELINE.json configs[3] (polarised T/E/B CMB-only, Nside 2048, lmax 4000) through the CR-level ABI: A is
+    symmetric (size-independent property of cr_matmulA, which uses Yt not YtW for exactly that reason,
+    comm_cr_mod.f90:771-1024), and a short fixed_iter PCG reduces the preconditioned residual."""
+    from commander_amd import synth
+    from commander_amd.cr import build_context
+    spec = synth.make_problem("cfg4")
+    ctx = build_context(spec)
+    assert ctx.ncr == 3 * (LMAX + 1) ** 2
+    rng = np.random.default_rng(7)
+    x, y = rng.standard_normal(ctx.ncr), rng.standard_normal(ctx.ncr)
+    Ax, Ay = ctx.cr_matmulA(x), ctx.cr_matmulA(y)
+    lhs, rhs = float(y @ Ax), float(x @ Ay)
+    assert abs(lhs - rhs) <= 1e-11 * np.linalg.norm(y) * np.linalg.norm(Ax)
+    assert float(x @ Ax) > float(x @ x) * (1 - 1e-12)      # A = 1 + (positive semi-definite)
+    ctx.initPrecond()
+    ctx.update_precond()
+    xs, niter, stat, res = ctx.solve_cr_eqn_by_CG(Ax, conv_crit="fixed_iter", maxiter=8)
+    assert stat == 0 and niter == 8
+    assert res[0] < 1e-2 * res[1]
