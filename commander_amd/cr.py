@@ -142,11 +142,38 @@ class CRContext:
         return int(self.L.cmdr_band_npix(self._h, b))
 
     # ---- preconditioner (initPrecond / update_precond: comm_signal_mod.f90:179, comm_cr_mod.f90:76) -------
-    def initPrecond(self):
-        check(self.L.cmdr_precond_init_diag(self._h), self.L)
+    def initPrecond(self, precond="diagonal"):
+        """``cpar%cg_precond``: 'diagonal' (initDiffPrecond_diagonal) or 'pseudoinv' (alpha_nu, comm_N_rms_mod.f90:217)."""
+        self.precond = precond
+        if precond == "diagonal":
+            check(self.L.cmdr_precond_init_diag(self._h), self.L)
+        elif precond == "pseudoinv":
+            check(self.L.cmdr_precond_init_pseudoinv(self._h), self.L)
+        else:
+            raise ValueError(precond)
 
     def update_precond(self):
-        check(self.L.cmdr_precond_update_diag(self._h), self.L)
+        if getattr(self, "precond", "diagonal") == "pseudoinv":
+            check(self.L.cmdr_precond_update_pseudoinv(self._h), self.L)
+        else:
+            check(self.L.cmdr_precond_update_diag(self._h), self.L)
+
+    def alpha_nu(self, band):
+        out = np.zeros(self.band_shape[band][1])
+        check(self.L.cmdr_get_alpha_nu(self._h, int(band), _p(out)), self.L)
+        return out
+
+    def set_mixing_map(self, comp, band, F):
+        """``F(band,0)%p%map`` of a component with spatially varying mixing (npix_local[, nmaps]); None = F_mean path."""
+        if F is None:
+            check(self.L.cmdr_comp_set_mixing_map(self._h, int(comp), int(band), None, 0), self.L)
+            return
+        F = _f(np.asarray(F, dtype=np.float64).reshape(len(F), -1))
+        check(self.L.cmdr_comp_set_mixing_map(self._h, int(comp), int(band), _p(F), F.shape[1]), self.L)
+
+    def set_cl_diag(self, comp, cl):
+        cl = _f(np.asarray(cl, dtype=np.float64).reshape(len(cl), -1))
+        check(self.L.cmdr_comp_set_cl_diag(self._h, int(comp), _p(cl)), self.L)
 
     def invN_diag(self, band):
         """``data(band)%N%invN_diag%alm`` (nalm, nmaps) after initPrecond (comm_N_mod.f90:127-197)."""
@@ -244,6 +271,9 @@ def build_context(spec, device=0, rings_by_nside=None, _lib=None):
     for c in spec["comps"]:
         ctx.add_comp(c["lmax"], c["nmaps"], c["F_mean"], c.get("sqrtS_mat"), c.get("sqrtInvS_mat"), c.get("S_mat"),
                      c.get("active", True))
+    for k, c in enumerate(spec["comps"]):
+        for ib, F in (c.get("F_map") or {}).items():
+            ctx.set_mixing_map(k, ib, F)
     ctx.finalize()
     return ctx
 

@@ -282,6 +282,39 @@ int cmdr_precond_update_diag(cmdr_ctx* ctx) {
         ctx->sys->sync();
     });
 }
+int cmdr_precond_init_pseudoinv(cmdr_ctx* ctx) {
+    return guarded([&] {
+        CMDR_REQUIRE(ctx, "ctx is NULL");
+        ctx->sys->precond_init_pseudoinv();
+    });
+}
+int cmdr_precond_update_pseudoinv(cmdr_ctx* ctx) {
+    return guarded([&] {
+        CMDR_REQUIRE(ctx, "ctx is NULL");
+        ctx->sys->precond_update_pseudoinv();
+        ctx->sys->sync();
+    });
+}
+int cmdr_get_alpha_nu(cmdr_ctx* ctx, int band, double* out_host) {
+    return guarded([&] {
+        CMDR_REQUIRE(ctx && out_host && band >= 0 && band < ctx->sys->nband(), "bad arguments");
+        const std::vector<double>& a = ctx->sys->alpha_nu(band);
+        CMDR_REQUIRE(!a.empty(), "cmdr_precond_init_pseudoinv has not run");
+        std::copy(a.begin(), a.end(), out_host);
+    });
+}
+int cmdr_comp_set_mixing_map(cmdr_ctx* ctx, int comp, int band, const double* F, int nmaps) {
+    return guarded([&] {
+        CMDR_REQUIRE(ctx, "ctx is NULL");
+        ctx->sys->set_mixing_map(comp, band, F, nmaps);
+    });
+}
+int cmdr_comp_set_cl_diag(cmdr_ctx* ctx, int comp, const double* cl) {
+    return guarded([&] {
+        CMDR_REQUIRE(ctx, "ctx is NULL");
+        ctx->sys->set_cl_diag(comp, cl);
+    });
+}
 int cmdr_get_invN_diag(cmdr_ctx* ctx, int band, double* out_host) {
     return guarded([&] {
         CMDR_REQUIRE(ctx && out_host && band >= 0 && band < ctx->sys->nband(), "bad arguments");

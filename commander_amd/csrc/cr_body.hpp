@@ -57,11 +57,17 @@ CMDR_HD void sqrtS_elem(const CompDev& C, const double* __restrict__ smat, int k
 CMDR_HD void band_prep_elem(const CompDev* __restrict__ comps, int ncomp, const double* __restrict__ sx,
                             const double* __restrict__ w /* [ncomp][lmax_g+1] for this bm */, int stokes,
                             double* __restrict__ ast_base, int nbs, int bm, const double* __restrict__ cnorm,
-                            int lmax_g, int m, int l) {
+                            int lmax_g, int m, int l,
+                            const double* __restrict__ extra = nullptr /* packed a_lm(lmax_g) added as is */) {
     const int64_t t = d_moffp(lmax_g, m) + (l - m);
     double* __restrict__ ast = ast_base + 2 * (t * nbs + bm) - 2 * t;  // maps interleaved: slot of (t, bm)
     double re = 0.0, im = 0.0;
     if (l <= lmax_g) {
+        if (extra) {   // band signal of the components with spatially varying mixing (already mixed and beam-convolved)
+            const int64_t i = d_packed_index(lmax_g, l, m);
+            re = extra[i];
+            if (m > 0) im = extra[i + 1];
+        }
         for (int c = 0; c < ncomp; ++c) {
             const CompDev C = comps[c];
             if (l > C.lmax || stokes >= C.nmaps) continue;
@@ -123,10 +129,17 @@ CMDR_HD void band_post_elem(const CompDev& C, int c, int ncomp, const double* __
 //   E' = -cnorm2 kappa_m / 2 * sum_c wE[c][l] sx_{c,E}(l,m),  B' likewise (comm_map_mod.f90:446-449 spin-2 call on 2:3)
 CMDR_HD void band_prep2_elem(const CompDev* __restrict__ comps, int ncomp, const double* __restrict__ sx,
                              const double* __restrict__ wE, const double* __restrict__ wB, double* __restrict__ st,
-                             int npol, int ip, const double* __restrict__ cnorm2, int lmax_g, int m, int l) {
+                             int npol, int ip, const double* __restrict__ cnorm2, int lmax_g, int m, int l,
+                             const double* __restrict__ extraE = nullptr, const double* __restrict__ extraB = nullptr) {
     const int64_t t = d_moffp(lmax_g, m) + (l - m);
     double v[4] = {0.0, 0.0, 0.0, 0.0};
     if (l <= lmax_g && l >= 2) {
+        if (extraE) {
+            const int64_t i = d_packed_index(lmax_g, l, m);
+            v[0] = extraE[i];
+            v[2] = extraB[i];
+            if (m > 0) { v[1] = extraE[i + 1]; v[3] = extraB[i + 1]; }
+        }
         for (int c = 0; c < ncomp; ++c) {
             const CompDev C = comps[c];
             if (l > C.lmax || C.nmaps < 3) continue;
@@ -169,6 +182,55 @@ CMDR_HD void band_post2_elem(const CompDev& C, int c, int ncomp, const double* _
     e[0] += s[0] * f;
     b[0] += s[2] * f;
     if (m > 0) { e[1] += s[1] * f; b[1] += s[3] * f; }
+}
+
+// alm_equal with an optional per-l factor (comm_map_mod.f90:1148-1165 + comm_B_bl_mod.f90:108-127):
+//   dst(l,m) (+)= f_l * src(l,m) for l <= min(lmax_s, lmax_d, lcut); without accumulate the rest of dst is zero-filled.
+CMDR_HD void alm_copy_elem(const double* __restrict__ src, int lmax_s, double* __restrict__ dst, int lmax_d,
+                           const double* __restrict__ fl, int accumulate, int lcut, int m, int l) {
+    const int64_t id = d_packed_index(lmax_d, l, m);
+    double re = 0.0, im = 0.0;
+    if (l <= lmax_s && l <= lcut) {
+        const int64_t is = d_packed_index(lmax_s, l, m);
+        const double f = fl ? fl[l] : 1.0;
+        re = f * src[is];
+        if (m > 0) im = f * src[is + 1];
+    }
+    if (accumulate) {
+        dst[id] += re;
+        if (m > 0) dst[id + 1] += im;
+    } else {
+        dst[id] = re;
+        if (m > 0) dst[id + 1] = im;
+    }
+}
+
+// Prior part and scatter of the pseudo-inverse preconditioner (applyDiffPrecond_pseudoinv,
+// comm_diffuse_comp_mod.f90:2328-2372): out_c = z_c + sum_c' Q[stokes][c][c'][l] x_c' for active components
+// (Q = B B^t, B = prior columns of pinv(U)); inactive components keep x.
+CMDR_HD void pinv_prior_elem(const CompDev* __restrict__ comps, int ncomp, const double* __restrict__ Q, int lmax_pre,
+                             int nmaps_pre, const double* __restrict__ x, const double* __restrict__ z,
+                             double* __restrict__ out, int m, int l) {
+    const int nslot = m == 0 ? 1 : 2;
+    for (int j = 0; j < nmaps_pre; ++j)
+        for (int sl = 0; sl < nslot; ++sl) {
+            double v[8];
+            for (int k = 0; k < ncomp; ++k) {
+                const CompDev C = comps[k];
+                v[k] = (C.active && l <= C.lmax && j < C.nmaps)
+                           ? x[C.pos + (int64_t)j * C.nalm + d_packed_index(C.lmax, l, m) + sl] : 0.0;
+            }
+            for (int k1 = 0; k1 < ncomp; ++k1) {
+                const CompDev C = comps[k1];
+                if (l > C.lmax || j >= C.nmaps) continue;
+                const int64_t i = C.pos + (int64_t)j * C.nalm + d_packed_index(C.lmax, l, m) + sl;
+                if (!C.active) { out[i] = x[i]; continue; }
+                double s = z[i];
+                for (int k2 = 0; k2 < ncomp; ++k2)
+                    s += Q[(((int64_t)j * ncomp + k1) * ncomp + k2) * (lmax_pre + 1) + l] * v[k2];
+                out[i] = s;
+            }
+        }
 }
 
 // Diagonal preconditioner (applyDiffPrecond_diagonal, comm_diffuse_comp_mod.f90:2186-2235): per (l, m, stokes)

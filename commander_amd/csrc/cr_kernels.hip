@@ -27,17 +27,20 @@ void launch_sqrtS(const CompDev* comps, int ncomp, int lmax_max, const double* s
 
 __global__ void k_band_prep(const CompDev* __restrict__ comps, int ncomp, const double* __restrict__ sx,
                             const double* __restrict__ w, const int* __restrict__ bm_stokes,
-                            double* __restrict__ ast, int nbm, const double* __restrict__ cnorm, int lmax_g) {
+                            double* __restrict__ ast, int nbm, const double* __restrict__ cnorm, int lmax_g,
+                            const double* __restrict__ extra) {
     const int m = blockIdx.y, l = m + blockIdx.x * 256 + threadIdx.x;
     if (l > lmax_g + 1) return;
     const int bm = blockIdx.z;
+    const int64_t na = (int64_t)(lmax_g + 1) * (lmax_g + 1);
     band_prep_elem(comps, ncomp, sx, w + (int64_t)bm * ncomp * (lmax_g + 1), bm_stokes[bm], ast, nbm, bm, cnorm,
-                   lmax_g, m, l);
+                   lmax_g, m, l, extra ? extra + bm * na : nullptr);
 }
 void launch_band_prep(const CompDev* comps, int ncomp, const double* sx, const double* w, const int* bm_stokes,
-                      double* ast, const double* cnorm, int lmax_g, int nbm, hipStream_t s) {
+                      double* ast, const double* cnorm, int lmax_g, int nbm, hipStream_t s, const double* extra) {
     dim3 grid((lmax_g + 2 + 255) / 256, lmax_g + 1, nbm);
-    hipLaunchKernelGGL(k_band_prep, grid, dim3(256), 0, s, comps, ncomp, sx, w, bm_stokes, ast, nbm, cnorm, lmax_g);
+    hipLaunchKernelGGL(k_band_prep, grid, dim3(256), 0, s, comps, ncomp, sx, w, bm_stokes, ast, nbm, cnorm, lmax_g,
+                       extra);
 }
 
 __global__ void k_band_post(const CompDev* __restrict__ comps, int ncomp, const double* __restrict__ part,
@@ -60,18 +63,19 @@ void launch_band_post(const CompDev* comps, int ncomp, int lmax_max, const doubl
 
 __global__ void k_band_prep2(const CompDev* __restrict__ comps, int ncomp, const double* __restrict__ sx,
                              const double* __restrict__ w, int nT, double* __restrict__ st, int npol,
-                             const double* __restrict__ cnorm2, int lmax_g) {
+                             const double* __restrict__ cnorm2, int lmax_g, const double* __restrict__ extra) {
     const int m = blockIdx.y, l = m + blockIdx.x * 256 + threadIdx.x;
     if (l > lmax_g + 1) return;
     const int ip = blockIdx.z;
     const int64_t ws = (int64_t)ncomp * (lmax_g + 1);
+    const int64_t na = (int64_t)(lmax_g + 1) * (lmax_g + 1);
     band_prep2_elem(comps, ncomp, sx, w + (nT + 2 * ip) * ws, w + (nT + 2 * ip + 1) * ws, st, npol, ip, cnorm2, lmax_g,
-                    m, l);
+                    m, l, extra ? extra + (nT + 2 * ip) * na : nullptr, extra ? extra + (nT + 2 * ip + 1) * na : nullptr);
 }
 void launch_band_prep2(const CompDev* comps, int ncomp, const double* sx, const double* w, int nT, double* st, int npol,
-                       const double* cnorm2, int lmax_g, hipStream_t s) {
+                       const double* cnorm2, int lmax_g, hipStream_t s, const double* extra) {
     dim3 grid((lmax_g + 2 + 255) / 256, lmax_g + 1, npol);
-    hipLaunchKernelGGL(k_band_prep2, grid, dim3(256), 0, s, comps, ncomp, sx, w, nT, st, npol, cnorm2, lmax_g);
+    hipLaunchKernelGGL(k_band_prep2, grid, dim3(256), 0, s, comps, ncomp, sx, w, nT, st, npol, cnorm2, lmax_g, extra);
 }
 __global__ void k_band_post2(const CompDev* __restrict__ comps, int ncomp, const double* __restrict__ part2,
                              int64_t pps, int64_t pcs, int nchunk, int npol, const double* __restrict__ w, int nT,
@@ -88,6 +92,31 @@ void launch_band_post2(const CompDev* comps, int ncomp, int lmax_max, const doub
     dim3 grid((lmax_max + 1 + 255) / 256, lmax_max + 1, ncomp);
     hipLaunchKernelGGL(k_band_post2, grid, dim3(256), 0, s, comps, ncomp, part2, pps, pcs, nchunk, npol, w, nT, cnorm2,
                        lmax_g, yc);
+}
+
+__global__ void k_alm_copy(const double* __restrict__ src, int lmax_s, double* __restrict__ dst, int lmax_d,
+                           const double* __restrict__ fl, int accumulate, int lcut) {
+    const int m = blockIdx.y, l = m + blockIdx.x * 256 + threadIdx.x;
+    if (l > lmax_d) return;
+    alm_copy_elem(src, lmax_s, dst, lmax_d, fl, accumulate, lcut, m, l);
+}
+void launch_alm_copy(const double* src, int lmax_s, double* dst, int lmax_d, const double* fl, bool accumulate,
+                     hipStream_t s, int lcut) {
+    dim3 grid((lmax_d + 1 + 255) / 256, lmax_d + 1);
+    hipLaunchKernelGGL(k_alm_copy, grid, dim3(256), 0, s, src, lmax_s, dst, lmax_d, fl, accumulate ? 1 : 0, lcut);
+}
+
+__global__ void k_pinv_prior(const CompDev* __restrict__ comps, int ncomp, const double* __restrict__ Q, int lmax_pre,
+                             int nmaps_pre, const double* __restrict__ x, const double* __restrict__ z,
+                             double* __restrict__ out) {
+    const int m = blockIdx.y, l = m + blockIdx.x * 256 + threadIdx.x;
+    if (l > lmax_pre) return;
+    pinv_prior_elem(comps, ncomp, Q, lmax_pre, nmaps_pre, x, z, out, m, l);
+}
+void launch_pinv_prior(const CompDev* comps, int ncomp, int /*lmax_max*/, const double* Q, int lmax_pre, int nmaps_pre,
+                       const double* x, const double* z, double* out, hipStream_t s) {
+    dim3 grid((lmax_pre + 1 + 255) / 256, lmax_pre + 1);
+    hipLaunchKernelGGL(k_pinv_prior, grid, dim3(256), 0, s, comps, ncomp, Q, lmax_pre, nmaps_pre, x, z, out);
 }
 
 __global__ void k_precond_diag(const CompDev* __restrict__ comps, int ncomp, const double* __restrict__ P,

@@ -112,6 +112,9 @@ int CrSystem::add_band(int nside, int lmax, int nmaps, const double* siN, const 
     std::vector<double> s1(siN, siN + np);
     if (sg_mask) for (int64_t i = 0; i < np; ++i) s1[i] *= sg_mask[i];                         // :304-313 (applied twice = once, mask is 0/1)
     if (sg_mask) B.siN_raw.upload(siN, (size_t)np);
+    B.Nmap_h.resize(np);
+    for (int64_t i = 0; i < np; ++i)                                                            // :288-301
+        B.Nmap_h[i] = siN[i] > 0.0 ? (sg_mask ? sg_mask[i] : 1.0) / (siN[i] * siN[i]) : 0.0;
     B.siN.upload(s1);
     B.mul.upload(mul);
     return (int)bands_.size() - 1;
@@ -141,6 +144,9 @@ int CrSystem::add_comp(int lmax_amp, int nmaps, int lmax_cl, const double* sqrtS
         C.S.assign(S, S + n);
     }
     C.F_mean.assign(F_mean, F_mean + (size_t)bands_.size() * nmaps);
+    C.F_map.resize(bands_.size());
+    C.F_map_nm.assign(bands_.size(), 0);
+    C.mulF.resize(bands_.size());
     return (int)comps_.size() - 1;
 }
 
@@ -206,32 +212,198 @@ void CrSystem::finalize() {
         G.plan = std::make_unique<ShtPlan>(G.nside, G.lmax, rings, B0.has_wring ? B0.wring.data() : nullptr, G.nbm,
                                            G.npol > 0);
         const int64_t np = G.plan->npix_local();
-        std::vector<double> w((size_t)G.nbm * ncomp * (G.lmax + 1), 0.0);
         std::vector<const double*> mp(G.nbm);
+        std::vector<double> bl((size_t)G.nbm * (G.lmax + 1));
         for (int bm = 0; bm < G.nbm; ++bm) {
             const int b = G.bm_band[bm], j = G.bm_stokes[bm];
             Band& B = bands_[b];
             CMDR_REQUIRE((int64_t)B.siN.size() == np * B.nmaps, "siN size does not match the plan's local map");
             mp[bm] = B.mul.get() + (int64_t)j * np;
-            for (int c = 0; c < ncomp; ++c) {
-                const Comp& C = comps_[c];
-                if (!C.d.active || j >= C.d.nmaps) continue;
-                const double F = C.F_mean[b + (size_t)bands_.size() * j];
-                for (int l = 0; l <= std::min(G.lmax, C.d.lmax); ++l)
-                    w[((size_t)bm * ncomp + c) * (G.lmax + 1) + l] = F * B.b_l[l + (size_t)(B.lmax + 1) * j] * B.mb_eff;
-            }
+            for (int l = 0; l <= G.lmax; ++l) bl[(size_t)bm * (G.lmax + 1) + l] = B.b_l[l + (size_t)(B.lmax + 1) * j] * B.mb_eff;
         }
-        G.w.upload(w);
+        G.bl.upload(bl);
         G.bm_stokes_dev.upload(G.bm_stokes);
         G.mul_ptrs.upload(mp);
         for (int b : G.bands) bands_[b].group = g;
     }
+    (void)ncomp;
+    rebuild_weights();
+    rebuild_mixing();
     sx_.alloc(ncr_); yc_.alloc(ncr_); r_.alloc(ncr_); d_.alloc(ncr_); q_.alloc(ncr_); s_.alloc(ncr_); tmp_.alloc(ncr_);
     dot_partial_.alloc(dot_partial_count());
     scal_.alloc(16);
     scal_.zero(stream_);
     sync();
     finalized_ = true;
+}
+
+// w[bm][c][l] = F_mean * b_l * mb_eff for the components on the constant-mixing fast path; 0 for (band, component)
+// pairs with a mixing map (they go through mix_forward / mix_adjoint), inactive components and l beyond either lmax.
+void CrSystem::rebuild_weights() {
+    const int ncomp = (int)comps_.size();
+    for (Group& G : groups_) {
+        std::vector<double> w((size_t)G.nbm * ncomp * (G.lmax + 1), 0.0);
+        for (int bm = 0; bm < G.nbm; ++bm) {
+            const int b = G.bm_band[bm], j = G.bm_stokes[bm];
+            const Band& B = bands_[b];
+            for (int c = 0; c < ncomp; ++c) {
+                const Comp& C = comps_[c];
+                if (!C.d.active || j >= C.d.nmaps || !C.F_map[b].empty()) continue;
+                const double F = C.F_mean[b + (size_t)bands_.size() * j];
+                for (int l = 0; l <= std::min(G.lmax, C.d.lmax); ++l)
+                    w[((size_t)bm * ncomp + c) * (G.lmax + 1) + l] = F * B.b_l[l + (size_t)(B.lmax + 1) * j] * B.mb_eff;
+            }
+        }
+        G.w.upload(w);
+    }
+}
+
+void CrSystem::set_mixing_map(int comp, int band, const double* F, int nmaps) {
+    CMDR_REQUIRE(comp >= 0 && comp < (int)comps_.size() && band >= 0 && band < (int)bands_.size(), "bad comp / band");
+    Comp& C = comps_[comp];
+    if (!F) {
+        C.F_map[band].clear();
+        C.F_map_nm[band] = 0;
+    } else {
+        const int nm = std::min(C.d.nmaps, bands_[band].nmaps);
+        CMDR_REQUIRE(nmaps == nm, "mixing map must have min(component nmaps, band nmaps) columns");
+        CMDR_REQUIRE(nm == 1 || nm == 3, "mixing maps need nmaps = 1 or 3");
+        const int64_t np = band_npix(band);
+        C.F_map[band].assign(F, F + np * nm);
+        C.F_map_nm[band] = nm;
+    }
+    if (finalized_) {
+        sync();
+        rebuild_weights();
+        rebuild_mixing();
+    }
+}
+
+void CrSystem::set_cl_diag(int comp, const double* cl) {
+    CMDR_REQUIRE(comp >= 0 && comp < (int)comps_.size(), "bad comp");
+    Comp& C = comps_[comp];
+    CMDR_REQUIRE(C.d.lmax_cl >= 0 && cl, "component has no C_l");
+    C.cl_diag.assign(cl, cl + (size_t)(C.d.lmax_cl + 1) * C.d.nmaps);
+}
+
+// Batches of (band, component) pairs with a mixing map, per plan: scalar columns first, then (Q,U) pairs, as many
+// per sandwich() call as the plan has map slots.
+void CrSystem::rebuild_mixing() {
+    for (Group& G : groups_) {
+        ShtPlan& P = *G.plan;
+        const int64_t np = P.npix_local(), na = P.nalm();
+        const std::vector<double> pw = P.pixel_weights();
+        G.mix.clear();
+        std::vector<MixCol> T, Pp;
+        for (int c = 0; c < (int)comps_.size(); ++c) {
+            Comp& C = comps_[c];
+            for (int ib = 0; ib < (int)G.bands.size(); ++ib) {
+                const int b = G.bands[ib];
+                if (C.F_map[b].empty()) { C.mulF[b] = DevBuf<double>(); continue; }
+                const int nm = C.F_map_nm[b];
+                std::vector<double> mf((size_t)np * nm);
+                for (int j = 0; j < nm; ++j)
+                    for (int64_t i = 0; i < np; ++i) mf[(size_t)j * np + i] = C.F_map[b][(size_t)j * np + i] * pw[i];
+                C.mulF[b].upload(mf);
+                if (!C.d.active) continue;                      // comm_cr_mod.f90:851-854
+                T.push_back({ib, c, 0});
+                if (nm == 3) {
+                    int ip = 0;
+                    for (int k = 0; k < ib; ++k) if (bands_[G.bands[k]].nmaps == 3) ++ip;
+                    Pp.push_back({G.nT + 2 * ip, c, 1});
+                }
+            }
+        }
+        if (T.empty()) continue;
+        const int cap = P.max_maps();
+        size_t it = 0, ip = 0;
+        while (it < T.size() || ip < Pp.size()) {
+            MixBatch B;
+            int used = 0;
+            while (it < T.size() && used < cap) { B.T.push_back(T[it++]); ++used; }
+            while (ip < Pp.size() && used + 2 <= cap) { B.P.push_back(Pp[ip++]); used += 2; }
+            CMDR_REQUIRE(used > 0, "plan has too few map slots for a polarised mixing pair");
+            std::vector<const double*> mp;
+            for (const MixCol& m : B.T) mp.push_back(comps_[m.comp].mulF[G.bm_band[m.bm]].get());
+            for (const MixCol& m : B.P) {
+                const double* f = comps_[m.comp].mulF[G.bm_band[m.bm]].get();
+                mp.push_back(f + np);
+                mp.push_back(f + 2 * np);
+            }
+            B.mul_ptrs.upload(mp);
+            G.mix.push_back(std::move(B));
+        }
+        G.mix_in.ensure((size_t)cap * na);
+        G.mix_out.ensure((size_t)cap * na);
+        G.E.ensure((size_t)G.nbm * na);
+        G.U.ensure((size_t)G.nbm * na);
+    }
+}
+
+// E[bm] = b_l * sum_{c with a mixing map} YtW F_bc Y (S^1/2 x)_c      (evalDiffuseBand, :2082-2089)
+void CrSystem::mix_forward(Group& G, const double* sx) {
+    ShtPlan& P = *G.plan;
+    const int64_t na = P.nalm();
+    CMDR_HIP_CHECK(hipMemsetAsync(G.E.get(), 0, sizeof(double) * G.nbm * na, stream_));
+    for (MixBatch& B : G.mix) {
+        const int nT = (int)B.T.size(), nP = (int)B.P.size();
+        int k = 0;
+        auto col_in = [&](const MixCol& m, int stokes) {
+            const CompDev& C = comps_[m.comp].d;
+            launch_alm_copy(sx + C.pos + (int64_t)stokes * C.nalm, C.lmax, G.mix_in.get() + (int64_t)k * na, G.lmax, nullptr,
+                            false, stream_);
+            ++k;
+        };
+        for (const MixCol& m : B.T) col_in(m, 0);
+        for (const MixCol& m : B.P) { col_in(m, 1); col_in(m, 2); }
+        P.sandwich(G.mix_in.get(), G.mix_out.get(), B.mul_ptrs.get(), nT, nP, stream_);
+        reduce(G.mix_out.get(), (int64_t)(nT + 2 * nP) * na);
+        k = 0;
+        auto col_out = [&](int bm) {
+            launch_alm_copy(G.mix_out.get() + (int64_t)k * na, G.lmax, G.E.get() + (int64_t)bm * na, G.lmax,
+                            G.bl.get() + (int64_t)bm * (G.lmax + 1), true, stream_);
+            ++k;
+        };
+        for (const MixCol& m : B.T) col_out(m.bm);
+        for (const MixCol& m : B.P) { col_out(m.bm); col_out(m.bm + 1); }
+    }
+}
+
+// yc_c += YtW F_bc Y b_l U[bm]  for the pairs with a mixing map          (projectDiffuseBand, :2153-2158)
+// rhs: cr_computeRHS first cuts the band a_lm to the component's lmax (alm_equal, comm_cr_mod.f90:634) and mixes
+// after that (:640-650); cr_matmulA mixes at the band's lmax and cuts afterwards (projectDiffuseBand).
+void CrSystem::mix_adjoint(Group& G, bool rhs) {
+    ShtPlan& P = *G.plan;
+    const int64_t na = P.nalm();
+    launch_part_to_alm(P.partials(), P.part_map_stride(), P.leg().tri_elems(), P.leg().nchunk, G.U.get(), na,
+                       P.leg().cnorm.get(), G.lmax, G.nT, stream_);
+    if (G.npol)
+        launch_part2_to_alm(P.partials2(), P.part2_pol_stride(), P.leg2().tri4(), P.leg2().nchunk,
+                            G.U.get() + (int64_t)G.nT * na, G.U.get() + (int64_t)(G.nT + 1) * na, 2 * na,
+                            P.leg2().cnorm.get(), G.lmax, G.npol, stream_);
+    reduce(G.U.get(), (int64_t)G.nbm * na);
+    for (MixBatch& B : G.mix) {
+        const int nT = (int)B.T.size(), nP = (int)B.P.size();
+        int k = 0;
+        auto col_in = [&](int bm, int comp) {
+            launch_alm_copy(G.U.get() + (int64_t)bm * na, G.lmax, G.mix_in.get() + (int64_t)k * na, G.lmax,
+                            G.bl.get() + (int64_t)bm * (G.lmax + 1), false, stream_,
+                            rhs ? comps_[comp].d.lmax : (1 << 30));
+            ++k;
+        };
+        for (const MixCol& m : B.T) col_in(m.bm, m.comp);
+        for (const MixCol& m : B.P) { col_in(m.bm, m.comp); col_in(m.bm + 1, m.comp); }
+        P.sandwich(G.mix_in.get(), G.mix_out.get(), B.mul_ptrs.get(), nT, nP, stream_);
+        k = 0;
+        auto col_out = [&](const MixCol& m, int stokes) {
+            const CompDev& C = comps_[m.comp].d;
+            launch_alm_copy(G.mix_out.get() + (int64_t)k * na, G.lmax, yc_.get() + C.pos + (int64_t)stokes * C.nalm, C.lmax,
+                            nullptr, true, stream_);
+            ++k;
+        };
+        for (const MixCol& m : B.T) col_out(m, 0);
+        for (const MixCol& m : B.P) { col_out(m, 1); col_out(m, 2); }
+    }
 }
 
 void CrSystem::reduce(double* v, int64_t n) {
@@ -241,7 +413,7 @@ void CrSystem::reduce(double* v, int64_t n) {
 }
 
 // ------------------------------------------------------------------------------------------------- matvec
-void CrSystem::adjoint_groups_to_yc(bool /*from_maps*/) {
+void CrSystem::adjoint_groups_to_yc(bool from_maps) {
     const int ncomp = (int)comps_.size();
     for (int g = 0; g < (int)groups_.size(); ++g) {
         Group& G = groups_[g];
@@ -257,6 +429,7 @@ void CrSystem::adjoint_groups_to_yc(bool /*from_maps*/) {
             launch_band_post2(comps_dev_.get(), ncomp, lmax_max_, P.partials2(), P.part2_pol_stride(), P.leg2().tri4(),
                               P.leg2().nchunk, G.npol, G.w.get(), G.nT, P.leg2().cnorm.get(), G.lmax, yc_.get(),
                               stream_);
+        if (!G.mix.empty()) mix_adjoint(G, from_maps);
     }
     reduce(yc_.get(), ncr_);
 }
@@ -269,11 +442,13 @@ void CrSystem::matmulA(const double* x, double* y) {
     launch_sqrtS(comps_dev_.get(), ncomp, lmax_max_, smat_.get(), 0, x, nullptr, sx_.get(), false, stream_);
     for (Group& G : groups_) {   // per-band loop :843-954, all bands of a geometry batched
         ShtPlan& P = *G.plan;
+        const double* extra = nullptr;
+        if (!G.mix.empty()) { mix_forward(G, sx_.get()); extra = G.E.get(); }            // varying mixing :2082-2084
         launch_band_prep(comps_dev_.get(), ncomp, sx_.get(), G.w.get(), G.bm_stokes_dev.get(), P.stream(),
-                         P.leg().cnorm.get(), G.lmax, G.nT, stream_);
+                         P.leg().cnorm.get(), G.lmax, G.nT, stream_, extra);
         if (G.npol)
             launch_band_prep2(comps_dev_.get(), ncomp, sx_.get(), G.w.get(), G.nT, P.stream2(), G.npol,
-                              P.leg2().cnorm.get(), G.lmax, stream_);
+                              P.leg2().cnorm.get(), G.lmax, stream_, extra);
         span_begin(0);
         P.synth_from_stream(G.nT, stream_);                                          // Y        :891 (T: spin 0)
         if (G.npol) P.synth2_from_stream(G.npol, G.nT, stream_);                     // (Q,U): spin 2, comm_map_mod.f90:446
@@ -511,11 +686,208 @@ void CrSystem::precond_update_diag() {
             }
     });
     P_.upload(P, stream_);
+    precond_type_ = 0;
     precond_ready_ = true;
 }
 
+// ------------------------------------------------------------------------------------------------- pseudo-inverse
+namespace {
+// Moore-Penrose pseudo-inverse of a small m x n matrix (row-major, m >= n) by one-sided Jacobi SVD; singular values
+// below thr * s_max are dropped (compute_pseudo_inverse, math_tools.f90:234-292: DGESVD, threshold 1e-12).
+// out: n x m row-major.
+void pseudo_inverse(const std::vector<double>& A, int m, int n, double thr, std::vector<double>& out) {
+    std::vector<double> U(A), V((size_t)n * n, 0.0);
+    for (int i = 0; i < n; ++i) V[i * n + i] = 1.0;
+    for (int sweep = 0; sweep < 60; ++sweep) {
+        double off = 0.0;
+        for (int p = 0; p < n; ++p)
+            for (int q = p + 1; q < n; ++q) {
+                double a = 0.0, b = 0.0, c = 0.0;
+                for (int i = 0; i < m; ++i) { a += U[i * n + p] * U[i * n + p]; b += U[i * n + q] * U[i * n + q]; c += U[i * n + p] * U[i * n + q]; }
+                if (c == 0.0) continue;
+                off = std::max(off, std::fabs(c) / std::sqrt(std::max(a * b, 1e-300)));
+                const double zeta = (b - a) / (2.0 * c);
+                const double t = (zeta >= 0.0 ? 1.0 : -1.0) / (std::fabs(zeta) + std::sqrt(1.0 + zeta * zeta));
+                const double cs = 1.0 / std::sqrt(1.0 + t * t), sn = cs * t;
+                for (int i = 0; i < m; ++i) {
+                    const double up = U[i * n + p], uq = U[i * n + q];
+                    U[i * n + p] = cs * up - sn * uq;
+                    U[i * n + q] = sn * up + cs * uq;
+                }
+                for (int i = 0; i < n; ++i) {
+                    const double vp = V[i * n + p], vq = V[i * n + q];
+                    V[i * n + p] = cs * vp - sn * vq;
+                    V[i * n + q] = sn * vp + cs * vq;
+                }
+            }
+        if (off < 1e-15) break;
+    }
+    std::vector<double> sv(n);
+    double smax = 0.0;
+    for (int j = 0; j < n; ++j) {
+        double a = 0.0;
+        for (int i = 0; i < m; ++i) a += U[i * n + j] * U[i * n + j];
+        sv[j] = std::sqrt(a);
+        smax = std::max(smax, sv[j]);
+    }
+    out.assign((size_t)n * m, 0.0);
+    for (int j = 0; j < n; ++j) {
+        if (!(sv[j] > thr * smax) || sv[j] == 0.0) continue;
+        const double inv2 = 1.0 / (sv[j] * sv[j]);          // V (1/s) (U_j / s)^T
+        for (int r = 0; r < n; ++r)
+            for (int i = 0; i < m; ++i) out[(size_t)r * m + i] += V[r * n + j] * inv2 * U[i * n + j];
+    }
+}
+}  // namespace
+
+void CrSystem::precond_init_pseudoinv() {
+    CMDR_REQUIRE(finalized_, "finalize first");
+    for (Group& G : groups_) {
+        ShtPlan& P = *G.plan;
+        const int64_t np = P.npix_local(), na = P.nalm();
+        const std::vector<double> pw = P.pixel_weights();
+        DevBuf<double> m2((size_t)2 * np), alm((size_t)2 * na), ones((size_t)2 * np), sums(2);
+        { std::vector<double> o((size_t)2 * np, 1.0); ones.upload(o); }
+        std::vector<const double*> mp(G.nbm);
+        for (int b : G.bands) {
+            Band& B = bands_[b];
+            B.alpha_nu.assign(B.nmaps, 0.0);
+            const double* sraw = B.siN_raw.size() ? B.siN_raw.get() : B.siN.get();
+            auto alpha_of = [&](int64_t n) {          // sqrt(sum tau^2 / sum tau)  (comm_N_rms_mod.f90:225-246)
+                launch_dot(m2.get(), ones.get(), n, dot_partial_.get(), sums.get(), 0, false, stream_);
+                launch_dot(m2.get(), m2.get(), n, dot_partial_.get(), sums.get(), 1, false, stream_);
+                reduce(sums.get(), 2);
+                double h[2];
+                sync();
+                CMDR_HIP_CHECK(hipMemcpy(h, sums.get(), sizeof(h), hipMemcpyDeviceToHost));
+                return h[0] > 0.0 ? std::sqrt(h[1] / h[0]) : 0.0;
+            };
+            // tau = Y Yt siN^2  (:221-223)
+            launch_pix(0, sraw, sraw, nullptr, m2.get(), np, stream_);
+            P.map2alm(m2.get(), np, alm.get(), na, 1, false, stream_);
+            reduce(alm.get(), na);
+            P.alm2map(alm.get(), na, m2.get(), np, 1, false, stream_);
+            B.alpha_nu[0] = alpha_of(np);
+            if (B.nmaps == 3) {
+                launch_pix(0, sraw + np, sraw + np, nullptr, m2.get(), 2 * np, stream_);
+                P.map2alm_spin2(m2.get(), m2.get() + np, alm.get(), alm.get() + na, false, stream_);
+                reduce(alm.get(), 2 * na);
+                P.alm2map_spin2(alm.get(), alm.get() + na, m2.get(), m2.get() + np, false, stream_);
+                B.alpha_nu[1] = B.alpha_nu[2] = alpha_of(2 * np);
+            }
+            // T operator of the preconditioner: WY . N . YtW  ->  pixel multiplier w^2 rms^2
+            std::vector<double> mulP(B.Nmap_h.size());
+            for (int j = 0; j < B.nmaps; ++j)
+                for (int64_t i = 0; i < np; ++i) mulP[(size_t)j * np + i] = B.Nmap_h[(size_t)j * np + i] * pw[i] * pw[i];
+            B.mulP.upload(mulP);
+        }
+        for (int bm = 0; bm < G.nbm; ++bm) mp[bm] = bands_[G.bm_band[bm]].mulP.get() + (int64_t)G.bm_stokes[bm] * np;
+        G.mulP_ptrs.upload(mp);
+    }
+    lmax_pre_ = -1;
+    nmaps_pre_ = 0;
+    for (const Comp& C : comps_) { lmax_pre_ = std::max(lmax_pre_, C.d.lmax); nmaps_pre_ = std::max(nmaps_pre_, C.d.nmaps); }
+    pinv_init_ = true;
+    precond_ready_ = false;
+}
+
+void CrSystem::precond_update_pseudoinv() {
+    CMDR_REQUIRE(pinv_init_, "precond_init_pseudoinv first");
+    const int nb = (int)bands_.size(), npre = (int)comps_.size(), L1 = lmax_pre_ + 1;
+    // pinv(U) per (stokes, l): [j][l][npre][nb + npre]
+    std::vector<double> PI((size_t)nmaps_pre_ * L1 * npre * (nb + npre), 0.0);
+    host_parallel_for(L1, [&](int l) {
+        std::vector<double> mat, inv;
+        for (int j = 0; j < nmaps_pre_; ++j) {
+            mat.assign((size_t)(nb + npre) * npre, 0.0);
+            for (int q = 0; q < nb; ++q) {
+                const Band& B = bands_[q];
+                if (l > B.lmax || j >= B.nmaps) continue;
+                for (int k = 0; k < npre; ++k) {
+                    const Comp& C = comps_[k];
+                    if (l > C.d.lmax || j >= C.d.nmaps || !C.d.active) continue;
+                    double v = B.alpha_nu[j] * B.b_l[l + (size_t)(B.lmax + 1) * j] * C.F_mean[q + (size_t)nb * j];
+                    if (C.d.lmax_cl >= 0) {                                      // sqrt(getCl(l, j))  :1591-1593
+                        double cl = 0.0;
+                        if (l <= C.d.lmax_cl)
+                            cl = C.cl_diag.empty() ? C.S[j + (size_t)C.d.nmaps * (j + (size_t)C.d.nmaps * l)]
+                                                   : C.cl_diag[l + (size_t)(C.d.lmax_cl + 1) * j];
+                        v *= std::sqrt(cl);
+                    }
+                    mat[(size_t)q * npre + k] = v;
+                }
+            }
+            for (int k = 0; k < npre; ++k) {                                     // prior section :1610-1614
+                const Comp& C = comps_[k];
+                if (C.d.lmax_cl < 0 || l > C.d.lmax || !C.d.active) continue;
+                mat[(size_t)(nb + k) * npre + k] = 1.0;
+            }
+            pseudo_inverse(mat, nb + npre, npre, 1e-12, inv);
+            std::copy(inv.begin(), inv.end(), PI.begin() + ((size_t)j * L1 + l) * npre * (nb + npre));
+        }
+    });
+    auto pin = [&](int j, int l, int k, int col) { return PI[(((size_t)j * L1 + l) * npre + k) * (nb + npre) + col]; };
+    for (Group& G : groups_) {
+        std::vector<double> wi((size_t)G.nbm * npre * (G.lmax + 1), 0.0), wo(wi.size(), 0.0);
+        for (int bm = 0; bm < G.nbm; ++bm) {
+            const int b = G.bm_band[bm], j = G.bm_stokes[bm];
+            const double a2 = bands_[b].alpha_nu[j] * bands_[b].alpha_nu[j];
+            for (int k = 0; k < npre; ++k)
+                for (int l = 0; l <= std::min(G.lmax, lmax_pre_); ++l) {
+                    const double v = j < nmaps_pre_ ? pin(j, l, k, b) : 0.0;
+                    wi[((size_t)bm * npre + k) * (G.lmax + 1) + l] = v;
+                    wo[((size_t)bm * npre + k) * (G.lmax + 1) + l] = v * a2;   // :2303-2305
+                }
+        }
+        G.w_pin.upload(wi);
+        G.w_pout.upload(wo);
+    }
+    std::vector<double> Q((size_t)nmaps_pre_ * npre * npre * L1, 0.0);             // B B^t, B = prior columns
+    for (int j = 0; j < nmaps_pre_; ++j)
+        for (int l = 0; l < L1; ++l)
+            for (int k1 = 0; k1 < npre; ++k1)
+                for (int k2 = 0; k2 < npre; ++k2) {
+                    double sacc = 0.0;
+                    for (int t = 0; t < npre; ++t) sacc += pin(j, l, k1, nb + t) * pin(j, l, k2, nb + t);
+                    Q[(((size_t)j * npre + k1) * npre + k2) * L1 + l] = sacc;
+                }
+    Qprior_.upload(Q, stream_);
+    precond_type_ = 1;
+    precond_ready_ = true;
+}
+
+// applyDiffPrecond_pseudoinv (comm_diffuse_comp_mod.f90:2238-2380)
+void CrSystem::apply_pseudoinv(const double* x, double* y) {
+    const int ncomp = (int)comps_.size();
+    for (int g = 0; g < (int)groups_.size(); ++g) {
+        Group& G = groups_[g];
+        ShtPlan& P = *G.plan;
+        launch_band_prep(comps_dev_.get(), ncomp, x, G.w_pin.get(), G.bm_stokes_dev.get(), P.stream(),
+                         P.leg().cnorm.get(), G.lmax, G.nT, stream_);                   // (U^+)^t   :2279-2291
+        if (G.npol)
+            launch_band_prep2(comps_dev_.get(), ncomp, x, G.w_pin.get(), G.nT, P.stream2(), G.npol,
+                              P.leg2().cnorm.get(), G.lmax, stream_);
+        P.synth_from_stream(G.nT, stream_);                                              // WY        :2295
+        if (G.npol) P.synth2_from_stream(G.npol, G.nT, stream_);
+        P.rings(2, nullptr, 0, G.mulP_ptrs.get(), false, G.nbm, stream_);                // N         :2297
+        P.adjoint_to_partials(G.nT, false, stream_);                                     // YtW       :2299
+        if (G.npol) P.adjoint2_to_partials(G.npol, G.nT, stream_);
+        launch_band_post(comps_dev_.get(), ncomp, lmax_max_, P.partials(), P.part_map_stride(), P.leg().tri_elems(),
+                         P.leg().nchunk, G.nT, G.bm_stokes_dev.get(), G.w_pout.get(), P.leg().cnorm.get(), G.lmax,
+                         yc_.get(), g > 0, stream_);                                     // alpha^2, U^+  :2303-2322
+        if (G.npol)
+            launch_band_post2(comps_dev_.get(), ncomp, lmax_max_, P.partials2(), P.part2_pol_stride(), P.leg2().tri4(),
+                              P.leg2().nchunk, G.npol, G.w_pout.get(), G.nT, P.leg2().cnorm.get(), G.lmax, yc_.get(),
+                              stream_);
+    }
+    reduce(yc_.get(), ncr_);
+    launch_pinv_prior(comps_dev_.get(), ncomp, lmax_max_, Qprior_.get(), lmax_pre_, nmaps_pre_, x, yc_.get(), y,
+                      stream_);                                                          // prior terms :2328-2372
+}
+
 void CrSystem::invM(const double* x, double* y) {
-    CMDR_REQUIRE(precond_ready_, "preconditioner not initialised (precond_init_diag + precond_update_diag)");
+    CMDR_REQUIRE(precond_ready_, "preconditioner not initialised (precond_init_* + precond_update_*)");
+    if (precond_type_ == 1) { apply_pseudoinv(x, y); return; }
     launch_precond_diag(comps_dev_.get(), (int)comps_.size(), P_.get(), lmax_pre_, nmaps_pre_, x, y, stream_);
 }
 

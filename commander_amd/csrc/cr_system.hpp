@@ -7,8 +7,9 @@
 //   M^-1 = block-diagonal in (l, m, stokes) over components        cr_invM :1026-1077, diagonal type
 //   PCG (Shewchuk form)                                            solve_cr_eqn_by_CG :48-406
 //
-// Scope: diffuse components with constant mixing (F_mean fast path, comm_diffuse_comp_mod.f90:2077-2080), white
-// per-pixel noise (comm_N_rms), spin-0 columns.
+// Scope: diffuse components with constant mixing (F_mean fast path, comm_diffuse_comp_mod.f90:2077-2080) or spatially
+// varying mixing (Y . F . YtW branch, :2082-2084, :2155-2157), white per-pixel noise (comm_N_rms), T and T,Q,U bands;
+// diagonal and pseudo-inverse preconditioners.
 #pragma once
 #include <memory>
 #include <vector>
@@ -41,6 +42,10 @@ class CrSystem {
     int add_comp(int lmax_amp, int nmaps, int lmax_cl, const double* sqrtS, const double* sqrtInvS,
                  const double* S, const double* F_mean, int active);
     void finalize();
+    // F(band,0)%p%map of a component with spatially varying mixing: npix_local x nmaps (nmaps = min of the band's and
+    // the component's), or nullptr to go back to the F_mean fast path.  Callable before or after finalize.
+    void set_mixing_map(int comp, int band, const double* F, int nmaps);
+    void set_cl_diag(int comp, const double* cl);   // getCl(l, p): (lmax_cl+1) x nmaps, for the pseudo-inverse U
     void set_allreduce(AllreduceFn fn, void* user) { allreduce_ = fn; allreduce_user_ = user; }
     void set_only_pol(bool v) { only_pol_ = v; }
 
@@ -52,6 +57,9 @@ class CrSystem {
 
     void precond_init_diag();     // initDiffPrecond_diagonal + compute_invN_lm
     void precond_update_diag();   // updateDiffPrecond_diagonal
+    void precond_init_pseudoinv();    // alpha_nu (comm_N_rms_mod.f90:217-246) and the N maps of the T operator
+    void precond_update_pseudoinv();  // updateDiffPrecond_pseudoinv (comm_diffuse_comp_mod.f90:1560-1658)
+    const std::vector<double>& alpha_nu(int band) const { return bands_[band].alpha_nu; }
     const double* invN_diag_dev(int band) const { return bands_[band].invN_diag.get(); }
 
     // all pointers below are device pointers
@@ -80,11 +88,23 @@ class CrSystem {
         std::vector<double> invN_diag_h;
         std::vector<double> wring;
         bool has_wring = false;
+        std::vector<double> Nmap_h;         // rms^2 (* mask), 0 where siN = 0: comm_N_rms%N (comm_N_rms_mod.f90:288-301)
+        DevBuf<double> mulP;                // (W_ring 4pi/Npix)^2 * Nmap: WY . N . YtW of the pseudo-inverse precond
+        std::vector<double> alpha_nu;       // [nmaps]
     };
     struct Comp {
         CompDev d;
         std::vector<double> sqrtS, sqrtInvS, S;  // nmaps x nmaps x (lmax_cl+1), Fortran order
         std::vector<double> F_mean;              // nband x nmaps, column-major (F_mean(band,0,stokes))
+        std::vector<std::vector<double>> F_map;  // [nband]: empty, or npix_local x nm host copy of F(band,0)%p%map
+        std::vector<int> F_map_nm;
+        std::vector<DevBuf<double>> mulF;        // [nband]: F * W_ring 4pi/Npix (device), built by rebuild_mixing
+        std::vector<double> cl_diag;             // optional getCl table
+    };
+    struct MixCol { int bm, comp, stokes; };     // one scalar column / first column of a (Q,U) pair of a mixing batch
+    struct MixBatch {
+        std::vector<MixCol> T, P;
+        DevBuf<const double*> mul_ptrs;          // [nT + 2 nP]
     };
     struct Group {
         int nside, lmax, nbm = 0;
@@ -95,7 +115,20 @@ class CrSystem {
         DevBuf<int> bm_stokes_dev;
         DevBuf<const double*> mul_ptrs;     // [nbm]
         DevBuf<double> tmpmap;              // [nbm][npix_local] (RHS only; allocated lazily)
+        DevBuf<double> bl;                  // [nbm][lmax+1]  b_l * mb_eff of each band map
+        // spatially varying mixing
+        std::vector<MixBatch> mix;
+        DevBuf<double> mix_in, mix_out;     // [max_maps][nalm]
+        DevBuf<double> E, U;                // [nbm][nalm]: mixed band signal in, Yt N^-1 Y output
+        // pseudo-inverse preconditioner
+        DevBuf<double> w_pin, w_pout;       // [nbm][ncomp][lmax+1]
+        DevBuf<const double*> mulP_ptrs;    // [nbm]
     };
+    void rebuild_weights();
+    void rebuild_mixing();
+    void mix_forward(Group& G, const double* sx);
+    void mix_adjoint(Group& G, bool rhs);
+    void apply_pseudoinv(const double* x, double* y);
     void adjoint_groups_to_yc(bool from_maps);
     struct Span { hipEvent_t a, b; int kind; };
     void span_begin(int kind);
@@ -124,6 +157,9 @@ class CrSystem {
     std::vector<double> M0_;                // [nmaps_pre][npre][npre][ntri(lmax_pre)]
     DevBuf<double> P_;
     bool precond_ready_ = false;
+    int precond_type_ = 0;                  // 0 diagonal, 1 pseudo-inverse
+    DevBuf<double> Qprior_;                 // [nmaps_pre][npre][npre][lmax_pre+1]
+    bool pinv_init_ = false;
     AllreduceFn allreduce_ = nullptr;
     void* allreduce_user_ = nullptr;
 };

@@ -42,18 +42,24 @@ void launch_part2_to_alm(const double* part, int64_t part_pol_stride, int64_t pc
 // ---- CR solver streams (cr_kernels.hip)
 void launch_sqrtS(const CompDev* comps, int ncomp, int lmax_max, const double* smat, int kind, const double* in,
                   const double* add, double* out, bool pass_inactive, hipStream_t s);
+// extra (optional): [nbm] packed a_lm(lmax_g) columns added to the band signal (varying-mixing components)
 void launch_band_prep(const CompDev* comps, int ncomp, const double* sx, const double* w, const int* bm_stokes,
-                      double* ast, const double* cnorm, int lmax_g, int nbm, hipStream_t s);
+                      double* ast, const double* cnorm, int lmax_g, int nbm, hipStream_t s,
+                      const double* extra = nullptr);
 void launch_band_post(const CompDev* comps, int ncomp, int lmax_max, const double* part, int64_t pms, int64_t pcs,
                       int nchunk, int nbm, const int* bm_stokes, const double* w, const double* cnorm, int lmax_g,
                       double* yc, bool accumulate, hipStream_t s);
 void launch_band_prep2(const CompDev* comps, int ncomp, const double* sx, const double* w, int nT, double* st, int npol,
-                       const double* cnorm2, int lmax_g, hipStream_t s);
+                       const double* cnorm2, int lmax_g, hipStream_t s, const double* extra = nullptr);
 void launch_band_post2(const CompDev* comps, int ncomp, int lmax_max, const double* part2, int64_t pps, int64_t pcs,
                        int nchunk, int npol, const double* w, int nT, const double* cnorm2, int lmax_g, double* yc,
                        hipStream_t s);
 void launch_precond_diag(const CompDev* comps, int ncomp, const double* P, int lmax_pre, int nmaps_pre,
                          const double* in, double* out, hipStream_t s);
+void launch_alm_copy(const double* src, int lmax_s, double* dst, int lmax_d, const double* fl, bool accumulate,
+                     hipStream_t s, int lcut = 1 << 30);
+void launch_pinv_prior(const CompDev* comps, int ncomp, int lmax_max, const double* Q, int lmax_pre, int nmaps_pre,
+                       const double* x, const double* z, double* out, hipStream_t s);
 void launch_fill_gl(double* ph, const double* wn, const double* ws, int npair_pad, int lmax, hipStream_t s);
 void launch_part_to_diag(const double* part, int64_t pcs, int nchunk, const double* cnorm, double* out, int lmax,
                          hipStream_t s);

@@ -148,6 +148,17 @@ void ShtPlan::map2alm(const double* d_map, int64_t map_stride, double* d_alm, in
     }
 }
 
+std::vector<double> ShtPlan::pixel_weights() const {
+    std::vector<double> w((size_t)T_.ring.npix_local, 0.0);
+    for (const RingPairDesc& d : T_.ring.pairs) {
+        for (int k = 0; k < d.nphi; ++k) {
+            w[d.startN + k] = d.wgt;
+            if (d.startS >= 0) w[d.startS + k] = d.wgt;
+        }
+    }
+    return w;
+}
+
 Leg2Args ShtPlan_leg2_args(const Legendre2Dev& L, const double* x) {
     Leg2Args A;
     A.lmax = L.lmax;
@@ -189,6 +200,32 @@ void ShtPlan::map2alm_spin2(const double* d_Q, const double* d_U, double* d_E, d
     adjoint2_to_partials(1, 0, s);
     launch_part2_to_alm(part2_.get(), part2_pol_stride(), leg2_.tri4(), leg2_.nchunk, d_E, d_B, 0, leg2_.cnorm.get(),
                         T_.lmax, 1, s);
+}
+
+void ShtPlan::sandwich(const double* d_in, double* d_out, const double* const* d_mul, int nT, int npol,
+                       hipStream_t s) {
+    CMDR_REQUIRE(nT + 2 * npol <= max_maps_, "sandwich: more columns than the plan was sized for");
+    CMDR_REQUIRE(npol == 0 || pol_, "plan was created without polarisation");
+    const int64_t na = nalm();
+    if (nT) {
+        launch_alm_to_stream(d_in, na, ast_.get(), leg_.cnorm.get(), T_.lmax, nT, s);
+        synth_from_stream(nT, s);
+    }
+    if (npol) {
+        launch_alm2_to_stream(d_in + nT * na, d_in + (nT + 1) * na, 2 * na, st2_.get(), npol, leg2_.cnorm.get(), T_.lmax, s);
+        synth2_from_stream(npol, nT, s);
+    }
+    rings(2, nullptr, 0, d_mul, false, nT + 2 * npol, s);
+    if (nT) {
+        adjoint_to_partials(nT, false, s);
+        launch_part_to_alm(part_.get(), part_map_stride(), leg_.tri_elems(), leg_.nchunk, d_out, na, leg_.cnorm.get(),
+                           T_.lmax, nT, s);
+    }
+    if (npol) {
+        adjoint2_to_partials(npol, nT, s);
+        launch_part2_to_alm(part2_.get(), part2_pol_stride(), leg2_.tri4(), leg2_.nchunk, d_out + nT * na,
+                            d_out + (nT + 1) * na, 2 * na, leg2_.cnorm.get(), T_.lmax, npol, s);
+    }
 }
 
 }  // namespace cmdr

@@ -62,6 +62,14 @@ class ShtPlan {
     void map2alm(const double* d_map, int64_t map_stride, double* d_alm, int64_t alm_stride, int nmaps,
                  bool weighted, hipStream_t s);
 
+    // y_k = Yt diag(mul_k) Y x_k with the map never leaving LDS: nT scalar columns followed by npol (E,B) pairs whose
+    // (Q,U) maps take mul_{nT+2i}, mul_{nT+2i+1}.  d_in / d_out: nT + 2 npol packed a_lm columns (stride nalm());
+    // d_mul: device array of nT + 2 npol device map pointers.  Ring weights (YtW / WY) are folded into mul by the
+    // caller (pixel_weights()).  Needs nT + 2 npol <= max_maps.
+    void sandwich(const double* d_in, double* d_out, const double* const* d_mul, int nT, int npol, hipStream_t s);
+    // W_ring * 4 pi / Npix for every pixel of the local map (host)
+    std::vector<double> pixel_weights() const;
+
     // Building blocks used by the fused CR matvec.
     double* stream() { return ast_.get(); }                // [max_maps][tri_elems]
     double* phases() { return ph_.get(); }                 // [max_maps][ph_elems]

@@ -61,6 +61,11 @@ def _sig(L):
     L.cmdr_precond_init_diag.argtypes = [c_vp]
     L.cmdr_precond_update_diag.argtypes = [c_vp]
     L.cmdr_get_invN_diag.argtypes = [c_vp, c_int, dp]
+    L.cmdr_precond_init_pseudoinv.argtypes = [c_vp]
+    L.cmdr_precond_update_pseudoinv.argtypes = [c_vp]
+    L.cmdr_get_alpha_nu.argtypes = [c_vp, c_int, dp]
+    L.cmdr_comp_set_mixing_map.argtypes = [c_vp, c_int, c_int, dp, c_int]
+    L.cmdr_comp_set_cl_diag.argtypes = [c_vp, c_int, dp]
     L.cmdr_matmulA.argtypes = [c_vp, dp, dp]
     L.cmdr_invM.argtypes = [c_vp, dp, dp]
     L.cmdr_matmulA_dev.argtypes = [c_vp, c_vp, c_vp]

@@ -25,7 +25,31 @@ CONFIGS = {
     "cfg3": dict(nside=1024, lmax=2000, nu=PLANCK_NU, fwhm=PLANCK_FWHM, comps=["cmb"]),
     # configs[3]: polarised T/E/B CMB-only at the SHT-roofline geometry
     "cfg4": dict(nside=2048, lmax=4000, nu=[143.0], fwhm=[7.3], comps=["cmb"], pol=True),
+    # configs[4]: BeyondPlanck-like full diffuse model; synchrotron and dust have spatially varying spectral indices
+    # (Y . F . YtW mixing branch), free-free and AME constant ones; pseudo-inverse preconditioner territory
+    "cfg5": dict(nside=1024, lmax=2000, nu=PLANCK_NU, fwhm=PLANCK_FWHM, comps=["cmb", "synch", "dust", "ff", "ame"],
+                 varying=["synch", "dust"]),
 }
+
+H_OVER_K = 0.0479924466  # K / GHz
+
+
+def mixing(name, nu, z):
+    """Synthetic mixing matrix F_nu(p) of a component (relative to its reference frequency); z = cos(theta) of the
+    pixels, or None for the spatially constant version (F_mean)."""
+    zz = 0.0 if z is None else z
+    if name == "cmb":
+        return 1.0 + 0.0 * zz
+    if name == "synch":
+        return (nu / 30.0) ** (-3.1 + 0.1 * zz)
+    if name == "dust":   # modified blackbody, beta_d = 1.55 + 0.05 cos(theta), T_d = 19.6 K, nu_ref = 545 GHz
+        x, x0 = H_OVER_K * nu / 19.6, H_OVER_K * 545.0 / 19.6
+        return (nu / 545.0) ** (1.55 + 0.05 * zz + 1.0) * (np.exp(x0) - 1.0) / (np.exp(x) - 1.0)
+    if name == "ff":
+        return (nu / 40.0) ** -2.14 + 0.0 * zz
+    if name == "ame":
+        return np.exp(-0.5 * (np.log(nu / 22.0) / 0.6) ** 2) + 0.0 * zz
+    raise ValueError(name)
 
 
 def gaussbeam(fwhm_arcmin, lmax):
@@ -44,6 +68,12 @@ def comp_Dl(name, lmax):
         D = np.full(lmax + 1, 1000.0)
     elif name == "synch":
         D = 100.0 * (np.maximum(l, 1.0) / 80.0) ** -2.5
+    elif name == "dust":
+        D = 300.0 * (np.maximum(l, 1.0) / 80.0) ** -2.6
+    elif name == "ff":
+        D = 30.0 * (np.maximum(l, 1.0) / 80.0) ** -2.2
+    elif name == "ame":
+        D = 30.0 * (np.maximum(l, 1.0) / 80.0) ** -2.4
     else:
         raise ValueError(name)
     D[0] = D[1] if lmax >= 1 else D[0]
@@ -90,12 +120,15 @@ def make_problem(cfg, nside=None, lmax=None, comp_lmax=None, pixels=None, pol=No
             tt = Dl[:, 0]
             Dl = np.stack([tt, 0.01 * tt * pm, 0.0 * tt, 1e-3 * tt * pm, 0.0 * tt, 1e-4 * tt * pm], axis=1)
         sq, isq, S = _cl.update_S(Dl, nm)
-        if name == "cmb":
-            F = np.ones((len(bands), nm))
-        else:
-            F = np.repeat(np.array([(b["nu"] / 30.0) ** -3.1 for b in bands])[:, None], nm, axis=1)
-        comps.append(dict(name=name, lmax=cl_lmax, nmaps=nm, F_mean=F, sqrtS_mat=sq, sqrtInvS_mat=isq, S_mat=S,
-                          Dl=Dl if pol else Dl[:, 0], active=True))
+        F = np.repeat(np.array([float(mixing(name, b["nu"], None)) for b in bands])[:, None], nm, axis=1)
+        comp = dict(name=name, lmax=cl_lmax, nmaps=nm, F_mean=F, sqrtS_mat=sq, sqrtInvS_mat=isq, S_mat=S,
+                    Dl=Dl if pol else Dl[:, 0], active=True)
+        if name in c.get("varying", []):
+            zl = z if pixels is None else z[pixels]
+            comp["F_map"] = {ib: np.repeat(mixing(name, b["nu"], zl)[:, None], nm, axis=1) for ib, b in enumerate(bands)}
+            # F_mean = full-sky pixel average of the map (comm_diffuse_comp_mod.f90:1991-1999)
+            comp["F_mean"] = np.repeat(np.array([mixing(name, b["nu"], z).mean() for b in bands])[:, None], nm, axis=1)
+        comps.append(comp)
     return dict(bands=bands, comps=comps, nside=nside, lmax=lmax, pixels=pixels)
 
 

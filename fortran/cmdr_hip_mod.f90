@@ -124,6 +124,34 @@ module cmdr_hip_mod
        integer(c_int)     :: ierr
      end function cmdr_precond_update_diag
 
+     function cmdr_precond_init_pseudoinv(ctx) bind(c, name='cmdr_precond_init_pseudoinv') result(ierr)
+       import :: c_int, c_ptr
+       type(c_ptr), value :: ctx
+       integer(c_int)     :: ierr
+     end function cmdr_precond_init_pseudoinv
+
+     function cmdr_precond_update_pseudoinv(ctx) bind(c, name='cmdr_precond_update_pseudoinv') result(ierr)
+       import :: c_int, c_ptr
+       type(c_ptr), value :: ctx
+       integer(c_int)     :: ierr
+     end function cmdr_precond_update_pseudoinv
+
+     ! F(band,0)%p%map of a component with spatially varying mixing; F = c_null_ptr returns to the F_mean path
+     function cmdr_comp_set_mixing_map(ctx, comp, band, F, nmaps) bind(c, name='cmdr_comp_set_mixing_map') result(ierr)
+       import :: c_int, c_ptr
+       type(c_ptr),    value :: ctx, F
+       integer(c_int), value :: comp, band, nmaps
+       integer(c_int)        :: ierr
+     end function cmdr_comp_set_mixing_map
+
+     function cmdr_comp_set_cl_diag(ctx, comp, cl) bind(c, name='cmdr_comp_set_cl_diag') result(ierr)
+       import :: c_int, c_ptr, c_double
+       type(c_ptr),    value      :: ctx
+       integer(c_int), value      :: comp
+       real(c_double), intent(in) :: cl(*)
+       integer(c_int)             :: ierr
+     end function cmdr_comp_set_cl_diag
+
      function cmdr_matmulA(ctx, x, y) bind(c, name='cmdr_matmulA') result(ierr)
        import :: c_int, c_ptr, c_double
        type(c_ptr),    value       :: ctx

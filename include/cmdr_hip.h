@@ -73,7 +73,7 @@ int cmdr_sht_execute_spin2_dev(cmdr_sht_plan* plan, int job, double* almE_dev, d
 
 /* ------------------------------------------------------------------------------------------------
  * CR level: the constrained-realization system of commander3/src/comm_cr_mod.f90 for diffuse components with
- * constant mixing (F_mean) and white per-pixel noise, spin-0 columns.  Call order:
+ * constant (F_mean) or spatially varying (F map) mixing and white per-pixel noise; T and T,Q,U bands.  Call order:
  *   cmdr_ctx_create -> [cmdr_ctx_set_rings] -> cmdr_band_add (every band, in data(i) order) ->
  *   cmdr_comp_add (every diffuse component, in compList order) -> cmdr_finalize ->
  *   cmdr_precond_init_diag -> cmdr_precond_update_diag -> cmdr_compute_rhs / cmdr_solve / cmdr_matmulA / cmdr_invM
@@ -106,6 +106,15 @@ int cmdr_band_add(cmdr_ctx* ctx, int nside, int lmax, int nmaps, const double* s
 int cmdr_comp_add(cmdr_ctx* ctx, int lmax_amp, int nmaps, int lmax_cl, const double* sqrtS_mat,
                   const double* sqrtInvS_mat, const double* S_mat, const double* F_mean, int active);
 int cmdr_finalize(cmdr_ctx* ctx);
+/* Spatially varying mixing matrix F(band,0)%p%map of one component at one band (producer: updateDiffuseMixmat,
+ * comm_diffuse_comp_mod.f90:1662-2023; stays on the Fortran side): npix_local x nmaps, nmaps = min(component, band).
+ * The pair then takes the Y . F . YtW branch of evalDiffuseBand / projectDiffuseBand / cr_computeRHS
+ * (:2082-2084, :2155-2157, comm_cr_mod.f90:640-650) instead of the F_mean fast path.  F = NULL returns to F_mean.
+ * May be called before or after cmdr_finalize, and again after every mixing-matrix update. */
+int cmdr_comp_set_mixing_map(cmdr_ctx* ctx, int comp, int band, const double* F, int nmaps);
+/* Optional comm_Cl%getCl(l, p) table [(lmax_cl+1) x nmaps] used by the pseudo-inverse preconditioner
+ * (comm_Cl_mod.f90:1440-1456: D_l 2pi/(l(l+1)) without the RJ2unit factors); default: S_mat(p,p,l). */
+int cmdr_comp_set_cl_diag(cmdr_ctx* ctx, int comp, const double* cl);
 int64_t cmdr_ncr(const cmdr_ctx* ctx);                    /* comm_cr_utils.f90:28 ncr */
 int64_t cmdr_band_npix(const cmdr_ctx* ctx, int band);    /* local pixels per Stokes column */
 
@@ -113,6 +122,13 @@ int64_t cmdr_band_npix(const cmdr_ctx* ctx, int band);    /* local pixels per St
  * then updateDiffPrecond_diagonal (:1313-1557). */
 int cmdr_precond_init_diag(cmdr_ctx* ctx);
 int cmdr_precond_update_diag(cmdr_ctx* ctx);
+/* Pseudo-inverse preconditioner, cg_precond = 'pseudoinv': alpha_nu of every band (comm_N_rms_mod.f90:217-246),
+ * then updateDiffPrecond_pseudoinv (comm_diffuse_comp_mod.f90:1560-1658; SVD pseudo-inverse math_tools.f90:234-292).
+ * cr_invM then runs applyDiffPrecond_pseudoinv (:2238-2380).  Whichever of the two update calls ran last selects the
+ * preconditioner type used by cmdr_invM / cmdr_solve. */
+int cmdr_precond_init_pseudoinv(cmdr_ctx* ctx);
+int cmdr_precond_update_pseudoinv(cmdr_ctx* ctx);
+int cmdr_get_alpha_nu(cmdr_ctx* ctx, int band, double* out_host /* [nmaps] */);
 /* copy out data(band)%N%invN_diag%alm (nalm x nmaps) -- for parity tests */
 int cmdr_get_invN_diag(cmdr_ctx* ctx, int band, double* out_host);
 

@@ -45,6 +45,21 @@ def lib():
     return _LIB
 
 
+def _threads(nthreads, nside):
+    """OpenMP team size: the GPU boxes expose far more hardware threads than this job's CPU share (16), and a full
+    team per small transform costs more in fork/join than the transform itself."""
+    if nthreads:
+        return int(nthreads)
+    try:
+        n = len(os.sched_getaffinity(0))
+    except AttributeError:
+        n = os.cpu_count() or 1
+    n = min(n, int(os.environ.get("ORACLE_THREADS", "16")))
+    if nside <= 64:
+        n = min(n, 4)
+    return max(n, 1)
+
+
 def _p(a):
     return a.ctypes.data_as(ctypes.POINTER(ctypes.c_double))
 
@@ -69,12 +84,12 @@ def sht(job, nside, lmax, alm=None, map=None, wring=None, fft_mode=1, use_mlim=T
         a = np.ascontiguousarray(alm, dtype=np.float64)
         assert a.shape == (nalm(lmax),), a.shape
         out = np.zeros(npix(nside))
-        rc = L.orc_sht(job, nside, lmax, wp, _p(a), _p(out), int(fft_mode), int(use_mlim), int(nthreads))
+        rc = L.orc_sht(job, nside, lmax, wp, _p(a), _p(out), int(fft_mode), int(use_mlim), _threads(nthreads, nside))
     else:
         m = np.ascontiguousarray(map, dtype=np.float64)
         assert m.shape == (npix(nside),), m.shape
         out = np.zeros(nalm(lmax))
-        rc = L.orc_sht(job, nside, lmax, wp, _p(out), _p(m), int(fft_mode), int(use_mlim), int(nthreads))
+        rc = L.orc_sht(job, nside, lmax, wp, _p(out), _p(m), int(fft_mode), int(use_mlim), _threads(nthreads, nside))
     if rc != 0:
         raise RuntimeError("orc_sht failed")
     return out
@@ -102,7 +117,7 @@ def invn_diag(nside, lmax, al0, nthreads=0):
     al0 = np.ascontiguousarray(al0, dtype=np.float64)
     assert al0.shape == (lmax + 1,)
     out = np.zeros(nalm(lmax))
-    L.orc_invn_diag(nside, lmax, _p(al0), _p(out), int(nthreads))
+    L.orc_invn_diag(nside, lmax, _p(al0), _p(out), _threads(nthreads, nside))
     return out
 
 
@@ -123,7 +138,8 @@ def sht_spin2(job, nside, lmax, almE=None, almB=None, mapQ=None, mapU=None, wrin
         q = np.ascontiguousarray(mapQ, dtype=np.float64)
         u = np.ascontiguousarray(mapU, dtype=np.float64)
         e, b = np.zeros(nalm(lmax)), np.zeros(nalm(lmax))
-    rc = L.orc_sht_spin2(job, nside, lmax, wp, _p(e), _p(b), _p(q), _p(u), int(fft_mode), int(use_mlim), int(nthreads))
+    rc = L.orc_sht_spin2(job, nside, lmax, wp, _p(e), _p(b), _p(q), _p(u), int(fft_mode), int(use_mlim),
+                         _threads(nthreads, nside))
     if rc != 0:
         raise RuntimeError("orc_sht_spin2 failed")
     return (q, u) if job in (JOB_Y, JOB_WY) else (e, b)

@@ -24,7 +24,8 @@ def oracle_system(spec, only_pol=False):
             cl = cro.Cl(c["lmax"], c["nmaps"], c["Dl"])
             # the product receives the tables from commander_amd.cl.update_S; make sure both sides hold the same
             assert np.allclose(cl.sqrtS_mat, c["sqrtS_mat"], rtol=1e-13, atol=0)
-        comps.append(cro.DiffuseComp(c["lmax"], c["nmaps"], cl, c["F_mean"], active=c.get("active", True)))
+        comps.append(cro.DiffuseComp(c["lmax"], c["nmaps"], cl, c["F_mean"], active=c.get("active", True),
+                                     F_map=c.get("F_map")))
     return cro.CRSystem(bands, comps, only_pol=only_pol)
 
 

@@ -230,12 +230,23 @@ void launch_sqrtS(const CompDev* comps, int ncomp, int, const double* smat, int 
             for (int l = m; l <= comps[c].lmax; ++l) sqrtS_elem(comps[c], smat, kind, in, add, out, m, l, pass_inactive);
 }
 void launch_band_prep(const CompDev* comps, int ncomp, const double* sx, const double* w, const int* bm_stokes,
-                      double* ast, const double* cnorm, int lmax_g, int nbm, hipStream_t) {
+                      double* ast, const double* cnorm, int lmax_g, int nbm, hipStream_t, const double* extra) {
+    const int64_t na = (int64_t)(lmax_g + 1) * (lmax_g + 1);
     for (int bm = 0; bm < nbm; ++bm)
         for (int m = 0; m <= lmax_g; ++m)
             for (int l = m; l <= lmax_g + 1; ++l)
                 band_prep_elem(comps, ncomp, sx, w + (int64_t)bm * ncomp * (lmax_g + 1), bm_stokes[bm], ast, nbm, bm,
-                               cnorm, lmax_g, m, l);
+                               cnorm, lmax_g, m, l, extra ? extra + bm * na : nullptr);
+}
+void launch_alm_copy(const double* src, int lmax_s, double* dst, int lmax_d, const double* fl, bool accumulate,
+                     hipStream_t, int lcut) {
+    for (int m = 0; m <= lmax_d; ++m)
+        for (int l = m; l <= lmax_d; ++l) alm_copy_elem(src, lmax_s, dst, lmax_d, fl, accumulate ? 1 : 0, lcut, m, l);
+}
+void launch_pinv_prior(const CompDev* comps, int ncomp, int, const double* Q, int lmax_pre, int nmaps_pre,
+                       const double* x, const double* z, double* out, hipStream_t) {
+    for (int m = 0; m <= lmax_pre; ++m)
+        for (int l = m; l <= lmax_pre; ++l) pinv_prior_elem(comps, ncomp, Q, lmax_pre, nmaps_pre, x, z, out, m, l);
 }
 void launch_band_post(const CompDev* comps, int ncomp, int, const double* part, int64_t pms, int64_t pcs,
                       int nchunk, int nbm, const int* bm_stokes, const double* w, const double* cnorm, int lmax_g,
@@ -247,13 +258,15 @@ void launch_band_post(const CompDev* comps, int ncomp, int, const double* part, 
                                accumulate ? 1 : 0, m, l);
 }
 void launch_band_prep2(const CompDev* comps, int ncomp, const double* sx, const double* w, int nT, double* st, int npol,
-                       const double* cnorm2, int lmax_g, hipStream_t) {
+                       const double* cnorm2, int lmax_g, hipStream_t, const double* extra) {
     const int64_t ws = (int64_t)ncomp * (lmax_g + 1);
+    const int64_t na = (int64_t)(lmax_g + 1) * (lmax_g + 1);
     for (int ip = 0; ip < npol; ++ip)
         for (int m = 0; m <= lmax_g; ++m)
             for (int l = m; l <= lmax_g + 1; ++l)
                 band_prep2_elem(comps, ncomp, sx, w + (nT + 2 * ip) * ws, w + (nT + 2 * ip + 1) * ws, st, npol, ip, cnorm2,
-                                lmax_g, m, l);
+                                lmax_g, m, l, extra ? extra + (nT + 2 * ip) * na : nullptr,
+                                extra ? extra + (nT + 2 * ip + 1) * na : nullptr);
 }
 void launch_band_post2(const CompDev* comps, int ncomp, int, const double* part2, int64_t pps, int64_t pcs, int nchunk,
                        int npol, const double* w, int nT, const double* cnorm2, int lmax_g, double* yc, hipStream_t) {

@@ -150,3 +150,43 @@ def test_polarised_cr_path_gpu():
     xs, n, st, res = ctx.solve_cr_eqn_by_CG(rhso, "fixed_iter", 1e-8, 5, 20, 1)
     xo, no, so = S.solve(rhso, "fixed_iter", 1e-8, 5, 20, 1)
     assert n == no == 20 and rel(xs, xo) < 1e-8
+
+
+def test_varying_mixing_and_pseudoinv_gpu():
+    """BASELINE.json configs[4] shape at reduced size (Nside=32, lmax=64): five diffuse components, synchrotron and
+    dust with spatially varying spectral indices (Y . F . YtW branch of evalDiffuseBand / projectDiffuseBand,
+    comm_diffuse_comp_mod.f90:2082-2084, 2155-2157), pseudo-inverse preconditioner (:2238-2380)."""
+    from commander_amd import synth
+    from commander_amd.cr import build_context
+    spec = synth.make_problem("cfg5", nside=32, lmax=64, comp_lmax=[64, 48, 64, 40, 40])
+    S = oracle_system(spec)
+    ctx = build_context(spec)
+    x = np.random.default_rng(55).standard_normal(ctx.ncr)
+    assert rel(ctx.cr_matmulA(x), S.matmulA(x)) < 1e-11
+    resid, xi, eta = synth.draw_inputs(spec)
+    rhso = S.computeRHS(resid, "sample", xi, eta)
+    assert rel(ctx.cr_computeRHS("sample", resid, xi, eta), rhso) < 1e-11
+    ctx.initPrecond("pseudoinv"); ctx.update_precond()
+    S.init_precond_pseudoinv(); S.update_precond_pseudoinv()
+    for ib, b in enumerate(S.bands):
+        assert np.allclose(ctx.alpha_nu(ib), b.alpha_nu, rtol=1e-11)
+    assert rel(ctx.cr_invM(x), S.invM(x)) < 1e-10
+    xs, n, st, res = ctx.solve_cr_eqn_by_CG(rhso, "fixed_iter", 1e-8, 5, 8, 1)
+    xo, no, so = S.solve(rhso, "fixed_iter", 1e-8, 5, 8, 1)
+    assert n == no == 8 and rel(xs, xo) < 1e-8
+
+
+def test_varying_mixing_polarised_gpu():
+    from commander_amd import synth, healpix
+    from commander_amd.cr import build_context
+    spec = synth.make_problem("cfg2", nside=32, lmax=64, pol=True)
+    z = healpix.pix_z(32)
+    spec["comps"][1]["F_map"] = {ib: np.repeat(synth.mixing("synch", b["nu"], z)[:, None], 3, axis=1) * [1.0, 1.02, 0.97]
+                                 for ib, b in enumerate(spec["bands"])}
+    S = oracle_system(spec)
+    ctx = build_context(spec)
+    x = np.random.default_rng(56).standard_normal(ctx.ncr)
+    assert rel(ctx.cr_matmulA(x), S.matmulA(x)) < 1e-11
+    ctx.initPrecond("pseudoinv"); ctx.update_precond()
+    S.init_precond_pseudoinv(); S.update_precond_pseudoinv()
+    assert rel(ctx.cr_invM(x), S.invM(x)) < 1e-10

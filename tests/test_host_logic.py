@@ -193,3 +193,68 @@ def test_emul_split_rings_fused_matvec(EL, monkeypatch):
     ctx = build_context(spec, _lib=EL)
     x = np.random.default_rng(4).standard_normal(ctx.ncr)
     assert rel(ctx.cr_matmulA(x), S.matmulA(x)) < 1e-12
+
+
+def _varying_spec(nside, lmax, pol=False, wring=False, comp_lmax=None):
+    """cfg2-like problem whose synchrotron component has a spatially varying spectral index
+    beta(p) = -3.1 + 0.1 cos(theta) (SURVEY.md §8d cfg 5), i.e. takes the Y . F . YtW branch."""
+    from commander_amd import synth, healpix
+    spec = synth.make_problem("cfg2", nside=nside, lmax=lmax, pol=pol, comp_lmax=comp_lmax)
+    z = healpix.pix_z(nside)
+    nm = 3 if pol else 1
+    if wring:
+        w = 1.0 + 0.03 * np.cos(np.arange(2 * nside))
+        for b in spec["bands"]:
+            b["wring"] = w
+    spec["comps"][1]["F_map"] = {ib: np.repeat(((b["nu"] / 30.0) ** (-3.1 + 0.1 * z))[:, None], nm, axis=1)
+                                 * (1.0 + 0.02 * np.arange(nm))[None, :]
+                                 for ib, b in enumerate(spec["bands"])}
+    return spec
+
+
+@pytest.mark.parametrize("pol,wring,clm", [(False, False, None), (False, True, [16, 11]), (True, False, [14, 16])])
+def test_emul_varying_mixing_vs_oracle(EL, pol, wring, clm):
+    from commander_amd import synth
+    from commander_amd.cr import build_context
+    spec = _varying_spec(8, 16, pol=pol, wring=wring, comp_lmax=clm)
+    S = oracle_system(spec)
+    ctx = build_context(spec, _lib=EL)
+    rng = np.random.default_rng(21)
+    x = rng.standard_normal(ctx.ncr)
+    assert rel(ctx.cr_matmulA(x), S.matmulA(x)) < 1e-12
+    resid, xi, eta = synth.draw_inputs(spec)
+    rhs = ctx.cr_computeRHS("sample", resid, xi, eta)
+    assert rel(rhs, S.computeRHS(resid, "sample", xi, eta)) < 1e-12
+    # back to the F_mean fast path
+    for ib in range(len(spec["bands"])):
+        ctx.set_mixing_map(1, ib, None)
+    S.comps[1].F_map = {}
+    assert rel(ctx.cr_matmulA(x), S.matmulA(x)) < 1e-12
+
+
+@pytest.mark.parametrize("pol", [False, True])
+def test_emul_pseudoinv_precond_vs_oracle(EL, pol):
+    from commander_amd import synth
+    from commander_amd.cr import build_context
+    spec = synth.make_problem("cfg2", nside=8, lmax=16, pol=pol)
+    S = oracle_system(spec)
+    ctx = build_context(spec, _lib=EL)
+    ctx.initPrecond("pseudoinv")
+    ctx.update_precond()
+    S.init_precond_pseudoinv()
+    S.update_precond_pseudoinv()
+    for ib, b in enumerate(S.bands):
+        assert np.allclose(ctx.alpha_nu(ib), b.alpha_nu, rtol=1e-12)
+    x = np.random.default_rng(5).standard_normal(ctx.ncr)
+    assert rel(ctx.cr_invM(x), S.invM(x)) < 1e-11
+    resid, xi, eta = synth.draw_inputs(spec)
+    b = S.computeRHS(resid, "sample", xi, eta)
+    xg, ng, sg, _ = ctx.solve_cr_eqn_by_CG(b, "fixed_iter", maxiter=6)
+    xo, no, so = S.solve(b, "fixed_iter", maxiter=6)
+    assert rel(xg, xo) < 1e-9
+    # switching back to the diagonal type
+    ctx.initPrecond("diagonal")
+    ctx.update_precond()
+    S.init_precond_diag()
+    S.update_precond_diag()
+    assert rel(ctx.cr_invM(x), S.invM(x)) < 1e-11

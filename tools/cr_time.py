@@ -6,9 +6,10 @@ from commander_amd import synth
 from commander_amd.cr import build_context
 
 cfg = sys.argv[1] if len(sys.argv) > 1 else "cfg3"
+precond = sys.argv[2] if len(sys.argv) > 2 else "diagonal"
 t0 = time.time(); spec = synth.make_problem(cfg); print("spec %.1fs" % (time.time() - t0), flush=True)
 t0 = time.time(); ctx = build_context(spec); print("context %.1fs ncr=%d" % (time.time() - t0, ctx.ncr), flush=True)
-t0 = time.time(); ctx.initPrecond(); print("initPrecond %.2fs" % (time.time() - t0), flush=True)
+t0 = time.time(); ctx.initPrecond(precond); print("initPrecond %.2fs" % (time.time() - t0), flush=True)
 t0 = time.time(); ctx.update_precond(); print("update_precond %.2fs" % (time.time() - t0), flush=True)
 resid, xi, eta = synth.draw_inputs(spec)
 dres = [ctx.dev(r.size, r) for r in resid]; dxi = [ctx.dev(r.size, r) for r in xi]; deta = ctx.dev(ctx.ncr, eta)
