@@ -32,14 +32,78 @@ __global__ void __launch_bounds__(256) k_leg_synth(LegArgs A, const WaveTask* __
     leg_synth_lane<R, NB>(A, ast, nbs, k0, ph, ph_stride, m, chunk, lw, lAend, threadIdx.x & 63);
 }
 
-// Adjoint: each wave reduces its 64 lanes through a private LDS tile and writes one partial column segment
+// ---- wave-wide reduction of 16 values per lane -------------------------------------------------------------
+// v[0..15] per lane -> on return the lanes with (lane & 3) == 0 hold sum_{64 lanes} v[lane >> 2].
+// Two register butterfly steps with the gfx950 row / half swaps (v_permlane32_swap, v_permlane16_swap) fold the four
+// 16-lane rows into one, leaving 4 values per lane; only those go through LDS (4 ds_write_b64 + 2 ds_read_b128 per
+// lane instead of 16 + 16: the LDS pipe, not the VALU, bounded the first version of this kernel); the last factor
+// of 4 is two quad-permute DPP steps.  Fixed summation order -> deterministic.
+constexpr int kRedPitch = 66;                 // doubles; 33 x 16 B: conflict-free ds_read_b128 for the read pattern below
+constexpr int kRedTile = 4 * kRedPitch;       // doubles per tile; two tiles per wave (double buffer)
+
+__device__ inline void swap_halves(double& a, double& b) {   // a <- {a.lo32lanes, b.lo32lanes}, b <- {a.hi, b.hi}
+    unsigned alo = __double2loint(a), ahi = __double2hiint(a), blo = __double2loint(b), bhi = __double2hiint(b);
+    auto r = __builtin_amdgcn_permlane32_swap(alo, blo, false, false);
+    alo = r[0]; blo = r[1];
+    r = __builtin_amdgcn_permlane32_swap(ahi, bhi, false, false);
+    ahi = r[0]; bhi = r[1];
+    a = __hiloint2double(ahi, alo);
+    b = __hiloint2double(bhi, blo);
+}
+__device__ inline void swap_rows(double& a, double& b) {     // odd rows of a <-> even rows of b (row = 16 lanes)
+    unsigned alo = __double2loint(a), ahi = __double2hiint(a), blo = __double2loint(b), bhi = __double2hiint(b);
+    auto r = __builtin_amdgcn_permlane16_swap(alo, blo, false, false);
+    alo = r[0]; blo = r[1];
+    r = __builtin_amdgcn_permlane16_swap(ahi, bhi, false, false);
+    ahi = r[0]; bhi = r[1];
+    a = __hiloint2double(ahi, alo);
+    b = __hiloint2double(bhi, blo);
+}
+template <int CTRL>
+__device__ inline double quad_perm(double v) {
+    int lo = __double2loint(v), hi = __double2hiint(v);
+    lo = __builtin_amdgcn_mov_dpp(lo, CTRL, 0xf, 0xf, true);
+    hi = __builtin_amdgcn_mov_dpp(hi, CTRL, 0xf, 0xf, true);
+    return __hiloint2double(hi, lo);
+}
+
+__device__ inline double wave_reduce16(const double* v, double* tile, int lane) {
+    double u[8], t[4];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {          // lanes < 32: value 2k, lanes >= 32: value 2k+1 (each summed over i, i^32)
+        double a = v[2 * k], b = v[2 * k + 1];
+        swap_halves(a, b);
+        u[k] = a + b;
+    }
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {          // row r of t[q]: value 4q + {0,2,1,3}[r], summed over the 4 rows
+        double a = u[2 * q], b = u[2 * q + 1];
+        swap_rows(a, b);
+        t[q] = a + b;
+    }
+#pragma unroll
+    for (int q = 0; q < 4; ++q) tile[q * kRedPitch + lane] = t[q];
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    // lane = 16 q + 4 rr + part reads columns 4 part .. 4 part + 3 of value 4q + rr, which lives in row perm(rr)
+    const int q = lane >> 4, rr = (lane >> 2) & 3, part = lane & 3;
+    const int row = ((rr & 1) << 1) | (rr >> 1);
+    const double* p = tile + q * kRedPitch + 16 * row + 4 * part;
+    double s = (p[0] + p[1]) + (p[2] + p[3]);
+    s += quad_perm<0xB1>(s);               // lane ^ 1
+    s += quad_perm<0x4E>(s);               // lane ^ 2
+    return s;
+}
+
+// Adjoint: each wave reduces its 64 lanes (wave_reduce16) and writes one partial column segment
 // part[map][chunk][padded triangle] (complex).  Deterministic: fixed summation order, no atomics.
 template <int R, int NB, bool SQUARE>
 __global__ void __launch_bounds__(256) k_leg_adj(LegArgs A, const WaveTask* __restrict__ tasks, int ntasks,
                                                  const double* __restrict__ ph, int64_t ph_stride, int k0,
                                                  double* __restrict__ part, int64_t part_map_stride,
                                                  int64_t part_chunk_stride) {
-    __shared__ double lds[4][16 * 65];
+    __shared__ __attribute__((aligned(16))) double lds[4][2 * kRedTile];
     const int wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int lane = threadIdx.x & 63;
     const int t = blockIdx.x * 4 + wid;
@@ -57,30 +121,20 @@ __global__ void __launch_bounds__(256) k_leg_adj(LegArgs A, const WaveTask* __re
     const double* __restrict__ al = A.alpha + (mo - m);
     double* __restrict__ out0 = part + chunk * part_chunk_stride + 2 * (mo - m);
     double* wl = lds[wid];
-    const int col = lane & 15, qtr = lane >> 4;
+    const int id = lane >> 2;              // value this lane ends up with: l = l0 + id/2, (re, im) = id & 1
+    int buf = 0;
     for (int l0 = lw; l0 <= lmax; l0 += kAdjL_) {
         double w[kAdjL_][R];
         if (l0 < lAend) leg_adj_mu_group<R, NB, SQUARE, true>(al, l0, S, w);
         else            leg_adj_mu_group<R, NB, SQUARE, false>(al, l0, S, w);
-        const int l = l0 + (col >> 1);
+        const int l = l0 + (id >> 1);
 #pragma unroll
         for (int k = 0; k < NB; ++k) {
             double v[16];
             leg_adj_products<R, NB>(S, w, k, v);
-#pragma unroll
-            for (int j = 0; j < 16; ++j) wl[j * 65 + lane] = v[j];
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-            __builtin_amdgcn_wave_barrier();
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-            double s = 0.0;
-#pragma unroll
-            for (int i = 0; i < 16; ++i) s += wl[col * 65 + qtr * 16 + i];
-            s += __shfl_xor(s, 16);
-            s += __shfl_xor(s, 32);
-            if (qtr == 0 && l <= lmax) out0[(k0 + k) * part_map_stride + 2 * l + (col & 1)] = s;
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-            __builtin_amdgcn_wave_barrier();
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            const double s = wave_reduce16(v, wl + buf * kRedTile, lane);   // double-buffered: one barrier per use
+            buf ^= 1;
+            if ((lane & 3) == 0 && l <= lmax) out0[(k0 + k) * part_map_stride + 2 * l + (id & 1)] = s;
         }
     }
 }
@@ -173,7 +227,7 @@ template <int R>
 __global__ void __launch_bounds__(256) k_leg2_adj(Leg2Args A, const WaveTask* __restrict__ tasks, int ntasks,
                                                   const double* __restrict__ ph, int64_t ph_stride, int kq,
                                                   double* __restrict__ part, int64_t part_chunk_stride) {
-    __shared__ double lds[4][16 * 65];
+    __shared__ __attribute__((aligned(16))) double lds[4][2 * kRedTile];
     const int wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int lane = threadIdx.x & 63;
     const int t = blockIdx.x * 4 + wid;
@@ -197,26 +251,16 @@ __global__ void __launch_bounds__(256) k_leg2_adj(Leg2Args A, const WaveTask* __
     const double* __restrict__ be = A.beta + (mo - m);
     double* __restrict__ out = part + chunk * part_chunk_stride + 4 * (mo - m);   // 4 doubles per l
     double* wl = lds[wid];
-    const int col = lane & 15, qtr = lane >> 4;
+    const int id = lane >> 2;              // value this lane ends up with: l = l0 + id/4, component id & 3
+    int buf = 0;
     for (int l0 = lw; l0 <= lmax; l0 += 4) {
         double v[16];
         if (l0 < lAend) leg2_adj_group<R, true>(A, al, be, l0, S, G, v);
         else            leg2_adj_group<R, false>(A, al, be, l0, S, G, v);
-#pragma unroll
-        for (int j = 0; j < 16; ++j) wl[j * 65 + lane] = v[j];
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-        double sacc = 0.0;
-#pragma unroll
-        for (int i = 0; i < 16; ++i) sacc += wl[col * 65 + qtr * 16 + i];
-        sacc += __shfl_xor(sacc, 16);
-        sacc += __shfl_xor(sacc, 32);
-        const int l = l0 + (col >> 2);
-        if (qtr == 0 && l <= lmax) out[4 * l + (col & 3)] = sacc;
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        const double sacc = wave_reduce16(v, wl + buf * kRedTile, lane);
+        buf ^= 1;
+        const int l = l0 + (id >> 2);
+        if ((lane & 3) == 0 && l <= lmax) out[4 * l + (id & 3)] = sacc;
     }
 }
 
@@ -325,11 +369,12 @@ __global__ void k_alm_to_stream(const double* __restrict__ alm, int64_t alm_stri
                                 int nbs, const double* __restrict__ cnorm, int lmax) {
     const int m = blockIdx.y, l = m + blockIdx.x * 256 + threadIdx.x;
     if (l > lmax + 1) return;
-    alm_to_stream_elem(alm + blockIdx.z * alm_stride, ast, nbs, blockIdx.z, cnorm, lmax, m, l);
+    for (int k = 0; k < nbs; ++k)   // the nbs entries of a stream row are contiguous: coalesced across l
+        alm_to_stream_elem(alm + k * alm_stride, ast, nbs, k, cnorm, lmax, m, l);
 }
 void launch_alm_to_stream(const double* alm, int64_t alm_stride, double* ast, const double* cnorm, int lmax,
                           int nmaps, hipStream_t s) {
-    dim3 grid((lmax + 2 + 255) / 256, lmax + 1, nmaps);
+    dim3 grid((lmax + 2 + 255) / 256, lmax + 1);
     hipLaunchKernelGGL(k_alm_to_stream, grid, dim3(256), 0, s, alm, alm_stride, ast, nmaps, cnorm, lmax);
 }
 
