@@ -139,14 +139,22 @@ __global__ void __launch_bounds__(256) k_leg_adj(LegArgs A, const WaveTask* __re
     }
 }
 
-int leg_max_batch(int R) {
-    int nb = R == 1 ? 9 : (R == 2 ? 4 : 2);
-    if (const char* e = std::getenv("CMDR_LEG_NB")) {   // tuning knob: cap the maps per wave
+// maps sharing one recursion per wave (register budget).  Tuning knobs: CMDR_LEG_NB caps both kernels,
+// CMDR_LEG_NB_S / CMDR_LEG_NB_A set the synthesis / adjoint value (up to the compiled maximum).
+static int leg_batch(int R, bool adjoint) {
+    const int cap = R == 1 ? 9 : (R == 2 ? 4 : (adjoint ? 3 : 4));
+    int nb = R == 1 ? 9 : (R == 2 ? 4 : 3);   // R = 4: 3 measured best for both kernels (9 maps: 3+3+3)
+    if (const char* e = std::getenv(adjoint ? "CMDR_LEG_NB_A" : "CMDR_LEG_NB_S")) {
+        const int v = std::atoi(e);
+        if (v >= 1 && v <= cap) nb = v;
+    }
+    if (const char* e = std::getenv("CMDR_LEG_NB")) {
         const int v = std::atoi(e);
         if (v >= 1 && v < nb) nb = v;
     }
     return nb;
 }
+int leg_max_batch(int R) { return leg_batch(R, false); }
 
 template <int R, int NB>
 static void synth_RN(const LegArgs& A, const WaveTask* tasks, int ntasks, const double* ast, int nbs, int k0,
@@ -157,7 +165,7 @@ static void synth_RN(const LegArgs& A, const WaveTask* tasks, int ntasks, const 
 void launch_leg_synth(const LegArgs& A, const WaveTask* tasks, int ntasks, const double* ast, double* ph,
                       int64_t ph_stride, int nmaps, hipStream_t s) {
     if (ntasks == 0 || nmaps == 0) return;
-    const int nbmax = leg_max_batch(A.R);
+    const int nbmax = leg_batch(A.R, false);
     const int nbatch = (nmaps + nbmax - 1) / nbmax;
     for (int k0 = 0, ib = 0; ib < nbatch; ++ib) {
         const int nb = (nmaps - k0 + (nbatch - ib) - 1) / (nbatch - ib);   // balanced split, e.g. 9 -> 3+3+3
@@ -168,7 +176,7 @@ void launch_leg_synth(const LegArgs& A, const WaveTask* tasks, int ntasks, const
         } else if (A.R == 2) {
             switch (nb) { CMDR_S(2, 1) CMDR_S(2, 2) CMDR_S(2, 3) CMDR_S(2, 4) }
         } else {
-            switch (nb) { CMDR_S(4, 1) CMDR_S(4, 2) }
+            switch (nb) { CMDR_S(4, 1) CMDR_S(4, 2) CMDR_S(4, 3) CMDR_S(4, 4) }
         }
 #undef CMDR_S
         k0 += nb;
@@ -192,9 +200,10 @@ void launch_leg_adj(const LegArgs& A, const WaveTask* tasks, int ntasks, const d
         }
         return;
     }
-    const int nbmax = leg_max_batch(A.R);
-    for (int k0 = 0; k0 < nmaps; k0 += nbmax) {
-        const int nb = std::min(nbmax, nmaps - k0);
+    const int nbmax = leg_batch(A.R, true);
+    const int nbatch = (nmaps + nbmax - 1) / nbmax;
+    for (int k0 = 0, ib = 0; ib < nbatch; ++ib) {
+        const int nb = (nmaps - k0 + (nbatch - ib) - 1) / (nbatch - ib);   // balanced split
 #define CMDR_A(RR, NN) case NN: adj_RN<RR, NN, false>(A, tasks, ntasks, ph, ph_stride, k0, part, pms, pcs, s); break;
         if (A.R == 1) {
             switch (nb) { CMDR_A(1, 1) CMDR_A(1, 2) CMDR_A(1, 3) CMDR_A(1, 4) CMDR_A(1, 5) CMDR_A(1, 6) CMDR_A(1, 7)
@@ -202,9 +211,10 @@ void launch_leg_adj(const LegArgs& A, const WaveTask* tasks, int ntasks, const d
         } else if (A.R == 2) {
             switch (nb) { CMDR_A(2, 1) CMDR_A(2, 2) CMDR_A(2, 3) CMDR_A(2, 4) }
         } else {
-            switch (nb) { CMDR_A(4, 1) CMDR_A(4, 2) }
+            switch (nb) { CMDR_A(4, 1) CMDR_A(4, 2) CMDR_A(4, 3) }
         }
 #undef CMDR_A
+        k0 += nb;
     }
 }
 

@@ -10,7 +10,7 @@
 
 namespace cmdr {
 
-int leg_max_batch(int R) { return R == 1 ? 9 : (R == 2 ? 4 : 2); }
+int leg_max_batch(int R) { return R == 1 ? 9 : (R == 2 ? 4 : 3); }
 
 template <int R, int NB>
 static void synth_RN(const LegArgs& A, const WaveTask* tasks, int ntasks, const double* ast, int nbs, int k0,
@@ -32,7 +32,7 @@ void launch_leg_synth(const LegArgs& A, const WaveTask* tasks, int ntasks, const
         } else if (A.R == 2) {
             switch (nb) { CMDR_S(2, 1) CMDR_S(2, 2) CMDR_S(2, 3) CMDR_S(2, 4) }
         } else {
-            switch (nb) { CMDR_S(4, 1) CMDR_S(4, 2) }
+            switch (nb) { CMDR_S(4, 1) CMDR_S(4, 2) CMDR_S(4, 3) }
         }
 #undef CMDR_S
     }
@@ -100,7 +100,7 @@ void launch_leg_adj(const LegArgs& A, const WaveTask* tasks, int ntasks, const d
         } else if (A.R == 2) {
             switch (nb) { CMDR_A(2, 1) CMDR_A(2, 2) CMDR_A(2, 3) CMDR_A(2, 4) }
         } else {
-            switch (nb) { CMDR_A(4, 1) CMDR_A(4, 2) }
+            switch (nb) { CMDR_A(4, 1) CMDR_A(4, 2) CMDR_A(4, 3) }
         }
 #undef CMDR_A
     }
