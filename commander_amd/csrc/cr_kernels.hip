@@ -25,23 +25,25 @@ void launch_sqrtS(const CompDev* comps, int ncomp, int lmax_max, const double* s
     hipLaunchKernelGGL(k_sqrtS, grid, dim3(256), 0, s, comps, smat, kind, in, add, out, pass_inactive ? 1 : 0);
 }
 
-// one thread per (l, m): the nbm entries of a stream row are contiguous (144 B at 9 maps), so consecutive l write
-// consecutive segments -- a thread per (l, m, bm) would write 16 B at a stride of nbm * 16 B
+// thread = (l, bm) with bm fastest: the nbm entries of a stream row are contiguous (144 B at 9 maps), so a wave
+// writes one contiguous run; the sx value of an l is read once and broadcast to its nbm lanes
 __global__ void k_band_prep(const CompDev* __restrict__ comps, int ncomp, const double* __restrict__ sx,
                             const double* __restrict__ w, const int* __restrict__ bm_stokes,
-                            double* __restrict__ ast, int nbm, const double* __restrict__ cnorm, int lmax_g,
+                            double* __restrict__ ast, int nbm, int lpb, const double* __restrict__ cnorm, int lmax_g,
                             const double* __restrict__ extra) {
-    const int m = blockIdx.y, l = m + blockIdx.x * 256 + threadIdx.x;
+    const int ll = threadIdx.x / nbm, bm = threadIdx.x - ll * nbm;
+    if (ll >= lpb) return;
+    const int m = blockIdx.y, l = m + blockIdx.x * lpb + ll;
     if (l > lmax_g + 1) return;
     const int64_t na = (int64_t)(lmax_g + 1) * (lmax_g + 1);
-    for (int bm = 0; bm < nbm; ++bm)
-        band_prep_elem(comps, ncomp, sx, w + (int64_t)bm * ncomp * (lmax_g + 1), bm_stokes[bm], ast, nbm, bm, cnorm,
-                       lmax_g, m, l, extra ? extra + bm * na : nullptr);
+    band_prep_elem(comps, ncomp, sx, w + (int64_t)bm * ncomp * (lmax_g + 1), bm_stokes[bm], ast, nbm, bm, cnorm,
+                   lmax_g, m, l, extra ? extra + bm * na : nullptr);
 }
 void launch_band_prep(const CompDev* comps, int ncomp, const double* sx, const double* w, const int* bm_stokes,
                       double* ast, const double* cnorm, int lmax_g, int nbm, hipStream_t s, const double* extra) {
-    dim3 grid((lmax_g + 2 + 255) / 256, lmax_g + 1);
-    hipLaunchKernelGGL(k_band_prep, grid, dim3(256), 0, s, comps, ncomp, sx, w, bm_stokes, ast, nbm, cnorm, lmax_g,
+    const int lpb = std::max(1, 256 / nbm);   // l values per block
+    dim3 grid((lmax_g + 2 + lpb - 1) / lpb, lmax_g + 1);
+    hipLaunchKernelGGL(k_band_prep, grid, dim3(256), 0, s, comps, ncomp, sx, w, bm_stokes, ast, nbm, lpb, cnorm, lmax_g,
                        extra);
 }
 

@@ -18,10 +18,13 @@ namespace cmdr {
 // recursion.  (R = 4, NB <= 2) is the measured optimum; an LDS-staged variant was slower (register pressure).
 template <int R, int NB>
 __global__ void __launch_bounds__(256) k_leg_synth(LegArgs A, const WaveTask* __restrict__ tasks, int ntasks,
-                                                   const double* __restrict__ ast, int nbs, int k0,
+                                                   const double* __restrict__ ast, int nbs, int k0, int rep,
                                                    double* __restrict__ ph, int64_t ph_stride) {
+    // rep batches of NB maps in one launch, task-major so that the longest tasks of every batch start first
+    // (small shards: a launch per batch would each wait for its own longest wave)
     const int wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int t = blockIdx.x * 4 + wid;
+    const int t = (blockIdx.x / rep) * 4 + wid;
+    k0 += (blockIdx.x % rep) * NB;
     if (t >= ntasks) return;
     const WaveTask T = tasks[t];
     if (T.chunk < 0) return;
@@ -100,13 +103,14 @@ __device__ inline double wave_reduce16(const double* v, double* tile, int lane) 
 // part[map][chunk][padded triangle] (complex).  Deterministic: fixed summation order, no atomics.
 template <int R, int NB, bool SQUARE>
 __global__ void __launch_bounds__(256) k_leg_adj(LegArgs A, const WaveTask* __restrict__ tasks, int ntasks,
-                                                 const double* __restrict__ ph, int64_t ph_stride, int k0,
+                                                 const double* __restrict__ ph, int64_t ph_stride, int k0, int rep,
                                                  double* __restrict__ part, int64_t part_map_stride,
                                                  int64_t part_chunk_stride) {
     __shared__ __attribute__((aligned(16))) double lds[4][2 * kRedTile];
     const int wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int lane = threadIdx.x & 63;
-    const int t = blockIdx.x * 4 + wid;
+    const int t = (blockIdx.x / rep) * 4 + wid;      // rep batches of NB maps per launch, task-major (see k_leg_synth)
+    k0 += (blockIdx.x % rep) * NB;
     if (t >= ntasks) return;
     const WaveTask T = tasks[t];
     if (T.chunk < 0) return;
@@ -157,19 +161,31 @@ static int leg_batch(int R, bool adjoint) {
 int leg_max_batch(int R) { return leg_batch(R, false); }
 
 template <int R, int NB>
-static void synth_RN(const LegArgs& A, const WaveTask* tasks, int ntasks, const double* ast, int nbs, int k0,
+static void synth_RN(const LegArgs& A, const WaveTask* tasks, int ntasks, const double* ast, int nbs, int k0, int rep,
                      double* ph, int64_t ph_stride, hipStream_t s) {
-    hipLaunchKernelGGL((k_leg_synth<R, NB>), dim3(ntasks / 4), dim3(256), 0, s, A, tasks, ntasks, ast, nbs, k0, ph,
-                       ph_stride);
+    hipLaunchKernelGGL((k_leg_synth<R, NB>), dim3((ntasks / 4) * rep), dim3(256), 0, s, A, tasks, ntasks, ast, nbs, k0,
+                       rep, ph, ph_stride);
+}
+// balanced split of nmaps into batches of at most nbmax maps, e.g. 9 -> 3+3+3, 8 -> 3+3+2; consecutive batches of
+// equal size share one launch: calls f(nb, k0, rep)
+template <class F>
+static void for_batches(int nmaps, int nbmax, F f) {
+    const int nbatch = (nmaps + nbmax - 1) / nbmax;
+    int k0 = 0, ib = 0;
+    while (ib < nbatch) {
+        const int nb = (nmaps - k0 + (nbatch - ib) - 1) / (nbatch - ib);
+        int rep = 1, k = k0 + nb;
+        while (ib + rep < nbatch && (nmaps - k + (nbatch - ib - rep) - 1) / (nbatch - ib - rep) == nb) { ++rep; k += nb; }
+        f(nb, k0, rep);
+        k0 = k;
+        ib += rep;
+    }
 }
 void launch_leg_synth(const LegArgs& A, const WaveTask* tasks, int ntasks, const double* ast, double* ph,
                       int64_t ph_stride, int nmaps, hipStream_t s) {
     if (ntasks == 0 || nmaps == 0) return;
-    const int nbmax = leg_batch(A.R, false);
-    const int nbatch = (nmaps + nbmax - 1) / nbmax;
-    for (int k0 = 0, ib = 0; ib < nbatch; ++ib) {
-        const int nb = (nmaps - k0 + (nbatch - ib) - 1) / (nbatch - ib);   // balanced split, e.g. 9 -> 3+3+3
-#define CMDR_S(RR, NN) case NN: synth_RN<RR, NN>(A, tasks, ntasks, ast, nmaps, k0, ph, ph_stride, s); break;
+    for_batches(nmaps, leg_batch(A.R, false), [&](int nb, int k0, int rep) {
+#define CMDR_S(RR, NN) case NN: synth_RN<RR, NN>(A, tasks, ntasks, ast, nmaps, k0, rep, ph, ph_stride, s); break;
         if (A.R == 1) {
             switch (nb) { CMDR_S(1, 1) CMDR_S(1, 2) CMDR_S(1, 3) CMDR_S(1, 4) CMDR_S(1, 5) CMDR_S(1, 6) CMDR_S(1, 7)
                           CMDR_S(1, 8) CMDR_S(1, 9) }
@@ -179,32 +195,28 @@ void launch_leg_synth(const LegArgs& A, const WaveTask* tasks, int ntasks, const
             switch (nb) { CMDR_S(4, 1) CMDR_S(4, 2) CMDR_S(4, 3) CMDR_S(4, 4) }
         }
 #undef CMDR_S
-        k0 += nb;
-    }
+    });
 }
 
 template <int R, int NB, bool SQ>
 static void adj_RN(const LegArgs& A, const WaveTask* tasks, int ntasks, const double* ph, int64_t ph_stride, int k0,
-                   double* part, int64_t pms, int64_t pcs, hipStream_t s) {
-    hipLaunchKernelGGL((k_leg_adj<R, NB, SQ>), dim3(ntasks / 4), dim3(256), 0, s, A, tasks, ntasks, ph,
-                       ph_stride, k0, part, pms, pcs);
+                   int rep, double* part, int64_t pms, int64_t pcs, hipStream_t s) {
+    hipLaunchKernelGGL((k_leg_adj<R, NB, SQ>), dim3((ntasks / 4) * rep), dim3(256), 0, s, A, tasks, ntasks, ph,
+                       ph_stride, k0, rep, part, pms, pcs);
 }
 void launch_leg_adj(const LegArgs& A, const WaveTask* tasks, int ntasks, const double* ph, int64_t ph_stride,
                     double* part, int64_t pms, int64_t pcs, int nmaps, bool square, hipStream_t s) {
     if (ntasks == 0 || nmaps == 0) return;
     if (square) {  // setup-time only (noise diagonal): one map at a time
         for (int k0 = 0; k0 < nmaps; ++k0) {
-            if (A.R == 1) adj_RN<1, 1, true>(A, tasks, ntasks, ph, ph_stride, k0, part, pms, pcs, s);
-            else if (A.R == 2) adj_RN<2, 1, true>(A, tasks, ntasks, ph, ph_stride, k0, part, pms, pcs, s);
-            else adj_RN<4, 1, true>(A, tasks, ntasks, ph, ph_stride, k0, part, pms, pcs, s);
+            if (A.R == 1) adj_RN<1, 1, true>(A, tasks, ntasks, ph, ph_stride, k0, 1, part, pms, pcs, s);
+            else if (A.R == 2) adj_RN<2, 1, true>(A, tasks, ntasks, ph, ph_stride, k0, 1, part, pms, pcs, s);
+            else adj_RN<4, 1, true>(A, tasks, ntasks, ph, ph_stride, k0, 1, part, pms, pcs, s);
         }
         return;
     }
-    const int nbmax = leg_batch(A.R, true);
-    const int nbatch = (nmaps + nbmax - 1) / nbmax;
-    for (int k0 = 0, ib = 0; ib < nbatch; ++ib) {
-        const int nb = (nmaps - k0 + (nbatch - ib) - 1) / (nbatch - ib);   // balanced split
-#define CMDR_A(RR, NN) case NN: adj_RN<RR, NN, false>(A, tasks, ntasks, ph, ph_stride, k0, part, pms, pcs, s); break;
+    for_batches(nmaps, leg_batch(A.R, true), [&](int nb, int k0, int rep) {
+#define CMDR_A(RR, NN) case NN: adj_RN<RR, NN, false>(A, tasks, ntasks, ph, ph_stride, k0, rep, part, pms, pcs, s); break;
         if (A.R == 1) {
             switch (nb) { CMDR_A(1, 1) CMDR_A(1, 2) CMDR_A(1, 3) CMDR_A(1, 4) CMDR_A(1, 5) CMDR_A(1, 6) CMDR_A(1, 7)
                           CMDR_A(1, 8) CMDR_A(1, 9) }
@@ -214,8 +226,7 @@ void launch_leg_adj(const LegArgs& A, const WaveTask* tasks, int ntasks, const d
             switch (nb) { CMDR_A(4, 1) CMDR_A(4, 2) CMDR_A(4, 3) }
         }
 #undef CMDR_A
-        k0 += nb;
-    }
+    });
 }
 
 // ---- spin-2 (Q,U <-> E,B): same task / wave structure; one polarisation pair per launch slice
