@@ -341,11 +341,18 @@ __global__ void __launch_bounds__(1024) k_ring(const RingDev* __restrict__ rings
                                               const double* const* __restrict__ mul, int weighted,
                                               const cd* __restrict__ tw, int log2Mmax,
                                               const cd* __restrict__ chirp, cd* __restrict__ scratch,
-                                              int64_t scratch_map_stride, int scratch_line) {
+                                              int64_t scratch_map_stride, int scratch_line, int ncls, int nmaps,
+                                              int per) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     cd* buf = reinterpret_cast<cd*>(smem);
-    const int pair = cls[blockIdx.x];
-    const int imap = blockIdx.y;
+    // Workgroups with equal blockIdx % 8 share an XCD (and its L2).  Give each of the 8 groups a contiguous run of the
+    // class's ring pairs and let it walk pair-major, map-minor: the maps of one pair re-use the pair's chirp / rotation
+    // tables from L2, and neighbouring pairs, whose phases share cache lines, stay on one XCD.
+    const int grp = blockIdx.x & 7, slot = blockIdx.x >> 3;
+    const int pl = slot / nmaps, imap = slot - pl * nmaps;
+    const int idx = grp * per + pl;
+    if (pl >= per || idx >= ncls) return;
+    const int pair = cls[idx];
     const RingDev d = rings[pair];
     const FftCtx c{(int)threadIdx.x, (int)blockDim.x};
     cd* sc = d.split ? scratch + imap * scratch_map_stride + (int64_t)(d.split - 1) * scratch_line : nullptr;
@@ -362,7 +369,8 @@ void launch_ring(int mode, const RingDev* rings, const int* cls, int ncls, int l
     int nthr = 512;   // measured: 512 > 256 threads per ring pair (more waves to cover LDS / global latency)
     if (const char* e = std::getenv("CMDR_RING_THREADS")) { const int v = std::atoi(e); if (v == 256 || v == 512 || v == 1024) nthr = v; }
     if (nthr > (1 << log2M) / 2) nthr = std::max(64, (1 << log2M) / 2);
-    dim3 grid(ncls, nmaps);
+    const int per = (ncls + 7) / 8;
+    dim3 grid(8 * per * nmaps);
 #define CMDR_RING(MM)                                                                                            \
     do {                                                                                                         \
         static bool attr_set = false;                                                                            \
@@ -373,7 +381,7 @@ void launch_ring(int mode, const RingDev* rings, const int* cls, int ncls, int l
         }                                                                                                        \
         hipLaunchKernelGGL(k_ring<MM>, grid, dim3(nthr), lds, s, rings, cls, ph, ph_stride, npair_pad, map,      \
                            map_stride, mul, weighted, tw, log2Mmax, chirp, scratch, scratch_map_stride,          \
-                           scratch_line);                                                                        \
+                           scratch_line, ncls, nmaps, per);                                                      \
     } while (0)
     if (mode == 0) CMDR_RING(0);
     else if (mode == 1) CMDR_RING(1);

@@ -478,6 +478,24 @@ struct FftCtx {
 CMDR_HD int lds_pad(int i) { return i + (i >> 3); }
 CMDR_HD int lds_elems(int log2M) { return (1 << log2M) + (1 << log2M >> 3) + 1; }
 
+// Twiddles of a register pass.  Stage t (half h << t) of the group at offset pos needs, for element j,
+//   exp(2 pi i (pos + (j mod 2^t) h) / (2 h 2^t)) = b_t * exp(2 pi i (j mod 2^t) / 2^(t+1)),  b_t = exp(2 pi i pos / (h 2^(t+1)))
+// so one table entry b_{K-1} per group gives every stage by squaring (b_{t-1} = b_t^2) and the second factor is one
+// of 1, e^{i pi/4}, i, e^{3 i pi/4}: one global load per group instead of 2^K - 1.
+CMDR_HD cd csqr(cd a) { return {a.x * a.x - a.y * a.y, 2.0 * a.x * a.y}; }
+template <int T>
+CMDR_HD cd rot_const(cd v, int jl) {   // v * exp(2 pi i jl / 2^(T+1)), jl < 2^T, T <= 2
+    if (T == 0) return v;
+    if (T == 1) return jl ? cd{-v.y, v.x} : v;
+    constexpr double r = 0.70710678118654752440;
+    switch (jl) {
+        case 0: return v;
+        case 1: return {(v.x - v.y) * r, (v.x + v.y) * r};
+        case 2: return {-v.y, v.x};
+        default: return {-(v.x + v.y) * r, (v.x - v.y) * r};
+    }
+}
+
 // K radix-2 DIT stages (halves h, 2h, .. h<<(K-1), h = 1<<hl) on the 2^K elements i0 + j*h held in registers.
 // bit-reversed order in -> natural order out, kernel exp(+2 pi i jk/M)
 template <int K>
@@ -488,6 +506,10 @@ CMDR_HD void fft_dit_pass(cd* buf, int log2M, int hl, const cd* __restrict__ tw,
     for (int g = c.tid; g < ngroups; g += c.nthr) {
         const int pos = g & hmask;
         const int i0 = ((g >> hl) << (hl + K)) + pos;
+        cd bt[K];
+        bt[K - 1] = tw[pos << (log2Mmax - (hl + K))];
+#pragma unroll
+        for (int t = K - 1; t > 0; --t) bt[t - 1] = csqr(bt[t]);
         cd v[N];
 #pragma unroll
         for (int j = 0; j < N; ++j) v[j] = buf[lds_pad(i0 + (j << hl))];
@@ -496,9 +518,9 @@ CMDR_HD void fft_dit_pass(cd* buf, int log2M, int hl, const cd* __restrict__ tw,
 #pragma unroll
             for (int j = 0; j < N; ++j) {
                 if (j & (1 << t)) continue;
-                const int e = pos + ((j & ((1 << t) - 1)) << hl);             // < h << t
-                const cd w = tw[e << (log2Mmax - (hl + t + 1))];
-                const cd u = v[j], x = cmul(v[j + (1 << t)], w);
+                const cd u = v[j];
+                cd x = cmul(v[j + (1 << t)], bt[t]);
+                x = t == 0 ? x : (t == 1 ? rot_const<1>(x, j & 1) : rot_const<2>(x, j & 3));
                 v[j] = cadd(u, x);
                 v[j + (1 << t)] = csub(u, x);
             }
@@ -518,6 +540,10 @@ CMDR_HD void fft_dif_pass(cd* buf, int log2M, int hl, const cd* __restrict__ tw,
     for (int g = c.tid; g < ngroups; g += c.nthr) {
         const int pos = g & hmask;
         const int i0 = ((g >> hl) << (hl + K)) + pos;
+        cd bt[K];
+        bt[K - 1] = tw[pos << (log2Mmax - (hl + K))];
+#pragma unroll
+        for (int t = K - 1; t > 0; --t) bt[t - 1] = csqr(bt[t]);
         cd v[N];
 #pragma unroll
         for (int j = 0; j < N; ++j) v[j] = buf[lds_pad(i0 + (j << hl))];
@@ -526,11 +552,10 @@ CMDR_HD void fft_dif_pass(cd* buf, int log2M, int hl, const cd* __restrict__ tw,
 #pragma unroll
             for (int j = 0; j < N; ++j) {
                 if (j & (1 << t)) continue;
-                const int e = pos + ((j & ((1 << t) - 1)) << hl);
-                const cd w = tw[e << (log2Mmax - (hl + t + 1))];
                 const cd u = v[j], x = v[j + (1 << t)];
                 v[j] = cadd(u, x);
-                v[j + (1 << t)] = cmul(csub(u, x), w);
+                cd d = cmul(csub(u, x), bt[t]);
+                v[j + (1 << t)] = t == 0 ? d : (t == 1 ? rot_const<1>(d, j & 1) : rot_const<2>(d, j & 3));
             }
         }
 #pragma unroll
