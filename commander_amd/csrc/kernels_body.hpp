@@ -532,8 +532,10 @@ CMDR_HD void fft_dit_pass(cd* buf, int log2M, int hl, const cd* __restrict__ tw,
 }
 
 // K radix-2 DIF stages (halves h<<(K-1), .., 2h, h).  natural order in -> bit-reversed order out.
+// post (optional, last pass only): store conj(v) * post[position] instead of v -- the Bluestein spectrum product
 template <int K>
-CMDR_HD void fft_dif_pass(cd* buf, int log2M, int hl, const cd* __restrict__ tw, int log2Mmax, FftCtx c) {
+CMDR_HD void fft_dif_pass(cd* buf, int log2M, int hl, const cd* __restrict__ tw, int log2Mmax, FftCtx c,
+                          const cd* __restrict__ post = nullptr) {
     constexpr int N = 1 << K;
     const int ngroups = 1 << (log2M - K);
     const int hmask = (1 << hl) - 1;
@@ -558,8 +560,16 @@ CMDR_HD void fft_dif_pass(cd* buf, int log2M, int hl, const cd* __restrict__ tw,
                 v[j + (1 << t)] = t == 0 ? d : (t == 1 ? rot_const<1>(d, j & 1) : rot_const<2>(d, j & 3));
             }
         }
+        if (post) {
 #pragma unroll
-        for (int j = 0; j < N; ++j) buf[lds_pad(i0 + (j << hl))] = v[j];
+            for (int j = 0; j < N; ++j) {
+                const int i = i0 + (j << hl);
+                buf[lds_pad(i)] = cmul(cconj(v[j]), post[i]);
+            }
+        } else {
+#pragma unroll
+            for (int j = 0; j < N; ++j) buf[lds_pad(i0 + (j << hl))] = v[j];
+        }
     }
     CMDR_BLOCK_SYNC();
 }
@@ -572,11 +582,13 @@ CMDR_HD void fft_dit_plus(cd* buf, int log2M, const cd* __restrict__ tw, int log
     for (; hl < log2M; hl += 3) fft_dit_pass<3>(buf, log2M, hl, tw, log2Mmax, c);
 }
 
-CMDR_HD void fft_dif_plus(cd* buf, int log2M, const cd* __restrict__ tw, int log2Mmax, FftCtx c) {
+CMDR_HD void fft_dif_plus(cd* buf, int log2M, const cd* __restrict__ tw, int log2Mmax, FftCtx c,
+                          const cd* __restrict__ post = nullptr) {
     const int k0 = log2M % 3;
-    for (int hl = log2M - 3; hl >= k0; hl -= 3) fft_dif_pass<3>(buf, log2M, hl, tw, log2Mmax, c);
-    if (k0 == 1) fft_dif_pass<1>(buf, log2M, 0, tw, log2Mmax, c);
-    else if (k0 == 2) fft_dif_pass<2>(buf, log2M, 0, tw, log2Mmax, c);
+    for (int hl = log2M - 3; hl >= k0; hl -= 3)
+        fft_dif_pass<3>(buf, log2M, hl, tw, log2Mmax, c, (hl == 0) ? post : nullptr);
+    if (k0 == 1) fft_dif_pass<1>(buf, log2M, 0, tw, log2Mmax, c, post);
+    else if (k0 == 2) fft_dif_pass<2>(buf, log2M, 0, tw, log2Mmax, c, post);
 }
 
 CMDR_HD int d_bitrev(int v, int bits) {
@@ -632,8 +644,10 @@ CMDR_HD void ring_scatter(cd* buf, const RingDev& d, const double* __restrict__ 
                           const cd* __restrict__ rot, const cd* __restrict__ w, FftCtx c) {
     const int n = d.nphi, M = 1 << d.log2M, mmax = d.mmax_eff;
     const bool flip = d.phi0 != 0.0;
-    for (int j = c.tid; j < (BLUE ? M : n); j += c.nthr) buf[lds_pad(j)] = {0.0, 0.0};
-    CMDR_BLOCK_SYNC();
+    // slots nobody writes below: mmax < j < n - mmax, and the Bluestein padding n <= j < M  (disjoint: no barrier)
+    for (int j = mmax + 1 + c.tid; j < n - mmax; j += c.nthr) buf[lds_pad(BLUE ? j : d_bitrev(j, d.log2M))] = {0.0, 0.0};
+    if (BLUE)
+        for (int j = n + c.tid; j < M; j += c.nthr) buf[lds_pad(j)] = {0.0, 0.0};
     constexpr int U = 4;
     for (int m0 = c.tid; m0 <= mmax; m0 += U * c.nthr) {
         double f[U][4];
@@ -679,58 +693,46 @@ CMDR_HD void idft_put(cd* buf, const FftSub& f, int j, cd v) {
     else buf[lds_pad(d_bitrev(j, f.log2M))] = v;
 }
 
-// Inverse DFT y_k = sum_j Z_j e^{+2 pi i jk/n} of slots placed with idft_put(); result in buf[lds_pad(k)], k < n.
+// Inverse DFT y_k = sum_j Z_j e^{+2 pi i jk/n} of slots placed with idft_put().  The result is read with idft_at():
+// the closing Bluestein factor w_k / M is applied on read, so that callers fold it into whatever pass touches the
+// pixels next instead of paying an LDS round trip for it.
 CMDR_HD void idft_core(cd* buf, const FftSub& f, const cd* __restrict__ tw, int log2Mmax, FftCtx c) {
     if (!f.bluestein) {
         fft_dit_plus(buf, f.log2M, tw, log2Mmax, c);
         return;
     }
-    // a_j = Z_j w_j ; F^-(a) = conj(F^+(conj a))
-    const int M = 1 << f.log2M;
-    fft_dif_plus(buf, f.log2M, tw, log2Mmax, c);
-    for (int p = c.tid; p < M; p += c.nthr) buf[lds_pad(p)] = cmul(cconj(buf[lds_pad(p)]), f.chat[p]);
-    CMDR_BLOCK_SYNC();
+    // a_j = Z_j w_j ; F^-(a) = conj(F^+(conj a)); the product with the chirp spectrum rides on the last DIF store
+    fft_dif_plus(buf, f.log2M, tw, log2Mmax, c, f.chat);
     fft_dit_plus(buf, f.log2M, tw, log2Mmax, c);
-    const double inv = 1.0 / (double)M;
-    for (int k = c.tid; k < f.n; k += c.nthr) {
-        const cd v = cmul(buf[lds_pad(k)], f.w[k]);
-        buf[lds_pad(k)] = {v.x * inv, v.y * inv};
-    }
-    CMDR_BLOCK_SYNC();
+}
+CMDR_HD cd idft_at(const cd* buf, const FftSub& f, int k) {
+    const cd v = buf[lds_pad(k)];
+    if (!f.bluestein) return v;
+    const double inv = 1.0 / (double)(1 << f.log2M);
+    const cd r = cmul(v, f.w[k]);
+    return {r.x * inv, r.y * inv};
 }
 
-// Forward DFT Z_j = sum_k z_k e^{-2 pi i jk/n} of z_k = buf[lds_pad(k)], k < n; read the result with dft_at().
+// Forward DFT Z_j = sum_k z_k e^{-2 pi i jk/n}.  Input form (dft_put, k < n; Bluestein images need zeros in n..M-1):
+// power of two conj(z_k), Bluestein z_k conj(w_k).  Read the result with dft_at().
+CMDR_HD cd dft_in(const FftSub& f, int k, cd z) {
+    if (!f.bluestein) return cconj(z);
+    return cmul(z, cconj(f.w[k]));        // conj(a_k), a_k = conj(z_k) w_k
+}
 CMDR_HD void dft_core(cd* buf, const FftSub& f, const cd* __restrict__ tw, int log2Mmax, FftCtx c) {
-    const int n = f.n, M = 1 << f.log2M;
     if (!f.bluestein) {
-        // Z = conj(F^+(conj z)); DIF leaves it bit-reversed
-        for (int k = c.tid; k < n; k += c.nthr) buf[lds_pad(k)] = cconj(buf[lds_pad(k)]);
-        CMDR_BLOCK_SYNC();
-        fft_dif_plus(buf, f.log2M, tw, log2Mmax, c);
+        fft_dif_plus(buf, f.log2M, tw, log2Mmax, c);   // Z = conj(F^+(conj z)); DIF leaves it bit-reversed
     } else {
         // conj(Z)_j = w_j sum_k (conj(z_k) w_k) conj(w_{j-k})  (same chirp machinery)
-        for (int k = c.tid; k < M; k += c.nthr) {
-            cd v = {0.0, 0.0};
-            if (k < n) v = cconj(cmul(cconj(buf[lds_pad(k)]), f.w[k]));   // conj(a_k), a_k = conj(z_k) w_k
-            buf[lds_pad(k)] = v;
-        }
-        CMDR_BLOCK_SYNC();
-        fft_dif_plus(buf, f.log2M, tw, log2Mmax, c);
-        for (int p = c.tid; p < M; p += c.nthr) buf[lds_pad(p)] = cmul(cconj(buf[lds_pad(p)]), f.chat[p]);
-        CMDR_BLOCK_SYNC();
+        fft_dif_plus(buf, f.log2M, tw, log2Mmax, c, f.chat);
         fft_dit_plus(buf, f.log2M, tw, log2Mmax, c);
-        const double inv = 1.0 / (double)M;
-        for (int j = c.tid; j < n; j += c.nthr) {
-            const cd v = cmul(buf[lds_pad(j)], f.w[j]);      // conj(Z_j) * M
-            buf[lds_pad(j)] = {v.x * inv, -v.y * inv};       // Z_j, natural order
-        }
-        CMDR_BLOCK_SYNC();
     }
 }
-
 CMDR_HD cd dft_at(const cd* buf, const FftSub& f, int j) {
     if (!f.bluestein) return cconj(buf[lds_pad(d_bitrev(j, f.log2M))]);
-    return buf[lds_pad(j)];
+    const double inv = 1.0 / (double)(1 << f.log2M);
+    const cd v = cmul(buf[lds_pad(j)], f.w[j]);          // conj(Z_j) * M
+    return {v.x * inv, -v.y * inv};
 }
 
 CMDR_HD FftSub ring_fft_desc(const RingDev& d, const cd* __restrict__ chirp) {
@@ -835,6 +837,42 @@ CMDR_HD cd ring_split_input(const double* __restrict__ ph, int64_t npair_pad, in
 
 // Whole ring-pair job of one workgroup.  MODE 0: phases -> map (* mul * weight); 1: map (* mul * weight) -> phases;
 // 2: phases -> pixels * mul -> phases (the fused Y^t N^-1 Y core of the matvec; the map never exists in HBM).
+// Every pointwise step (Bluestein's closing chirp factor, the pixel multiplier, the analysis input form, zero padding)
+// is folded into the one pass that touches the pixels.
+template <int MODE>
+CMDR_HD void ring_pixels(cd* buf, const FftSub& f, int npix, int k1, int kstep, const RingDev& d,
+                         double* __restrict__ mp, const double* __restrict__ mu, double wg, FftCtx c) {
+    // LDS element k2 <-> ring pixel k = k1 + kstep * k2 (kstep = 2 for the halves of a split ring)
+    const int M = 1 << f.log2M;
+    if (MODE == 0) {
+        for (int k2 = c.tid; k2 < npix; k2 += c.nthr) {
+            const int k = k1 + kstep * k2;
+            const cd v = idft_at(buf, f, k2);
+            mp[d.startN + k] = v.x * (wg * (mu ? mu[d.startN + k] : 1.0));
+            if (d.startS >= 0) mp[d.startS + k] = v.y * (wg * (mu ? mu[d.startS + k] : 1.0));
+        }
+        return;
+    }
+    for (int k2 = c.tid; k2 < (f.bluestein ? M : npix); k2 += c.nthr) {
+        cd o = {0.0, 0.0};
+        if (k2 < npix) {
+            const int k = k1 + kstep * k2;
+            cd z;
+            if (MODE == 1) {
+                z = {mp[d.startN + k] * (wg * (mu ? mu[d.startN + k] : 1.0)), 0.0};
+                if (d.startS >= 0) z.y = mp[d.startS + k] * (wg * (mu ? mu[d.startS + k] : 1.0));
+            } else {
+                z = idft_at(buf, f, k2);
+                z.x *= mu[d.startN + k];
+                z.y = d.startS >= 0 ? z.y * mu[d.startS + k] : 0.0;
+            }
+            o = dft_in(f, k2, z);
+        }
+        buf[lds_pad(k2)] = o;
+    }
+    CMDR_BLOCK_SYNC();
+}
+
 template <int MODE>
 CMDR_HD void ring_block(cd* buf, const RingDev& d, int pair, double* __restrict__ php, int64_t npair_pad,
                         double* __restrict__ mp, const double* __restrict__ mu, double wg,
@@ -844,31 +882,8 @@ CMDR_HD void ring_block(cd* buf, const RingDev& d, int pair, double* __restrict_
     const FftSub f = ring_fft_desc(d, chirp);
     if (!d.split) {
         if (MODE == 0 || MODE == 2) ring_synth_lds(buf, d, php, npair_pad, pair, tw, log2Mmax, chirp, c);
-        if (MODE == 0) {
-            for (int k = c.tid; k < n; k += c.nthr) {
-                const cd v = buf[lds_pad(k)];
-                mp[d.startN + k] = v.x * (wg * (mu ? mu[d.startN + k] : 1.0));
-                if (d.startS >= 0) mp[d.startS + k] = v.y * (wg * (mu ? mu[d.startS + k] : 1.0));
-            }
-            return;
-        }
-        if (MODE == 1) {
-            for (int k = c.tid; k < n; k += c.nthr) {
-                cd v = {mp[d.startN + k] * (wg * (mu ? mu[d.startN + k] : 1.0)), 0.0};
-                if (d.startS >= 0) v.y = mp[d.startS + k] * (wg * (mu ? mu[d.startS + k] : 1.0));
-                buf[lds_pad(k)] = v;
-            }
-            CMDR_BLOCK_SYNC();
-        }
-        if (MODE == 2) {
-            for (int k = c.tid; k < n; k += c.nthr) {
-                cd v = buf[lds_pad(k)];
-                v.x *= mu[d.startN + k];
-                v.y = d.startS >= 0 ? v.y * mu[d.startS + k] : 0.0;
-                buf[lds_pad(k)] = v;
-            }
-            CMDR_BLOCK_SYNC();
-        }
+        ring_pixels<MODE>(buf, f, n, 0, 1, d, mp, mu, wg, c);
+        if (MODE == 0) return;
         dft_core(buf, f, tw, log2Mmax, c);
         ring_store_phases(SpecDirect{buf, f}, d, php, npair_pad, pair, chirp, c);
         return;
@@ -885,34 +900,10 @@ CMDR_HD void ring_block(cd* buf, const RingDev& d, int pair, double* __restrict_
             CMDR_BLOCK_SYNC();
             idft_core(buf, f, tw, log2Mmax, c);
         }
+        ring_pixels<MODE>(buf, f, h, k1, 2, d, mp, mu, wg, c);
         if (MODE == 0) {
-            for (int k2 = c.tid; k2 < h; k2 += c.nthr) {
-                const int k = k1 + 2 * k2;
-                const cd v = buf[lds_pad(k2)];
-                mp[d.startN + k] = v.x * (wg * (mu ? mu[d.startN + k] : 1.0));
-                if (d.startS >= 0) mp[d.startS + k] = v.y * (wg * (mu ? mu[d.startS + k] : 1.0));
-            }
             CMDR_BLOCK_SYNC();
             continue;
-        }
-        if (MODE == 1) {
-            for (int k2 = c.tid; k2 < h; k2 += c.nthr) {
-                const int k = k1 + 2 * k2;
-                cd v = {mp[d.startN + k] * (wg * (mu ? mu[d.startN + k] : 1.0)), 0.0};
-                if (d.startS >= 0) v.y = mp[d.startS + k] * (wg * (mu ? mu[d.startS + k] : 1.0));
-                buf[lds_pad(k2)] = v;
-            }
-            CMDR_BLOCK_SYNC();
-        }
-        if (MODE == 2) {
-            for (int k2 = c.tid; k2 < h; k2 += c.nthr) {
-                const int k = k1 + 2 * k2;
-                cd v = buf[lds_pad(k2)];
-                v.x *= mu[d.startN + k];
-                v.y = d.startS >= 0 ? v.y * mu[d.startS + k] : 0.0;
-                buf[lds_pad(k2)] = v;
-            }
-            CMDR_BLOCK_SYNC();
         }
         dft_core(buf, f, tw, log2Mmax, c);
         if (k1 == 0) {
