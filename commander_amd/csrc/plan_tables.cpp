@@ -430,7 +430,9 @@ void RingTables::build(int nside_, int lmax_, const std::vector<int>& rings, con
     }
     if (std::getenv("CMDR_DEBUG_PLAN")) std::fprintf(stderr, "[cmdr] ring plan nside=%d: %d pairs, %d split (line %d), log2Mmax %d\n", nside, npair, nsplit, split_line, log2Mmax);
     classes.assign(log2Mmax + 1, {});
-    for (int p = 0; p < npair; ++p) classes[pairs[p].log2M].push_back(p);
+    // launch classes = LDS image size; the short rings (a few hundred workgroups per size) share one launch
+    const int kMinClass = std::min(log2Mmax, 10);
+    for (int p = 0; p < npair; ++p) classes[std::max(pairs[p].log2M, kMinClass)].push_back(p);
     const int Mmax = 1 << log2Mmax;
     twiddle.resize(Mmax);  // Mmax/2 complex
     for (int k = 0; k < Mmax / 2; ++k) {
