@@ -486,6 +486,12 @@ void CrSystem::compute_rhs(bool sample, const double* const* resid, const double
     }
     adjoint_groups_to_yc(true);                                                      // beam, F_mean :616-639
     // rhs = S^1/2 yc + eta + S^-1/2 mu   (:652-659, :690-728)
+    if (sample && only_pol_) {   // no temperature fluctuation term: "if (j == 1 .and. only_pol) cycle" (:705)
+        CMDR_HIP_CHECK(hipMemcpyAsync(q_.get(), eta, ncr_ * sizeof(double), hipMemcpyDeviceToDevice, stream_));
+        for (const Comp& C : comps_)
+            CMDR_HIP_CHECK(hipMemsetAsync(q_.get() + C.d.pos, 0, C.d.nalm * sizeof(double), stream_));
+        eta = q_.get();
+    }
     const double* add = nullptr;
     if (mu) {
         launch_sqrtS(comps_dev_.get(), ncomp, lmax_max_, smat_.get(), 1, mu, sample ? eta : nullptr, tmp_.get(), false,

@@ -190,3 +190,8 @@ def test_varying_mixing_polarised_gpu():
     ctx.initPrecond("pseudoinv"); ctx.update_precond()
     S.init_precond_pseudoinv(); S.update_precond_pseudoinv()
     assert rel(ctx.cr_invM(x), S.invM(x)) < 1e-10
+
+
+def test_edge_cases_gpu():
+    from helpers import edge_case_checks
+    edge_case_checks()

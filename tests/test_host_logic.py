@@ -258,3 +258,8 @@ def test_emul_pseudoinv_precond_vs_oracle(EL, pol):
     S.init_precond_diag()
     S.update_precond_diag()
     assert rel(ctx.cr_invM(x), S.invM(x)) < 1e-11
+
+
+def test_emul_edge_cases(EL):
+    from helpers import edge_case_checks
+    edge_case_checks(_lib=EL, tol=1e-12)
