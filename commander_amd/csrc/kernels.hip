@@ -342,15 +342,16 @@ __global__ void __launch_bounds__(1024) k_ring(const RingDev* __restrict__ rings
                                               const cd* __restrict__ tw, int log2Mmax,
                                               const cd* __restrict__ chirp, cd* __restrict__ scratch,
                                               int64_t scratch_map_stride, int scratch_line, int ncls, int nmaps,
-                                              int per) {
+                                              int per, int xbl) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     cd* buf = reinterpret_cast<cd*>(smem);
-    // Workgroups with equal blockIdx % 8 share an XCD (and its L2).  Give each of the 8 groups a contiguous run of the
-    // class's ring pairs and let it walk pair-major, map-minor: the maps of one pair re-use the pair's chirp / rotation
-    // tables from L2, and neighbouring pairs, whose phases share cache lines, stay on one XCD.
+    // Workgroups with equal blockIdx % 8 share an XCD (and its L2).  Deal the class's ring pairs to the 8 groups in
+    // blocks of 2^xbl neighbours (4 pairs x 32 B = one 128-B line of the phase array) and let each group walk pair-major,
+    // map-minor: the maps of one pair re-use the pair's chirp / rotation tables from L2, line-sharing neighbours stay
+    // on one XCD, and cheap (belt) and expensive (Bluestein, split) rings spread evenly over the XCDs.
     const int grp = blockIdx.x & 7, slot = blockIdx.x >> 3;
     const int pl = slot / nmaps, imap = slot - pl * nmaps;
-    const int idx = grp * per + pl;
+    const int idx = (((pl >> xbl) * 8 + grp) << xbl) + (pl & ((1 << xbl) - 1));
     if (pl >= per || idx >= ncls) return;
     const int pair = cls[idx];
     const RingDev d = rings[pair];
@@ -369,7 +370,10 @@ void launch_ring(int mode, const RingDev* rings, const int* cls, int ncls, int l
     int nthr = 512;   // measured: 512 > 256 threads per ring pair (more waves to cover LDS / global latency)
     if (const char* e = std::getenv("CMDR_RING_THREADS")) { const int v = std::atoi(e); if (v == 256 || v == 512 || v == 1024) nthr = v; }
     if (nthr > (1 << log2M) / 2) nthr = std::max(64, (1 << log2M) / 2);
-    const int per = (ncls + 7) / 8;
+    static int xbl = -1;                      // log2 of the pairs per block
+    if (xbl < 0) { xbl = 4; if (const char* e = std::getenv("CMDR_RING_XBL")) { const int v = std::atoi(e); if (v >= 0 && v <= 10) xbl = v; } }
+    const int xb = 1 << xbl;
+    const int per = ((ncls + 8 * xb - 1) / (8 * xb)) * xb;   // pairs per XCD group: whole blocks
     dim3 grid(8 * per * nmaps);
 #define CMDR_RING(MM)                                                                                            \
     do {                                                                                                         \
@@ -381,7 +385,7 @@ void launch_ring(int mode, const RingDev* rings, const int* cls, int ncls, int l
         }                                                                                                        \
         hipLaunchKernelGGL(k_ring<MM>, grid, dim3(nthr), lds, s, rings, cls, ph, ph_stride, npair_pad, map,      \
                            map_stride, mul, weighted, tw, log2Mmax, chirp, scratch, scratch_map_stride,          \
-                           scratch_line, ncls, nmaps, per);                                                      \
+                           scratch_line, ncls, nmaps, per, xbl);                                                 \
     } while (0)
     if (mode == 0) CMDR_RING(0);
     else if (mode == 1) CMDR_RING(1);
