@@ -457,12 +457,12 @@ void ShtTables::build(int nside_, int lmax_, const std::vector<int>& rings_in, c
     }
     const int np = (int)rings.size();
     // 4 ring pairs per lane: amortises the adjoint's cross-lane reduction and the scalar coefficient stream of the
-    // synthesis (measured optimum on MI355X; tunable through CMDR_LEG_R / CMDR_LEG_RS).  Small problems (ring-sharded
-    // ranks: 256 pairs at Nside 1024 on 8 GPUs) keep the wave count up instead: at least 4 chunks per m for the
-    // synthesis, 2 for the adjoint (measured with tools/cr_time_rank.py).
-    int R = 4, Rs = 4;
-    while (R > 1 && np < 128 * R) R >>= 1;
-    while (Rs > 1 && np < 256 * Rs) Rs >>= 1;
+    // synthesis (measured optimum on MI355X; tunable through CMDR_LEG_R / CMDR_LEG_RS).  Ring-sharded ranks (256
+    // pairs at Nside 1024 on 8 GPUs) keep R = 4 for the adjoint -- the batches of a launch are fused, so even one
+    // chunk per m fills the GPU -- and run the synthesis with 2 (measured with tools/cr_time_rank.py).
+    int R = 4, Rs = np >= 2048 ? 4 : 2;
+    while (R > 1 && np < 64 * R) R >>= 1;
+    while (Rs > 1 && np < 64 * Rs) Rs >>= 1;
     if (const char* e = std::getenv("CMDR_LEG_R")) { const int v = std::atoi(e); if (v == 1 || v == 2 || v == 4) R = v; }
     if (const char* e = std::getenv("CMDR_LEG_RS")) { const int v = std::atoi(e); if (v == 1 || v == 2 || v == 4) Rs = v; }
     (void)max_maps;
