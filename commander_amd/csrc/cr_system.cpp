@@ -6,7 +6,7 @@
 
 namespace cmdr {
 
-CrSystem::CrSystem(int device) : device_(device) {
+CrSystem::CrSystem(int device) {
     CMDR_HIP_CHECK(hipSetDevice(device));
     CMDR_HIP_CHECK(hipStreamCreate(&stream_));
 }

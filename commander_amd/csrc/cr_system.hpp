@@ -79,7 +79,7 @@ class CrSystem {
 
   private:
     struct Band {
-        int nside, lmax, nmaps, group = -1, bm0 = 0;
+        int nside, lmax, nmaps, group = -1;
         double mb_eff;
         std::vector<double> b_l;            // (lmax+1) x nmaps, column-major
         DevBuf<double> siN, mul;            // npix_local x nmaps: 1/rms (* samp-group mask), and siN^2 * mask
@@ -139,7 +139,6 @@ class CrSystem {
     long long prof_n_[4] = {0, 0, 0, 0};
     void reduce(double* v, int64_t n);
 
-    int device_;
     hipStream_t stream_ = nullptr;
     std::vector<Band> bands_;
     std::vector<Comp> comps_;

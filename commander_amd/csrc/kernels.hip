@@ -15,7 +15,7 @@ namespace cmdr {
 // scalar unit.  Measured on MI355X (tools/microbench/fp64_synth.hip): fp64 FMA sustains ~61 TFLOP/s (clock ~1.9 GHz
 // under load), scalar-cache hits are free, scalar-cache MISSES sustain only ~1.5 B/clk/CU, and LDS broadcast reads
 // ~4 B/clk/CU -- so the stream bytes per VALU cycle, not the VALU itself, bound how many maps can share one
-// recursion.  (R = 4, NB <= 2) is the measured optimum; an LDS-staged variant was slower (register pressure).
+// recursion.  (R = 4, NB = 3) is the measured optimum; an LDS-staged variant was slower (register pressure).
 template <int R, int NB>
 __global__ void __launch_bounds__(256) k_leg_synth(LegArgs A, const WaveTask* __restrict__ tasks, int ntasks,
                                                    const double* __restrict__ ast, int nbs, int k0, int rep,

@@ -27,7 +27,6 @@ class LegendreDev {  // device mirror of LegendreTables
 class Legendre2Dev {  // device mirror of Legendre2Tables
   public:
     void upload(const Legendre2Tables& T);
-    Leg2Args args() const;
     int lmax = -1, npair_pad = 0, R = 2, nchunk = 0, ntasks = 0;
     DevBuf<double> x, seed, alpha, beta, cnorm;
     DevBuf<int> ls;
