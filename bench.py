@@ -138,11 +138,25 @@ def main():
     if dist is not None:
         import torch
 
-        def allreduce(ptr, n):
-            t = torch.as_tensor(CudaView(ptr, n), device="cuda:%d" % local_rank)
-            dist.all_reduce(t)
-            torch.cuda.synchronize()
-        ctx.set_allreduce(allreduce)
+        views = {}
+
+        def allreduce(ptr, n, stream):
+            # RCCL all-reduce ordered on the library's own stream: torch makes its NCCL stream wait for the current
+            # stream before the collective and the current stream wait for the collective after it, so nothing here
+            # blocks the host and a whole fixed_iter solve stays queued ahead of the GPU
+            key = (ptr, n)
+            if key not in views:
+                views[key] = torch.as_tensor(CudaView(ptr, n), device="cuda:%d" % local_rank)
+            with torch.cuda.stream(torch.cuda.ExternalStream(stream, device="cuda:%d" % local_rank)):
+                dist.all_reduce(views[key])
+        if os.environ.get("CMDR_BENCH_BLOCKING_ALLREDUCE") == "1":   # the MPI-style blocking callback, for comparison
+            def allreduce_blocking(ptr, n):
+                t = torch.as_tensor(CudaView(ptr, n), device="cuda:%d" % local_rank)
+                dist.all_reduce(t)
+                torch.cuda.synchronize()
+            ctx.set_allreduce(allreduce_blocking)
+        else:
+            ctx.set_allreduce_stream(allreduce)
     ctx.initPrecond()
     ctx.update_precond()
     resid, xi, eta = synth.draw_inputs(spec)

@@ -15,6 +15,7 @@ from .lib import CmdrError, check
 _dp = ctypes.POINTER(ctypes.c_double)
 _vp = ctypes.c_void_p
 ALLREDUCE_CB = ctypes.CFUNCTYPE(None, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64)
+ALLREDUCE_STREAM_CB = ctypes.CFUNCTYPE(None, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64, ctypes.c_void_p)
 
 CRIT = {"residual": 0, "fixed_iter": 1}  # cpar%cg_conv_crit (comm_cr_mod.f90:220-229); 'chisq' is not on this path
 
@@ -99,6 +100,15 @@ class CRContext:
         cb = ALLREDUCE_CB(_cb)
         self._keep.append(cb)
         check(self.L.cmdr_ctx_set_allreduce(self._h, ctypes.cast(cb, _vp), None), self.L)
+
+    def set_allreduce_stream(self, fn):
+        """fn(dev_ptr: int, n: int, hip_stream: int) ENQUEUES the in-place sum over ranks on the library's stream
+        (RCCL through torch.cuda.ExternalStream in bench.py); no host synchronisation per matvec."""
+        def _cb(user, ptr, n, stream):
+            fn(ptr, n, stream or 0)
+        cb = ALLREDUCE_STREAM_CB(_cb)
+        self._keep.append(cb)
+        check(self.L.cmdr_ctx_set_allreduce_stream(self._h, ctypes.cast(cb, _vp), None), self.L)
 
     def set_only_pol(self, flag):
         check(self.L.cmdr_ctx_set_only_pol(self._h, int(bool(flag))), self.L)

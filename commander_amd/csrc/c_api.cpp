@@ -234,6 +234,12 @@ int cmdr_ctx_set_allreduce(cmdr_ctx* ctx, cmdr_allreduce_fn fn, void* user) {
         ctx->sys->set_allreduce(fn, user);
     });
 }
+int cmdr_ctx_set_allreduce_stream(cmdr_ctx* ctx, cmdr_allreduce_stream_fn fn, void* user) {
+    return guarded([&] {
+        CMDR_REQUIRE(ctx, "ctx is NULL");
+        ctx->sys->set_allreduce_stream(fn, user);
+    });
+}
 int cmdr_ctx_set_only_pol(cmdr_ctx* ctx, int only_pol) {
     return guarded([&] {
         CMDR_REQUIRE(ctx, "ctx is NULL");

@@ -407,6 +407,10 @@ void CrSystem::mix_adjoint(Group& G, bool rhs) {
 }
 
 void CrSystem::reduce(double* v, int64_t n) {
+    if (allreduce_s_) {   // stream-ordered collective: stays queued behind the kernels that produced v
+        allreduce_s_(allreduce_s_user_, v, n, reinterpret_cast<void*>(stream_));
+        return;
+    }
     if (!allreduce_) return;
     sync();
     allreduce_(allreduce_user_, v, n);

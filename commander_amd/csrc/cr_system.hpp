@@ -24,6 +24,8 @@ namespace cmdr {
 // the library stream idle; must return with the result complete.  The host language supplies it
 // (torch.distributed / RCCL in bench.py, MPI in the Fortran driver).
 using AllreduceFn = void (*)(void* user, double* dev_ptr, int64_t n);
+// Stream-ordered variant: enqueue the sum on the library stream and return (RCCL); no host synchronisation.
+using AllreduceStreamFn = void (*)(void* user, double* dev_ptr, int64_t n, void* hip_stream);
 
 struct SolveResult {
     int niter = 0;
@@ -47,6 +49,7 @@ class CrSystem {
     void set_mixing_map(int comp, int band, const double* F, int nmaps);
     void set_cl_diag(int comp, const double* cl);   // getCl(l, p): (lmax_cl+1) x nmaps, for the pseudo-inverse U
     void set_allreduce(AllreduceFn fn, void* user) { allreduce_ = fn; allreduce_user_ = user; }
+    void set_allreduce_stream(AllreduceStreamFn fn, void* user) { allreduce_s_ = fn; allreduce_s_user_ = user; }
     void set_only_pol(bool v) { only_pol_ = v; }
 
     int64_t ncr() const { return ncr_; }
@@ -161,6 +164,8 @@ class CrSystem {
     bool pinv_init_ = false;
     AllreduceFn allreduce_ = nullptr;
     void* allreduce_user_ = nullptr;
+    AllreduceStreamFn allreduce_s_ = nullptr;
+    void* allreduce_s_user_ = nullptr;
 };
 
 }  // namespace cmdr

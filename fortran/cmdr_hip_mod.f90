@@ -79,6 +79,14 @@ module cmdr_hip_mod
        integer(c_int)        :: ierr
      end function cmdr_ctx_set_allreduce
 
+     ! stream-ordered variant (RCCL-style): fn(user, dev_ptr, n, hip_stream) enqueues the sum on hip_stream
+     function cmdr_ctx_set_allreduce_stream(ctx, fn, user) bind(c, name='cmdr_ctx_set_allreduce_stream') result(ierr)
+       import :: c_int, c_ptr, c_funptr
+       type(c_ptr),    value :: ctx, user
+       type(c_funptr), value :: fn
+       integer(c_int)        :: ierr
+     end function cmdr_ctx_set_allreduce_stream
+
      function cmdr_band_add(ctx, nside, lmax, nmaps, siN, b_l, mb_eff, sg_mask, wring) &
           & bind(c, name='cmdr_band_add') result(idx)
        import :: c_int, c_ptr, c_double

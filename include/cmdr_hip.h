@@ -92,6 +92,11 @@ int cmdr_ctx_set_rings(cmdr_ctx* ctx, int nside, int nrings, const int* rings);
  * (comm_utils.f90:599-614). */
 typedef void (*cmdr_allreduce_fn)(void* user, double* dev_ptr, int64_t n);
 int cmdr_ctx_set_allreduce(cmdr_ctx* ctx, cmdr_allreduce_fn fn, void* user);
+/* Stream-ordered variant for collective libraries that take a stream (RCCL): fn must ENQUEUE the in-place sum on
+ * hip_stream (the library's own hipStream_t) and may return before it has run.  No host synchronisation happens per
+ * matvec then, so a whole fixed_iter solve is queued ahead of the GPU.  Takes precedence over the blocking callback. */
+typedef void (*cmdr_allreduce_stream_fn)(void* user, double* dev_ptr, int64_t n, void* hip_stream);
+int cmdr_ctx_set_allreduce_stream(cmdr_ctx* ctx, cmdr_allreduce_stream_fn fn, void* user);
 int cmdr_ctx_set_only_pol(cmdr_ctx* ctx, int only_pol);
 
 /* data(i): comm_data_mod.f90:33-63.  siN = 1/rms (0 in masked pixels, comm_N_rms_mod.f90:179-193),
