@@ -44,7 +44,10 @@ def _worker(rank, world, port, out_dir, mode):
         buf = np.ctypeslib.as_array(ctypes.cast(ptr, ctypes.POINTER(ctypes.c_double)), shape=(n,))
         t = torch.from_numpy(buf)
         dist.all_reduce(t)
-    ctx.set_allreduce(allreduce)
+    if mode == "stream":   # the stream-ordered callback variant (RCCL in bench.py); the emulation has no streams
+        ctx.set_allreduce_stream(lambda ptr, n, stream: allreduce(ptr, n))
+    else:
+        ctx.set_allreduce(allreduce)
     ctx.initPrecond("pseudoinv" if mode == "varying" else "diagonal")
     ctx.update_precond()
     x = np.random.default_rng(5).standard_normal(ctx.ncr)
@@ -58,7 +61,7 @@ def _worker(rank, world, port, out_dir, mode):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("mode", ["const", "varying"])
+@pytest.mark.parametrize("mode", ["const", "varying", "stream"])
 def test_two_rank_ring_sharding_matches_single_rank(tmp_path, mode):
     import torch.multiprocessing as mp
     from helpers import emul_lib, rel
