@@ -9,10 +9,29 @@ namespace cmdr {
 CrSystem::CrSystem(int device) {
     CMDR_HIP_CHECK(hipSetDevice(device));
     CMDR_HIP_CHECK(hipStreamCreate(&stream_));
+    CMDR_HIP_CHECK(hipStreamCreate(&stream_ring_));
+    if (const char* e = std::getenv("CMDR_PIPELINE")) pipeline_ = std::atoi(e) != 0;
 }
 
 CrSystem::~CrSystem() {
+    for (Group& G : groups_) {
+        for (hipEvent_t e : G.ev_synth) (void)hipEventDestroy(e);
+        for (hipEvent_t e : G.ev_ring) (void)hipEventDestroy(e);
+    }
+    if (stream_ring_) (void)hipStreamDestroy(stream_ring_);
     if (stream_) (void)hipStreamDestroy(stream_);
+}
+
+bool CrSystem::pipelined(const Group& G) const { return pipeline_ && G.npol == 0 && G.nT > kPipeBatch; }
+
+void CrSystem::pipeline_events(Group& G, int nbatch) {
+    while ((int)G.ev_synth.size() < nbatch) {
+        hipEvent_t a, b;
+        CMDR_HIP_CHECK(hipEventCreateWithFlags(&a, hipEventDisableTiming));
+        CMDR_HIP_CHECK(hipEventCreateWithFlags(&b, hipEventDisableTiming));
+        G.ev_synth.push_back(a);
+        G.ev_ring.push_back(b);
+    }
 }
 
 void CrSystem::sync() { CMDR_HIP_CHECK(hipStreamSynchronize(stream_)); }
@@ -40,26 +59,28 @@ void CrSystem::problem_info(int64_t* out) const {
     out[2] = steps;
 }
 
-void CrSystem::span_begin(int kind) {
+void CrSystem::span_begin(int kind, hipStream_t st) {
     if (!profile_) return;
     Span s;
     s.kind = kind;
+    s.s = st ? st : stream_;
     CMDR_HIP_CHECK(hipEventCreate(&s.a));
     CMDR_HIP_CHECK(hipEventCreate(&s.b));
-    CMDR_HIP_CHECK(hipEventRecord(s.a, stream_));
+    CMDR_HIP_CHECK(hipEventRecord(s.a, s.s));
     spans_.push_back(s);
     open_.push_back((int)spans_.size() - 1);
 }
 
 void CrSystem::span_end() {
     if (!profile_) return;
-    CMDR_HIP_CHECK(hipEventRecord(spans_[open_.back()].b, stream_));
+    CMDR_HIP_CHECK(hipEventRecord(spans_[open_.back()].b, spans_[open_.back()].s));
     open_.pop_back();
 }
 
 void CrSystem::read_profile(double* ms_sum, long long* count) {
     if (!spans_.empty()) {
         sync();
+        CMDR_HIP_CHECK(hipStreamSynchronize(stream_ring_));
         for (Span& s : spans_) {
             float ms = 0.f;
             CMDR_HIP_CHECK(hipEventElapsedTime(&ms, s.a, s.b));
@@ -423,8 +444,18 @@ void CrSystem::adjoint_groups_to_yc(bool from_maps) {
         Group& G = groups_[g];
         ShtPlan& P = *G.plan;
         span_begin(2);
-        P.adjoint_to_partials(G.nT, false, stream_);
-        if (G.npol) P.adjoint2_to_partials(G.npol, G.nT, stream_);
+        if (G.ring_pending) {
+            const int nbatch = (G.nT + kPipeBatch - 1) / kPipeBatch;
+            for (int j = 0; j < nbatch; ++j) {
+                const int k0 = j * kPipeBatch, nb = std::min(kPipeBatch, G.nT - k0);
+                CMDR_HIP_CHECK(hipStreamWaitEvent(stream_, G.ev_ring[j], 0));
+                P.adjoint_range(k0, nb, stream_);
+            }
+            G.ring_pending = false;
+        } else {
+            P.adjoint_to_partials(G.nT, false, stream_);
+            if (G.npol) P.adjoint2_to_partials(G.npol, G.nT, stream_);
+        }
         span_end();
         launch_band_post(comps_dev_.get(), ncomp, lmax_max_, P.partials(), P.part_map_stride(), P.leg().tri_elems(),
                          P.leg().nchunk, G.nT, G.bm_stokes_dev.get(), G.w.get(), P.leg().cnorm.get(), G.lmax,
@@ -453,6 +484,25 @@ void CrSystem::matmulA(const double* x, double* y) {
         if (G.npol)
             launch_band_prep2(comps_dev_.get(), ncomp, sx_.get(), G.w.get(), G.nT, P.stream2(), G.npol,
                               P.leg2().cnorm.get(), G.lmax, stream_, extra);
+        if (pipelined(G)) {
+            // batches of 3 maps: Y of batch j+1 (main stream, VALU-bound) beside N^-1 of batch j (ring stream, LDS-bound)
+            const int nbatch = (G.nT + kPipeBatch - 1) / kPipeBatch;
+            pipeline_events(G, nbatch);
+            span_begin(0);
+            for (int j = 0; j < nbatch; ++j) {
+                const int k0 = j * kPipeBatch, nb = std::min(kPipeBatch, G.nT - k0);
+                P.synth_range(k0, nb, G.nT, stream_);
+                CMDR_HIP_CHECK(hipEventRecord(G.ev_synth[j], stream_));
+                CMDR_HIP_CHECK(hipStreamWaitEvent(stream_ring_, G.ev_synth[j], 0));
+                span_begin(1, stream_ring_);
+                P.rings_fused_range(k0, nb, G.mul_ptrs.get(), stream_ring_);
+                span_end();
+                CMDR_HIP_CHECK(hipEventRecord(G.ev_ring[j], stream_ring_));
+            }
+            span_end();
+            G.ring_pending = true;
+            continue;
+        }
         span_begin(0);
         P.synth_from_stream(G.nT, stream_);                                          // Y        :891 (T: spin 0)
         if (G.npol) P.synth2_from_stream(G.npol, G.nT, stream_);                     // (Q,U): spin 2, comm_map_mod.f90:446

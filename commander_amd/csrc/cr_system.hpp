@@ -118,6 +118,8 @@ class CrSystem {
         DevBuf<int> bm_stokes_dev;
         DevBuf<const double*> mul_ptrs;     // [nbm]
         DevBuf<double> tmpmap;              // [nbm][npix_local] (RHS only; allocated lazily)
+        std::vector<hipEvent_t> ev_synth, ev_ring;   // pipelined matvec: per batch of maps
+        bool ring_pending = false;          // the adjoint must wait for ev_ring
         DevBuf<double> bl;                  // [nbm][lmax+1]  b_l * mb_eff of each band map
         // spatially varying mixing
         std::vector<MixBatch> mix;
@@ -133,9 +135,18 @@ class CrSystem {
     void mix_adjoint(Group& G, bool rhs);
     void apply_pseudoinv(const double* x, double* y);
     void adjoint_groups_to_yc(bool from_maps);
-    struct Span { hipEvent_t a, b; int kind; };
-    void span_begin(int kind);
+    static constexpr int kPipeBatch = 3;   // maps per pipeline stage = maps per Legendre recursion at R = 4
+    struct Span { hipEvent_t a, b; int kind; hipStream_t s; };
+    void span_begin(int kind, hipStream_t s = nullptr);   // nullptr: the main stream
     void span_end();
+    // Pipelined matvec (T-only plans with more than one batch of maps): the LDS-bound ring stage of batch j runs on a
+    // second stream beside the VALU-bound Legendre synthesis of batch j+1 / adjoint of batch j-1.  OFF by default
+    // (CMDR_PIPELINE=1 enables it): measured 12.6 ms against 12.2 ms serial at cfg3 -- a ring workgroup (8 waves,
+    // 147 KB LDS) does not fit beside a CU full of Legendre waves (register file), so the streams only time-slice.
+    bool pipelined(const Group& G) const;
+    void pipeline_events(Group& G, int nbatch);
+    hipStream_t stream_ring_ = nullptr;
+    bool pipeline_ = false;
     std::vector<Span> spans_;
     std::vector<int> open_;
     double prof_ms_[4] = {0, 0, 0, 0};

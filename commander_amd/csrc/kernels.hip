@@ -182,10 +182,11 @@ static void for_batches(int nmaps, int nbmax, F f) {
     }
 }
 void launch_leg_synth(const LegArgs& A, const WaveTask* tasks, int ntasks, const double* ast, double* ph,
-                      int64_t ph_stride, int nmaps, hipStream_t s) {
+                      int64_t ph_stride, int nmaps, hipStream_t s, int nbs) {
     if (ntasks == 0 || nmaps == 0) return;
+    if (nbs < 0) nbs = nmaps;
     for_batches(nmaps, leg_batch(A.R, false), [&](int nb, int k0, int rep) {
-#define CMDR_S(RR, NN) case NN: synth_RN<RR, NN>(A, tasks, ntasks, ast, nmaps, k0, rep, ph, ph_stride, s); break;
+#define CMDR_S(RR, NN) case NN: synth_RN<RR, NN>(A, tasks, ntasks, ast, nbs, k0, rep, ph, ph_stride, s); break;
         if (A.R == 1) {
             switch (nb) { CMDR_S(1, 1) CMDR_S(1, 2) CMDR_S(1, 3) CMDR_S(1, 4) CMDR_S(1, 5) CMDR_S(1, 6) CMDR_S(1, 7)
                           CMDR_S(1, 8) CMDR_S(1, 9) }

@@ -12,8 +12,9 @@ namespace cmdr {
 
 // coefficient stream: maps interleaved, ast[((t * nmaps) + k) * 2 + {re, im}]
 int leg_max_batch(int R);
+// nbs: maps interleaved in the stream buffer (default nmaps); a sub-range of maps is addressed by shifting ast / ph
 void launch_leg_synth(const LegArgs& A, const WaveTask* tasks, int ntasks, const double* ast, double* ph,
-                      int64_t ph_stride, int nmaps, hipStream_t s);
+                      int64_t ph_stride, int nmaps, hipStream_t s, int nbs = -1);
 void launch_leg_adj(const LegArgs& A, const WaveTask* tasks, int ntasks, const double* ph, int64_t ph_stride,
                     double* part, int64_t part_map_stride, int64_t part_chunk_stride, int nmaps, bool square,
                     hipStream_t s);

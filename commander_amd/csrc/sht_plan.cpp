@@ -122,6 +122,28 @@ void ShtPlan::rings(int mode, double* d_map, int64_t map_stride, const double* c
     }
 }
 
+void ShtPlan::synth_range(int k0, int n, int nbs, hipStream_t s) {
+    launch_leg_synth(leg_.args_synth(), leg_.tasks_s.get(), leg_.ntasks_s, ast_.get() + 2 * k0,
+                     ph_.get() + (int64_t)k0 * leg_.ph_elems(), leg_.ph_elems(), n, s, nbs);
+}
+
+void ShtPlan::rings_fused_range(int k0, int n, const double* const* d_mul, hipStream_t s) {
+    const int64_t sms = (int64_t)T_.ring.nsplit * T_.ring.split_line;
+    for (size_t c = 0; c < cls_.size(); ++c) {
+        if (!ncls_[c]) continue;
+        launch_ring(2, rings_.get(), cls_[c].get(), ncls_[c], (int)c, ph_.get() + (int64_t)k0 * leg_.ph_elems(),
+                    leg_.ph_elems(), leg_.npair_pad, nullptr, 0, d_mul + k0, 0,
+                    reinterpret_cast<const cd*>(tw_.get()), T_.ring.log2Mmax,
+                    reinterpret_cast<const cd*>(chirp_.get()),
+                    reinterpret_cast<cd*>(ring_scratch_.get()) + (int64_t)k0 * sms, sms, T_.ring.split_line, n, s);
+    }
+}
+
+void ShtPlan::adjoint_range(int k0, int n, hipStream_t s) {
+    launch_leg_adj(leg_.args(), leg_.tasks.get(), leg_.ntasks, ph_.get() + (int64_t)k0 * leg_.ph_elems(), leg_.ph_elems(),
+                   part_.get() + (int64_t)k0 * part_map_stride(), part_map_stride(), leg_.tri_elems(), n, false, s);
+}
+
 void ShtPlan::adjoint_to_partials(int nmaps, bool square, hipStream_t s) {
     launch_leg_adj(leg_.args(), leg_.tasks.get(), leg_.ntasks, ph_.get(), leg_.ph_elems(), part_.get(),
                    part_map_stride(), leg_.tri_elems(), nmaps, square, s);

@@ -78,6 +78,11 @@ class ShtPlan {
     void rings(int mode, double* d_map, int64_t map_stride, const double* const* d_mul, bool weighted, int nmaps,
                hipStream_t s);                                                       // see launch_ring
     void adjoint_to_partials(int nmaps, bool square, hipStream_t s);                 // phases -> partials
+    // the same three stages on maps k0 .. k0+n-1 of a stream holding nbs maps (pipelined matvec: the ring stage of
+    // one batch runs beside the Legendre stage of the next)
+    void synth_range(int k0, int n, int nbs, hipStream_t s);
+    void rings_fused_range(int k0, int n, const double* const* d_mul, hipStream_t s);
+    void adjoint_range(int k0, int n, hipStream_t s);
     const LegendreDev& leg() const { return leg_; }
 
   private:

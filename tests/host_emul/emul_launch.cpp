@@ -21,11 +21,12 @@ static void synth_RN(const LegArgs& A, const WaveTask* tasks, int ntasks, const 
                                   tasks[t].lAend, lane);
 }
 void launch_leg_synth(const LegArgs& A, const WaveTask* tasks, int ntasks, const double* ast, double* ph,
-                      int64_t ph_stride, int nmaps, hipStream_t) {
+                      int64_t ph_stride, int nmaps, hipStream_t, int nbs) {
+    if (nbs < 0) nbs = nmaps;
     const int nbmax = leg_max_batch(A.R);
     for (int k0 = 0; k0 < nmaps; k0 += nbmax) {
         const int nb = std::min(nbmax, nmaps - k0);
-#define CMDR_S(RR, NN) case NN: synth_RN<RR, NN>(A, tasks, ntasks, ast, nmaps, k0, ph, ph_stride); break;
+#define CMDR_S(RR, NN) case NN: synth_RN<RR, NN>(A, tasks, ntasks, ast, nbs, k0, ph, ph_stride); break;
         if (A.R == 1) {
             switch (nb) { CMDR_S(1, 1) CMDR_S(1, 2) CMDR_S(1, 3) CMDR_S(1, 4) CMDR_S(1, 5) CMDR_S(1, 6) CMDR_S(1, 7)
                           CMDR_S(1, 8) CMDR_S(1, 9) }

@@ -26,6 +26,9 @@ inline hipError_t hipStreamCreate(hipStream_t* s) { *s = nullptr; return 0; }
 inline hipError_t hipStreamDestroy(hipStream_t) { return 0; }
 typedef void* hipEvent_t;
 inline hipError_t hipEventCreate(hipEvent_t* e) { *e = nullptr; return 0; }
+inline hipError_t hipEventCreateWithFlags(hipEvent_t* e, unsigned) { *e = nullptr; return 0; }
+inline hipError_t hipStreamWaitEvent(hipStream_t, hipEvent_t, unsigned) { return 0; }
+constexpr unsigned hipEventDisableTiming = 2;
 inline hipError_t hipEventRecord(hipEvent_t, hipStream_t) { return 0; }
 inline hipError_t hipEventSynchronize(hipEvent_t) { return 0; }
 inline hipError_t hipEventElapsedTime(float* ms, hipEvent_t, hipEvent_t) { *ms = 0.f; return 0; }

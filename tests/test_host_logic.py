@@ -263,3 +263,25 @@ def test_emul_pseudoinv_precond_vs_oracle(EL, pol):
 def test_emul_edge_cases(EL):
     from helpers import edge_case_checks
     edge_case_checks(_lib=EL, tol=1e-12)
+
+
+def test_emul_nine_band_pipelined_matvec(EL):
+    """9 Planck-like bands at a toy size against the oracle, on the serial path and on the optional pipelined one
+    (CMDR_PIPELINE=1: ring stage of a 3-map batch on its own stream)."""
+    import os
+    from commander_amd import synth
+    from commander_amd.cr import build_context
+    spec = synth.make_problem("cfg3", nside=8, lmax=16)
+    S = oracle_system(spec)
+    x = np.random.default_rng(3).standard_normal(S.ncr)
+    ref = S.matmulA(x)
+    ctx = build_context(spec, _lib=EL)
+    assert rel(ctx.cr_matmulA(x), ref) < 1e-12
+    resid, xi, eta = synth.draw_inputs(spec)
+    assert rel(ctx.cr_computeRHS("sample", resid, xi, eta), S.computeRHS(resid, "sample", xi, eta)) < 1e-12
+    os.environ["CMDR_PIPELINE"] = "1"
+    try:
+        ctx1 = build_context(spec, _lib=EL)
+        assert rel(ctx1.cr_matmulA(x), ref) < 1e-12
+    finally:
+        del os.environ["CMDR_PIPELINE"]
