@@ -69,7 +69,16 @@ def cpu_baseline(spec, nthreads):
         reps += 1
     nb = len(spec["bands"])
     pairs_per_solve = nb * (NITER + 1) + nb * 0.5
+    cpu = "unknown"
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                cpu = line.split(":", 1)[1].strip()
+                break
+    except OSError:
+        pass
     return {"value": 1.0 / (pairs_per_solve * t_pair), "unit": "solves/s", "cores": nthreads, "kind": "port",
+            "cpu": cpu,
             "sample": "best of %d Yt+Y pairs (oracle/sht_oracle.c, OpenMP) at Nside=%d lmax=%d = %.2f s each; "
                       "extrapolated x %.1f pairs per solve" % (reps, nside, lmax, t_pair, pairs_per_solve)}
 
@@ -231,6 +240,9 @@ def main():
                                    "peak equals the vector peak)",
                          "avg_launch_ms": t_leg * 1e3, "launches": nl, "flop_per_launch": flop_launch,
                          "hbm_iter_gbs": b_iter / t_mv / 1e9 if t_mv else None,
+                         # whole-matvec fp64 view (SURVEY.md 8d F_iter, mlim-pruned): synthesis + adjoint flops over
+                         # the matvec wall time, ring stage and streams included
+                         "fp64_iter_tflops": 2.0 * flop_launch / t_mv / 1e12 if t_mv else None,
                          "hbm_iter_frac": b_iter / t_mv / 1e9 / HBM_PEAK_GBS if t_mv else None,
                          "ms": {"leg_synth": ms[0] / max(int(cnt[0]), 1), "ring_fused": ms[1] / max(int(cnt[1]), 1),
                                 "leg_adjoint": ms[2] / max(int(cnt[2]), 1), "matvec": ms[3] / max(int(cnt[3]), 1)}},
