@@ -35,6 +35,139 @@ __global__ void __launch_bounds__(256) k_leg_synth(LegArgs A, const WaveTask* __
     leg_synth_lane<R, NB>(A, ast, nbs, k0, ph, ph_stride, m, chunk, lw, lAend, threadIdx.x & 63);
 }
 
+// Synthesis, workgroup form: the 4 waves of a workgroup are 4 adjacent chunks of ONE m (LegArgs::wg).  The column's
+// coefficients (NB complex a_lm entries and alpha per l) are fetched once per workgroup by coalesced vector loads,
+// staged through a double-buffered LDS tile of kTileL l values and read back as LDS broadcasts (uniform VGPR
+// operands): the scalar-cache miss bandwidth (~1.5 B/clk/CU, measured) that bounds k_leg_synth no longer enters.
+constexpr int kTileL = 32;
+template <int R, int NB>
+__global__ void __launch_bounds__(256) k_leg_synth_wg(LegArgs A, const WaveTask* __restrict__ tasks, int ntasks,
+                                                      const double* __restrict__ ast, int nbs, int k0, int rep,
+                                                      double* __restrict__ ph, int64_t ph_stride) {
+    constexpr int ROW = 2 * NB + 2;                     // doubles per l: NB x (re, im), alpha_{l+1}, pad
+    constexpr int NE = kTileL * ROW;                    // doubles per tile
+    constexpr int NLD = (NE + 255) / 256;               // global loads per thread and tile
+    __shared__ __attribute__((aligned(16))) double tile[2][NE];
+    const int wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    const int tb = blockIdx.x / rep;
+    k0 += (blockIdx.x % rep) * NB;
+    const WaveTask T = tasks[tb * 4 + wid];
+    const int m = __builtin_amdgcn_readfirstlane(tasks[tb * 4].m);
+    int lw0 = tasks[tb * 4].lw;
+#pragma unroll
+    for (int i = 1; i < 4; ++i) lw0 = min(lw0, tasks[tb * 4 + i].lw);
+    lw0 = __builtin_amdgcn_readfirstlane(lw0);
+    const int chunk = __builtin_amdgcn_readfirstlane(T.chunk);
+    const int lw = __builtin_amdgcn_readfirstlane(T.lw);
+    const int lAend = __builtin_amdgcn_readfirstlane(T.lAend);
+    const int lmax = A.lmax;
+    const int64_t mo = d_moffp(lmax, m);
+    const double* __restrict__ al = A.alpha + (mo - m);
+    const double* __restrict__ as = ast + 2 * ((int64_t)nbs * (mo - m) + k0);
+    const int64_t ls2 = 2 * (int64_t)nbs;
+    // per-lane state (as leg_synth_lane)
+    double x[R], mc[R], mp[R], sc[R], sp[R];
+    double Er[R][NB], Ei[R][NB], Or[R][NB], Oi[R][NB];
+    int ls[R];
+    const int base = (chunk < 0 ? 0 : chunk) * 64 * R + lane;
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        const int p = base + r * 64;
+        const int64_t idx = (int64_t)m * A.npair_pad + p;
+        x[r] = A.x[p];
+        ls[r] = chunk < 0 ? 0x7fffffff : A.ls[idx];
+        sc[r] = A.seedc[idx];
+        sp[r] = A.seedp[idx];
+        mc[r] = mp[r] = 0.0;
+#pragma unroll
+        for (int k = 0; k < NB; ++k) Er[r][k] = Ei[r][k] = Or[r][k] = Oi[r][k] = 0.0;
+    }
+    // tile element e -> (row = l - lb, col): col < 2 NB: stream double, col == 2 NB: alpha_{l+1}
+    auto fetch = [&](int lb, double* v) {
+#pragma unroll
+        for (int i = 0; i < NLD; ++i) {
+            const int e = (int)threadIdx.x + 256 * i;
+            const int row = e / ROW, col = e - row * ROW;
+            const int l = lb + row;
+            double val = 0.0;
+            if (e < NE && l <= lmax + 1) {
+                if (col < 2 * NB) val = as[ls2 * l + col];
+                else if (col == 2 * NB) val = al[l + 1];
+            }
+            v[i] = val;
+        }
+    };
+    double pre[NLD];
+    const int ntile = (lmax - lw0) / kTileL + 1;
+    fetch(lw0, pre);
+    for (int t = 0; t < ntile; ++t) {
+        double* cur = tile[t & 1];
+#pragma unroll
+        for (int i = 0; i < NLD; ++i) {
+            const int e = (int)threadIdx.x + 256 * i;
+            if (e < NE) cur[e] = pre[i];
+        }
+        __syncthreads();                                  // tile t visible; tile t-1 (same buffer as t+1) fully consumed
+        const int lb = lw0 + t * kTileL;
+        if (t + 1 < ntile) fetch(lb + kTileL, pre);       // in flight while this tile is consumed
+        if (chunk < 0 || lb + kTileL <= lw) continue;     // this wave has not started yet (wave-uniform)
+        const int lend = min(lb + kTileL, lmax + 1);
+        int l = max(lb, lw);
+        for (; l < lend && l < lAend; l += 2) {           // Phase A: lanes switch on at their own ls
+            const double* __restrict__ c0 = cur + (l - lb) * ROW;
+            const double* __restrict__ c1 = c0 + ROW;
+            const double al1 = c0[2 * NB], al2 = c1[2 * NB];
+#pragma unroll
+            for (int r = 0; r < R; ++r) {
+                if (ls[r] == l) { mc[r] = sc[r]; mp[r] = sp[r]; }
+#pragma unroll
+                for (int k = 0; k < NB; ++k) { Er[r][k] += mc[r] * c0[2 * k]; Ei[r][k] += mc[r] * c0[2 * k + 1]; }
+                double tt = al1 * x[r] * mc[r] - mp[r];
+                mp[r] = mc[r];
+                mc[r] = tt;
+                if (ls[r] == l + 1) { mc[r] = sc[r]; mp[r] = sp[r]; }
+#pragma unroll
+                for (int k = 0; k < NB; ++k) { Or[r][k] += mc[r] * c1[2 * k]; Oi[r][k] += mc[r] * c1[2 * k + 1]; }
+                tt = al2 * x[r] * mc[r] - mp[r];
+                mp[r] = mc[r];
+                mc[r] = tt;
+            }
+        }
+        for (; l < lend; l += 2) {                        // Phase B: pure recursion + accumulate
+            const double* __restrict__ c0 = cur + (l - lb) * ROW;
+            const double* __restrict__ c1 = c0 + ROW;
+            const double al1 = c0[2 * NB], al2 = c1[2 * NB];
+#pragma unroll
+            for (int r = 0; r < R; ++r) {
+#pragma unroll
+                for (int k = 0; k < NB; ++k) { Er[r][k] += mc[r] * c0[2 * k]; Ei[r][k] += mc[r] * c0[2 * k + 1]; }
+                double tt = al1 * x[r] * mc[r] - mp[r];
+                mp[r] = mc[r];
+                mc[r] = tt;
+#pragma unroll
+                for (int k = 0; k < NB; ++k) { Or[r][k] += mc[r] * c1[2 * k]; Oi[r][k] += mc[r] * c1[2 * k + 1]; }
+                tt = al2 * x[r] * mc[r] - mp[r];
+                mp[r] = mc[r];
+                mc[r] = tt;
+            }
+        }
+    }
+    if (chunk < 0) return;
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        const int p = base + r * 64;
+#pragma unroll
+        for (int k = 0; k < NB; ++k) {
+            double* o = ph + (k0 + k) * ph_stride + ((int64_t)m * A.npair_pad + p) * 4;
+            o[0] = Er[r][k] + Or[r][k];
+            o[1] = Ei[r][k] + Oi[r][k];
+            o[2] = Er[r][k] - Or[r][k];
+            o[3] = Ei[r][k] - Oi[r][k];
+        }
+    }
+}
+
 // ---- wave-wide reduction of 16 values per lane -------------------------------------------------------------
 // v[0..15] per lane -> on return the lanes with (lane & 3) == 0 hold sum_{64 lanes} v[lane >> 2].
 // Two register butterfly steps with the gfx950 row / half swaps (v_permlane32_swap, v_permlane16_swap) fold the four
@@ -163,8 +296,12 @@ int leg_max_batch(int R) { return leg_batch(R, false); }
 template <int R, int NB>
 static void synth_RN(const LegArgs& A, const WaveTask* tasks, int ntasks, const double* ast, int nbs, int k0, int rep,
                      double* ph, int64_t ph_stride, hipStream_t s) {
-    hipLaunchKernelGGL((k_leg_synth<R, NB>), dim3((ntasks / 4) * rep), dim3(256), 0, s, A, tasks, ntasks, ast, nbs, k0,
-                       rep, ph, ph_stride);
+    if (A.wg && R >= 2 && NB <= 4)
+        hipLaunchKernelGGL((k_leg_synth_wg<(R >= 2 ? R : 2), (NB <= 4 ? NB : 4)>), dim3((ntasks / 4) * rep), dim3(256), 0,
+                           s, A, tasks, ntasks, ast, nbs, k0, rep, ph, ph_stride);
+    else
+        hipLaunchKernelGGL((k_leg_synth<R, NB>), dim3((ntasks / 4) * rep), dim3(256), 0, s, A, tasks, ntasks, ast, nbs,
+                           k0, rep, ph, ph_stride);
 }
 // balanced split of nmaps into batches of at most nbmax maps, e.g. 9 -> 3+3+3, 8 -> 3+3+2; consecutive batches of
 // equal size share one launch: calls f(nb, k0, rep)

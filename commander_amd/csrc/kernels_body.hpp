@@ -47,6 +47,7 @@ struct LegArgs {
     const double* seedc;   // mu_{ls}
     const double* seedp;   // mu_{ls-1}
     const double* alpha;   // [ntrip]
+    int wg;                // synthesis task list grouped by m: the 4 tasks of a workgroup are 4 chunks of one m
 };
 
 // ---------------------------------------------------------------------------------------------------------

@@ -143,9 +143,31 @@ void LegendreTables::build(int lmax_, const std::vector<double>& x_, const std::
     group = 4;
     make_tasks(Rs, tm);
     tasks_s.clear();
-    for (int m = 0; m < nm; ++m) tasks_s.insert(tasks_s.end(), tm[m].begin(), tm[m].end());
-    std::stable_sort(tasks_s.begin(), tasks_s.end(), [](const WaveTask& a, const WaveTask& b) { return a.lw < b.lw; });
-    while (tasks_s.size() % 4) { WaveTask t; t.m = 0; t.chunk = -1; t.lw = lmax + 1; t.lAend = lmax + 1; tasks_s.push_back(t); }
+    synth_wg = false;
+    bool want_wg = nchunk_s % 4 == 0;
+    if (const char* e = std::getenv("CMDR_SYNTH_WG")) want_wg = want_wg && std::atoi(e) != 0;
+    if (want_wg) {
+        // workgroup = 4 adjacent chunks of one m: the coefficient stream of the column is staged through LDS once
+        // per workgroup instead of being streamed through the scalar cache by every wave (k_leg_synth_wg)
+        struct Grp { int lw; WaveTask t[4]; };
+        std::vector<Grp> groups;
+        for (int m = 0; m < nm; ++m)
+            for (int g = 0; g < nchunk_s / 4; ++g) {
+                Grp G;
+                G.lw = lmax + 2;
+                for (int k = 0; k < 4; ++k) { G.t[k].m = m; G.t[k].chunk = -1; G.t[k].lw = lmax + 2; G.t[k].lAend = lmax + 2; }
+                for (const WaveTask& t : tm[m])
+                    if (t.chunk / 4 == g) { G.t[t.chunk % 4] = t; G.lw = std::min(G.lw, t.lw); }
+                if (G.lw <= lmax) groups.push_back(G);
+            }
+        std::stable_sort(groups.begin(), groups.end(), [](const Grp& a, const Grp& b) { return a.lw < b.lw; });
+        for (const Grp& G : groups) tasks_s.insert(tasks_s.end(), G.t, G.t + 4);
+        synth_wg = true;
+    } else {
+        for (int m = 0; m < nm; ++m) tasks_s.insert(tasks_s.end(), tm[m].begin(), tm[m].end());
+        std::stable_sort(tasks_s.begin(), tasks_s.end(), [](const WaveTask& a, const WaveTask& b) { return a.lw < b.lw; });
+        while (tasks_s.size() % 4) { WaveTask t; t.m = 0; t.chunk = -1; t.lw = lmax + 1; t.lAend = lmax + 1; tasks_s.push_back(t); }
+    }
 }
 
 // --------------------------------------------------------------------------------------------- spin-2 tables

@@ -35,6 +35,7 @@ struct LegendreTables {
     // adjoint kernel: R pairs per lane, one task per wavefront, 4 per workgroup, longest first
     std::vector<WaveTask> tasks;
     int group = 4;
+    bool synth_wg = false;               // tasks_s grouped: tasks_s[4i .. 4i+3] = 4 chunks of one m (chunk = -1: none)
     // synthesis kernel: Rs pairs per lane, same layout (its own list so R and Rs can be tuned independently)
     int Rs = 1, nchunk_s = 0;
     std::vector<WaveTask> tasks_s;

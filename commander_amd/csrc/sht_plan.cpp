@@ -8,6 +8,7 @@ void LegendreDev::upload(const LegendreTables& T) {
     R = T.R;
     nchunk = T.nchunk;
     Rs = T.Rs;
+    synth_wg = T.synth_wg;
     ntasks_s = (int)T.tasks_s.size();
     tasks_s.upload(T.tasks_s);
     ntasks = (int)T.tasks.size();
@@ -30,12 +31,14 @@ LegArgs LegendreDev::args() const {
     A.seedc = seedc.get();
     A.seedp = seedp.get();
     A.alpha = alpha.get();
+    A.wg = 0;
     return A;
 }
 
 LegArgs LegendreDev::args_synth() const {
     LegArgs A = args();
     A.R = Rs;
+    A.wg = synth_wg ? 1 : 0;
     return A;
 }
 
