@@ -296,8 +296,8 @@ int leg_max_batch(int R) { return leg_batch(R, false); }
 template <int R, int NB>
 static void synth_RN(const LegArgs& A, const WaveTask* tasks, int ntasks, const double* ast, int nbs, int k0, int rep,
                      double* ph, int64_t ph_stride, hipStream_t s) {
-    if (A.wg && R >= 2 && NB <= 4)
-        hipLaunchKernelGGL((k_leg_synth_wg<(R >= 2 ? R : 2), (NB <= 4 ? NB : 4)>), dim3((ntasks / 4) * rep), dim3(256), 0,
+    if (A.wg && NB <= 4)
+        hipLaunchKernelGGL((k_leg_synth_wg<R, (NB <= 4 ? NB : 4)>), dim3((ntasks / 4) * rep), dim3(256), 0,
                            s, A, tasks, ntasks, ast, nbs, k0, rep, ph, ph_stride);
     else
         hipLaunchKernelGGL((k_leg_synth<R, NB>), dim3((ntasks / 4) * rep), dim3(256), 0, s, A, tasks, ntasks, ast, nbs,
@@ -322,7 +322,7 @@ void launch_leg_synth(const LegArgs& A, const WaveTask* tasks, int ntasks, const
                       int64_t ph_stride, int nmaps, hipStream_t s, int nbs) {
     if (ntasks == 0 || nmaps == 0) return;
     if (nbs < 0) nbs = nmaps;
-    for_batches(nmaps, leg_batch(A.R, false), [&](int nb, int k0, int rep) {
+    for_batches(nmaps, A.wg ? std::min(leg_batch(A.R, false), 4) : leg_batch(A.R, false), [&](int nb, int k0, int rep) {
 #define CMDR_S(RR, NN) case NN: synth_RN<RR, NN>(A, tasks, ntasks, ast, nbs, k0, rep, ph, ph_stride, s); break;
         if (A.R == 1) {
             switch (nb) { CMDR_S(1, 1) CMDR_S(1, 2) CMDR_S(1, 3) CMDR_S(1, 4) CMDR_S(1, 5) CMDR_S(1, 6) CMDR_S(1, 7)

@@ -478,13 +478,14 @@ void ShtTables::build(int nside_, int lmax_, const std::vector<int>& rings_in, c
         sth[p] = r.sth;
     }
     const int np = (int)rings.size();
-    // 4 ring pairs per lane: amortises the adjoint's cross-lane reduction and the scalar coefficient stream of the
-    // synthesis (measured optimum on MI355X; tunable through CMDR_LEG_R / CMDR_LEG_RS).  Ring-sharded ranks (256
-    // pairs at Nside 1024 on 8 GPUs) keep R = 4 for the adjoint -- the batches of a launch are fused, so even one
-    // chunk per m fills the GPU -- and run the synthesis with 2 (measured with tools/cr_time_rank.py).
-    int R = 4, Rs = np >= 2048 ? 4 : 2;
+    // Adjoint: 4 ring pairs per lane amortise the cross-lane reduction (also on small ring-sharded ranks: the batches
+    // of a launch are fused, so even one chunk per m fills the GPU).  Synthesis: 2 pairs per lane (higher occupancy;
+    // its coefficients come through LDS in the workgroup form, which needs the chunks of an m in groups of 4 -- 1 pair
+    // per lane where 2 would leave fewer than 4 chunks, e.g. 256-pair shards).  Measured with tools/cr_time.py and
+    // tools/cr_time_rank.py; tunable through CMDR_LEG_R / CMDR_LEG_RS.
+    int R = 4, Rs = 2;
     while (R > 1 && np < 64 * R) R >>= 1;
-    while (Rs > 1 && np < 64 * Rs) Rs >>= 1;
+    while (Rs > 1 && (np < 64 * Rs || ((np + 64 * R - 1) / (64 * R) * R / Rs) % 4 != 0)) Rs >>= 1;
     if (const char* e = std::getenv("CMDR_LEG_R")) { const int v = std::atoi(e); if (v == 1 || v == 2 || v == 4) R = v; }
     if (const char* e = std::getenv("CMDR_LEG_RS")) { const int v = std::atoi(e); if (v == 1 || v == 2 || v == 4) Rs = v; }
     (void)max_maps;
