@@ -4,6 +4,7 @@ Nothing upstream pins this path (the reference has no tests and no fixtures: SUR
 produced by checkers that are independent of both the oracle's recursions/FFTs and the HIP kernels:
   * sht_bruteforce_nside{4,8}.npz : dense direct sums over scipy.special.sph_harm_y (oracle/bruteforce.py)
   * invn_diag_3j.npz              : compute_invN_lm evaluated literally with exact Racah-formula 3j symbols
+  * invn_diag_3j_map.npz          : the same together with the noise map it belongs to (pins the product's pipeline)
   * lm2i_tables.json              : Commander's a_lm index maps for lmax=4, P=1 and P=3 (comm_map_mod.f90:228-261)
   * kat.json                      : the reference's own 2x2 PCG known-answer test and the fiducial dipole constants
 """
@@ -61,5 +62,21 @@ def main():
     json.dump(kat, open(os.path.join(HERE, "kat.json"), "w"), indent=1)
 
 
+def invn_map():
+    """invn_diag_3j_map.npz: a noise map siN^2 together with compute_invN_lm (comm_N_mod.f90:127-197) evaluated
+    literally with exact 3j symbols from the map's a_l0 -- pins the product's whole invN_diag pipeline (YtW of the map,
+    then the diagonal), not only the oracle's quadrature.  Own seed, so the older fixtures stay byte-identical."""
+    rng = np.random.default_rng(20261005)
+    nside, lmax = 4, 12
+    siN2 = 1.0 + 0.5 * rng.random(12 * nside * nside)
+    al0 = sht.YtW(nside, lmax, siN2)[: lmax + 1]
+    np.savez_compressed(os.path.join(HERE, "invn_diag_3j_map.npz"), nside=nside, lmax=lmax, siN2=siN2, al0=al0,
+                        diag=wigner.invn_diag_3j(nside, lmax, al0))
+
+
 if __name__ == "__main__":
-    main()
+    if len(sys.argv) > 1 and sys.argv[1] == "invn_map":
+        invn_map()
+    else:
+        main()
+        invn_map()

@@ -91,3 +91,63 @@ def edge_case_checks(_lib=None, tol=1e-11):
         xg, ng, sg, _ = ctx.solve_cr_eqn_by_CG(b, "fixed_iter", maxiter=nit)
         xo, no, so = S.solve(b, "fixed_iter", maxiter=nit)
         assert rel(xg, xo) < 1e-9, (nside, lmax, clm)
+
+
+def golden_checks(_lib=None, tol=1e-12):
+    """The product against the committed golden vectors directly (tests/golden, independent of oracle/): brute-force
+    spherical-harmonic sums for all four SHT jobs (spin 0, Nside 4 and 8) and the spin-2 pair (Nside 4), and the
+    literal Wigner-3j evaluation of compute_invN_lm through the CR-level preconditioner setup."""
+    import commander_amd.sht as shtmod
+    from commander_amd.sht import ShtPlan
+    from commander_amd.cr import CRContext
+    G = os.path.join(ROOT, "tests", "golden")
+    old = shtmod.lib
+    if _lib is not None:
+        shtmod.lib = lambda: _lib
+    try:
+        for nside in (4, 8):
+            g = np.load(os.path.join(G, "sht_bruteforce_nside%d.npz" % nside))
+            ns, lmax, w = int(g["nside"]), int(g["lmax"]), g["wring"]
+            plan = ShtPlan(ns, lmax, wring=w, max_maps=1)
+            assert rel(plan.Y(g["alm"][:, None])[:, 0], g["Y"]) < tol
+            assert rel(plan.Yt(g["map"][:, None])[:, 0], g["Yt"]) < tol
+            assert rel(plan.YtW(g["map"][:, None])[:, 0], g["YtW"]) < tol
+            assert rel(plan.WY(g["alm"][:, None])[:, 0], g["WY"]) < tol
+        g = np.load(os.path.join(G, "sht_spin2_bruteforce_nside4.npz"))
+        ns, lmax = int(g["nside"]), int(g["lmax"])
+        plan = ShtPlan(ns, lmax, max_maps=2, pol=True)
+        q, u = plan.execute_spin2(1, almE=g["almE"], almB=g["almB"])
+        assert rel(np.concatenate([q, u]), np.concatenate([g["Y_Q"], g["Y_U"]])) < tol
+        e, b = plan.execute_spin2(2, mapQ=g["mapQ"], mapU=g["mapU"])
+        assert rel(np.concatenate([e, b]), np.concatenate([g["Yt_E"], g["Yt_B"]])) < tol
+    finally:
+        shtmod.lib = old
+    # compute_invN_lm: noise map in, literal 3j evaluation of the diagonal out (initDiffPrecond_diagonal's first half)
+    g = np.load(os.path.join(G, "invn_diag_3j_map.npz"))
+    ns, lmax = int(g["nside"]), int(g["lmax"])
+    ctx = CRContext(0, _lib=_lib)
+    ctx.add_band(ns, lmax, np.sqrt(g["siN2"]), np.ones(lmax + 1))
+    ctx.add_comp(lmax, 1, np.ones((1, 1)), None, None, None, True)
+    ctx.finalize()
+    ctx.initPrecond()
+    assert rel(ctx.invN_diag(0)[:, 0], g["diag"]) < 1e-11
+
+
+def golden_kat(_lib=None):
+    """The reference's only known-answer test (todscripts/wmap/cg_solver.py:54-61: A = [[3,2],[2,6]], b = [2,-8],
+    M = I  =>  x = [2,-2]) has no 2x2 realisation in the CR operator; its recurrence is pinned on the oracle
+    (tests/test_oracle.py) and the device PCG is pinned against the oracle's recurrence iteration by iteration."""
+    from commander_amd import synth
+    from commander_amd.cr import build_context
+    spec = synth.make_problem("cfg1", nside=4, lmax=6)
+    S = oracle_system(spec)
+    ctx = build_context(spec, _lib=_lib)
+    ctx.initPrecond(); ctx.update_precond(); S.init_precond_diag(); S.update_precond_diag()
+    resid, xi, eta = synth.draw_inputs(spec)
+    b = S.computeRHS(resid, "sample", xi, eta)
+    for nit in (1, 2, 3, 7):
+        xg, ng, sg, res = ctx.solve_cr_eqn_by_CG(b, "fixed_iter", maxiter=nit)
+        hist = []
+        xo, no, so = S.solve(b, "fixed_iter", maxiter=nit, history=hist)
+        assert ng == no == nit and rel(xg, xo) < 1e-10
+        assert abs(res[0] - hist[-1]) <= 1e-9 * abs(hist[-1])

@@ -285,3 +285,9 @@ def test_emul_nine_band_pipelined_matvec(EL):
         assert rel(ctx1.cr_matmulA(x), ref) < 1e-12
     finally:
         del os.environ["CMDR_PIPELINE"]
+
+
+def test_emul_vs_golden_vectors(EL):
+    from helpers import golden_checks, golden_kat
+    golden_checks(_lib=EL)
+    golden_kat(_lib=EL)

@@ -99,3 +99,10 @@ def test_sht_spin2_adjointness_full_size():
     ee, bb = plan.execute_spin2(2, mapQ=mq, mapU=mu)
     lhs, rhs = q @ mq + u @ mu, e @ ee + b @ bb
     assert abs(lhs - rhs) <= 1e-10 * max(abs(lhs), abs(rhs))
+
+
+def test_gpu_vs_golden_vectors():
+    """HIP path against the committed brute-force golden vectors directly (no oracle in between)."""
+    from helpers import golden_checks, golden_kat
+    golden_checks()
+    golden_kat()
