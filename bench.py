@@ -133,16 +133,28 @@ def main():
         import torch.distributed as dist
         torch.cuda.set_device(local_rank)
         dist.init_process_group(backend="nccl", rank=rank, world_size=world)
-    from commander_amd import synth, healpix
+    from commander_amd import synth, healpix, shard
     from commander_amd.cr import build_context
 
     cfg = args.config
     nside, lmax = synth.CONFIGS[cfg]["nside"], synth.CONFIGS[cfg]["lmax"]
-    rings = pixels = None
+    rings = pixels = bands = None
+    lay = shard.rank_layout(len(synth.CONFIGS[cfg]["nu"]), world, rank)
+    if os.environ.get("CMDR_BENCH_SHARD"):          # "BxR": force band_parts x ring_parts
+        bp, rp = (int(v) for v in os.environ["CMDR_BENCH_SHARD"].split("x"))
+        lay = shard.rank_layout(len(synth.CONFIGS[cfg]["nu"]), world, rank, bp, rp)
+    ring_groups = None
     if world > 1:
-        rings = healpix.rank_rings(nside, rank, world)
-        pixels = healpix.local_pixels(nside, rings)
-    spec = synth.make_problem(cfg, pixels=pixels)
+        # band x ring-set hybrid: this rank owns lay["bands"] on ring set lay["ring_index"]
+        if lay["ring_parts"] > 1:
+            rings = healpix.rank_rings(nside, lay["ring_index"], lay["ring_parts"])
+            pixels = healpix.local_pixels(nside, rings)
+        if lay["band_parts"] > 1:
+            bands = lay["bands"]
+            if lay["ring_parts"] > 1:   # every rank creates every group, in the same order
+                ring_groups = [dist.new_group([bg * lay["ring_parts"] + i for i in range(lay["ring_parts"])])
+                               for bg in range(lay["band_parts"])]
+    spec = synth.make_problem(cfg, pixels=pixels, bands=bands)
     ctx = build_context(spec, device=local_rank, rings_by_nside={nside: rings} if rings is not None else None)
     if dist is not None:
         import torch
@@ -158,6 +170,14 @@ def main():
                 views[key] = torch.as_tensor(CudaView(ptr, n), device="cuda:%d" % local_rank)
             with torch.cuda.stream(torch.cuda.ExternalStream(stream, device="cuda:%d" % local_rank)):
                 dist.all_reduce(views[key])
+        if world > 1 and lay["band_parts"] > 1:
+            grp = ring_groups[rank // lay["ring_parts"]] if ring_groups else None
+
+            def allreduce_rings(ptr, n):   # setup-time only (noise a_lm of a band over its ring sets)
+                t = torch.as_tensor(CudaView(ptr, n), device="cuda:%d" % local_rank)
+                dist.all_reduce(t, group=grp)
+                torch.cuda.synchronize()
+            ctx.set_band_sharding(allreduce_rings if grp is not None else None, lay["ring_parts"])
         if os.environ.get("CMDR_BENCH_BLOCKING_ALLREDUCE") == "1":   # the MPI-style blocking callback, for comparison
             def allreduce_blocking(ptr, n):
                 t = torch.as_tensor(CudaView(ptr, n), device="cuda:%d" % local_rank)
@@ -232,7 +252,8 @@ def main():
             "config": {"workload": "BASELINE.json configs[2]: 9 Planck-like bands, CMB T-only, Nside=%d lmax=%d, "
                                    "amp-sample = cr_computeRHS + %d fixed PCG iterations, diagonal preconditioner"
                                    % (nside, lmax, NITER),
-                       "parallelism": "ring-pair sharding x%d, replicated a_lm, 1 all-reduce(ncr) per matvec" % world
+                       "parallelism": "%d band groups x %d ring sets (hybrid sharding), replicated a_lm, "
+                                      "1 all-reduce(ncr) per matvec" % (lay["band_parts"], lay["ring_parts"])
                        if world > 1 else "single GPU", "ncr": ctx.ncr, "cg_iters_per_sec": args.steps * NITER / dt},
             "roofline": {"bound": "mfma", "achieved": achieved, "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s",
                          "frac": achieved / FP64_PEAK_TFLOPS, "traffic": traffic,

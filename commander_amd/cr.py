@@ -110,6 +110,17 @@ class CRContext:
         self._keep.append(cb)
         check(self.L.cmdr_ctx_set_allreduce_stream(self._h, ctypes.cast(cb, _vp), None), self.L)
 
+    def set_band_sharding(self, rings_fn, ring_replicas):
+        """Band x ring-set hybrid: rings_fn(dev_ptr, n) sums over the ranks holding the same bands (None: one rank)."""
+        cbp = None
+        if rings_fn is not None:
+            def _cb(user, ptr, n):
+                rings_fn(ptr, n)
+            cb = ALLREDUCE_CB(_cb)
+            self._keep.append(cb)
+            cbp = ctypes.cast(cb, _vp)
+        check(self.L.cmdr_ctx_set_band_sharding(self._h, cbp, None, int(ring_replicas)), self.L)
+
     def set_only_pol(self, flag):
         check(self.L.cmdr_ctx_set_only_pol(self._h, int(bool(flag))), self.L)
 

@@ -240,6 +240,12 @@ int cmdr_ctx_set_allreduce_stream(cmdr_ctx* ctx, cmdr_allreduce_stream_fn fn, vo
         ctx->sys->set_allreduce_stream(fn, user);
     });
 }
+int cmdr_ctx_set_band_sharding(cmdr_ctx* ctx, cmdr_allreduce_fn rings_fn, void* user, int ring_replicas) {
+    return guarded([&] {
+        CMDR_REQUIRE(ctx && ring_replicas >= 1, "bad arguments");
+        ctx->sys->set_band_sharding(rings_fn, user, ring_replicas);
+    });
+}
 int cmdr_ctx_set_only_pol(cmdr_ctx* ctx, int only_pol) {
     return guarded([&] {
         CMDR_REQUIRE(ctx, "ctx is NULL");

@@ -378,7 +378,7 @@ void CrSystem::mix_forward(Group& G, const double* sx) {
         for (const MixCol& m : B.T) col_in(m, 0);
         for (const MixCol& m : B.P) { col_in(m, 1); col_in(m, 2); }
         P.sandwich(G.mix_in.get(), G.mix_out.get(), B.mul_ptrs.get(), nT, nP, stream_);
-        reduce(G.mix_out.get(), (int64_t)(nT + 2 * nP) * na);
+        reduce_rings(G.mix_out.get(), (int64_t)(nT + 2 * nP) * na);
         k = 0;
         auto col_out = [&](int bm) {
             launch_alm_copy(G.mix_out.get() + (int64_t)k * na, G.lmax, G.E.get() + (int64_t)bm * na, G.lmax,
@@ -402,7 +402,7 @@ void CrSystem::mix_adjoint(Group& G, bool rhs) {
         launch_part2_to_alm(P.partials2(), P.part2_pol_stride(), P.leg2().tri4(), P.leg2().nchunk,
                             G.U.get() + (int64_t)G.nT * na, G.U.get() + (int64_t)(G.nT + 1) * na, 2 * na,
                             P.leg2().cnorm.get(), G.lmax, G.npol, stream_);
-    reduce(G.U.get(), (int64_t)G.nbm * na);
+    reduce_rings(G.U.get(), (int64_t)G.nbm * na);
     for (MixBatch& B : G.mix) {
         const int nT = (int)B.T.size(), nP = (int)B.P.size();
         int k = 0;
@@ -425,6 +425,13 @@ void CrSystem::mix_adjoint(Group& G, bool rhs) {
         for (const MixCol& m : B.T) col_out(m, 0);
         for (const MixCol& m : B.P) { col_out(m, 1); col_out(m, 2); }
     }
+}
+
+void CrSystem::reduce_rings(double* v, int64_t n) {
+    if (!band_sharded_) { reduce(v, n); return; }
+    if (!allreduce_rings_) return;           // one rank per ring group
+    sync();
+    allreduce_rings_(allreduce_rings_user_, v, n);
 }
 
 void CrSystem::reduce(double* v, int64_t n) {
@@ -624,7 +631,7 @@ void CrSystem::precond_init_diag() {
             const double* sraw = (B.siN_raw.size() ? B.siN_raw.get() : B.siN.get()) + (int64_t)j * np;
             launch_pix(0, sraw, sraw, nullptr, siN2.get(), np, stream_);   // invN_diag%map = siN**2 (comm_N_rms_mod.f90:217)
             P.map2alm(siN2.get(), np, alm.get(), na, 1, true, stream_);
-            reduce(alm.get(), na);
+            reduce_rings(alm.get(), na);
             std::vector<double> al0(lmax + 1);
             sync();
             CMDR_HIP_CHECK(hipMemcpy(al0.data(), alm.get(), sizeof(double) * (lmax + 1), hipMemcpyDeviceToHost));
@@ -694,6 +701,16 @@ void CrSystem::precond_init_diag() {
                     }
                 }
         }
+    if (band_sharded_) {   // M0 is a sum over bands: complete it over the ranks; every ring group contributes its bands
+                           // ring_replicas_ times
+        DevBuf<double> tmp(M0_.size());
+        tmp.upload(M0_, stream_);
+        reduce(tmp.get(), (int64_t)M0_.size());
+        sync();
+        CMDR_HIP_CHECK(hipMemcpy(M0_.data(), tmp.get(), sizeof(double) * M0_.size(), hipMemcpyDeviceToHost));
+        const double f = 1.0 / (double)ring_replicas_;
+        for (double& v : M0_) v *= f;
+    }
     precond_ready_ = false;
 }
 
@@ -802,6 +819,7 @@ void pseudo_inverse(const std::vector<double>& A, int m, int n, double thr, std:
 
 void CrSystem::precond_init_pseudoinv() {
     CMDR_REQUIRE(finalized_, "finalize first");
+    CMDR_REQUIRE(!band_sharded_, "the pseudo-inverse preconditioner needs every band on every rank (ring sharding only)");
     for (Group& G : groups_) {
         ShtPlan& P = *G.plan;
         const int64_t np = P.npix_local(), na = P.nalm();
@@ -816,7 +834,7 @@ void CrSystem::precond_init_pseudoinv() {
             auto alpha_of = [&](int64_t n) {          // sqrt(sum tau^2 / sum tau)  (comm_N_rms_mod.f90:225-246)
                 launch_dot(m2.get(), ones.get(), n, dot_partial_.get(), sums.get(), 0, false, stream_);
                 launch_dot(m2.get(), m2.get(), n, dot_partial_.get(), sums.get(), 1, false, stream_);
-                reduce(sums.get(), 2);
+                reduce_rings(sums.get(), 2);
                 double h[2];
                 sync();
                 CMDR_HIP_CHECK(hipMemcpy(h, sums.get(), sizeof(h), hipMemcpyDeviceToHost));
@@ -825,13 +843,13 @@ void CrSystem::precond_init_pseudoinv() {
             // tau = Y Yt siN^2  (:221-223)
             launch_pix(0, sraw, sraw, nullptr, m2.get(), np, stream_);
             P.map2alm(m2.get(), np, alm.get(), na, 1, false, stream_);
-            reduce(alm.get(), na);
+            reduce_rings(alm.get(), na);
             P.alm2map(alm.get(), na, m2.get(), np, 1, false, stream_);
             B.alpha_nu[0] = alpha_of(np);
             if (B.nmaps == 3) {
                 launch_pix(0, sraw + np, sraw + np, nullptr, m2.get(), 2 * np, stream_);
                 P.map2alm_spin2(m2.get(), m2.get() + np, alm.get(), alm.get() + na, false, stream_);
-                reduce(alm.get(), 2 * na);
+                reduce_rings(alm.get(), 2 * na);
                 P.alm2map_spin2(alm.get(), alm.get() + na, m2.get(), m2.get() + np, false, stream_);
                 B.alpha_nu[1] = B.alpha_nu[2] = alpha_of(2 * np);
             }

@@ -50,6 +50,14 @@ class CrSystem {
     void set_cl_diag(int comp, const double* cl);   // getCl(l, p): (lmax_cl+1) x nmaps, for the pseudo-inverse U
     void set_allreduce(AllreduceFn fn, void* user) { allreduce_ = fn; allreduce_user_ = user; }
     void set_allreduce_stream(AllreduceStreamFn fn, void* user) { allreduce_s_ = fn; allreduce_s_user_ = user; }
+    // Band x ring-set hybrid sharding: this rank holds a SUBSET of the bands (all components), on a subset of the
+    // rings.  `rings_fn` sums over the ranks that share this rank's bands (its ring group): per-band quantities
+    // (noise a_lm, mixing intermediates); the main callback sums over all ranks (the stacked vector, which is a sum
+    // over bands and rings).  ring_replicas = ranks per ring group (the band-summed preconditioner matrix is then
+    // counted that many times by the world sum).
+    void set_band_sharding(AllreduceFn rings_fn, void* user, int ring_replicas) {
+        allreduce_rings_ = rings_fn; allreduce_rings_user_ = user; ring_replicas_ = ring_replicas; band_sharded_ = true;
+    }
     void set_only_pol(bool v) { only_pol_ = v; }
 
     int64_t ncr() const { return ncr_; }
@@ -151,7 +159,8 @@ class CrSystem {
     std::vector<int> open_;
     double prof_ms_[4] = {0, 0, 0, 0};
     long long prof_n_[4] = {0, 0, 0, 0};
-    void reduce(double* v, int64_t n);
+    void reduce(double* v, int64_t n);         // over all ranks
+    void reduce_rings(double* v, int64_t n);   // over the ranks holding the same bands (== reduce without band sharding)
 
     hipStream_t stream_ = nullptr;
     std::vector<Band> bands_;
@@ -177,6 +186,10 @@ class CrSystem {
     void* allreduce_user_ = nullptr;
     AllreduceStreamFn allreduce_s_ = nullptr;
     void* allreduce_s_user_ = nullptr;
+    AllreduceFn allreduce_rings_ = nullptr;
+    void* allreduce_rings_user_ = nullptr;
+    int ring_replicas_ = 1;
+    bool band_sharded_ = false;
 };
 
 }  // namespace cmdr

@@ -51,6 +51,7 @@ def _sig(L):
     L.cmdr_ctx_set_rings.argtypes = [c_vp, c_int, c_int, ip]
     L.cmdr_ctx_set_allreduce.argtypes = [c_vp, c_vp, c_vp]
     L.cmdr_ctx_set_allreduce_stream.argtypes = [c_vp, c_vp, c_vp]
+    L.cmdr_ctx_set_band_sharding.argtypes = [c_vp, c_vp, c_vp, c_int]
     L.cmdr_ctx_set_only_pol.argtypes = [c_vp, c_int]
     L.cmdr_band_add.argtypes = [c_vp, c_int, c_int, c_int, dp, dp, c_dbl, dp, dp]
     L.cmdr_comp_add.argtypes = [c_vp, c_int, c_int, c_int, dp, dp, dp, dp, c_int]

@@ -80,10 +80,12 @@ def comp_Dl(name, lmax):
     return D
 
 
-def make_problem(cfg, nside=None, lmax=None, comp_lmax=None, pixels=None, pol=None):
+def make_problem(cfg, nside=None, lmax=None, comp_lmax=None, pixels=None, pol=None, bands=None):
     """Problem spec dict consumed by ``commander_amd.cr.build_context`` (and by the tests' oracle builder).
 
-    pixels: optional full-sky RING indices of a rank's local map (ring sharding); maps are then local."""
+    pixels: optional full-sky RING indices of a rank's local map (ring sharding); maps are then local.
+    bands:  optional subset of band indices this rank holds (band sharding); F_mean / F_map rows follow."""
+    band_subset = bands
     c = dict(CONFIGS[cfg]) if isinstance(cfg, str) else dict(cfg)
     nside = int(nside or c["nside"])
     lmax = int(lmax or c["lmax"])
@@ -129,7 +131,15 @@ def make_problem(cfg, nside=None, lmax=None, comp_lmax=None, pixels=None, pol=No
             # F_mean = full-sky pixel average of the map (comm_diffuse_comp_mod.f90:1991-1999)
             comp["F_mean"] = np.repeat(np.array([mixing(name, b["nu"], z).mean() for b in bands])[:, None], nm, axis=1)
         comps.append(comp)
-    return dict(bands=bands, comps=comps, nside=nside, lmax=lmax, pixels=pixels)
+    band_ids = list(range(len(bands)))
+    if band_subset is not None:
+        band_ids = [int(b) for b in band_subset]
+        bands = [bands[b] for b in band_ids]
+        for comp in comps:
+            comp["F_mean"] = comp["F_mean"][band_ids, :]
+            if "F_map" in comp:
+                comp["F_map"] = {i: comp["F_map"][b] for i, b in enumerate(band_ids)}
+    return dict(bands=bands, comps=comps, nside=nside, lmax=lmax, pixels=pixels, band_ids=band_ids)
 
 
 def ncr_of(spec):
@@ -143,7 +153,8 @@ def draw_inputs(spec):
     npix = 12 * nside * nside
     pix = spec["pixels"]
     resid, xi = [], []
-    for i, b in enumerate(spec["bands"]):
+    ids = spec.get("band_ids") or list(range(len(spec["bands"])))
+    for b, i in zip(spec["bands"], ids):          # sub-streams follow the GLOBAL band index (band sharding)
         g = rng(1, i).standard_normal(npix)
         z = healpix.pix_z(nside)
         rms = b["sigma0"] * (1.0 + 0.5 * z)

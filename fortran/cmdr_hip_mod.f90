@@ -87,6 +87,16 @@ module cmdr_hip_mod
        integer(c_int)        :: ierr
      end function cmdr_ctx_set_allreduce_stream
 
+     ! band x ring-set hybrid sharding: rings_fn sums over the ranks holding the same bands
+     function cmdr_ctx_set_band_sharding(ctx, rings_fn, user, ring_replicas) &
+          & bind(c, name='cmdr_ctx_set_band_sharding') result(ierr)
+       import :: c_int, c_ptr, c_funptr
+       type(c_ptr),    value :: ctx, user
+       type(c_funptr), value :: rings_fn
+       integer(c_int), value :: ring_replicas
+       integer(c_int)        :: ierr
+     end function cmdr_ctx_set_band_sharding
+
      function cmdr_band_add(ctx, nside, lmax, nmaps, siN, b_l, mb_eff, sg_mask, wring) &
           & bind(c, name='cmdr_band_add') result(idx)
        import :: c_int, c_ptr, c_double

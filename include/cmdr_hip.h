@@ -97,6 +97,11 @@ int cmdr_ctx_set_allreduce(cmdr_ctx* ctx, cmdr_allreduce_fn fn, void* user);
  * matvec then, so a whole fixed_iter solve is queued ahead of the GPU.  Takes precedence over the blocking callback. */
 typedef void (*cmdr_allreduce_stream_fn)(void* user, double* dev_ptr, int64_t n, void* hip_stream);
 int cmdr_ctx_set_allreduce_stream(cmdr_ctx* ctx, cmdr_allreduce_stream_fn fn, void* user);
+/* Band x ring-set hybrid sharding (both partitions at once): this rank holds a subset of the bands
+ * (cmdr_band_add only those; F_mean rows likewise) on a subset of the rings.  rings_fn sums over the ranks that hold
+ * the SAME bands (may be NULL when that group is one rank); the callback of cmdr_ctx_set_allreduce[_stream] sums over
+ * all ranks.  ring_replicas = number of ranks per band subset.  Diagonal preconditioner only. */
+int cmdr_ctx_set_band_sharding(cmdr_ctx* ctx, cmdr_allreduce_fn rings_fn, void* user, int ring_replicas);
 int cmdr_ctx_set_only_pol(cmdr_ctx* ctx, int only_pol);
 
 /* data(i): comm_data_mod.f90:33-63.  siN = 1/rms (0 in masked pixels, comm_N_rms_mod.f90:179-193),

@@ -89,3 +89,74 @@ def test_two_rank_ring_sharding_matches_single_rank(tmp_path, mode):
         assert rel(g["b"], b) < 1e-12
         assert rel(g["d0"], ctx.alpha_nu(0) if mode == "varying" else ctx.invN_diag(0)) < 1e-12
         assert rel(g["sol"], sol) < 1e-10
+
+
+def _hybrid_worker(rank, world, port, out_dir):
+    """4 ranks = 2 band groups x 2 ring sets (band x ring-set hybrid)."""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import ctypes
+    import torch
+    import torch.distributed as dist
+    from helpers import emul_lib
+    from commander_amd import synth, healpix, shard
+    from commander_amd.cr import build_context
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    EL = emul_lib()
+    nside, lmax, nband = 16, 32, 3
+    lay = shard.rank_layout(nband, world, rank, band_parts=2, ring_parts=2)
+    groups = [dist.new_group([bg * 2, bg * 2 + 1]) for bg in range(2)]      # every rank creates every group
+    rings = healpix.rank_rings(nside, lay["ring_index"], lay["ring_parts"])
+    pix = healpix.local_pixels(nside, rings)
+    spec = synth.make_problem("cfg2", nside=nside, lmax=lmax, pixels=pix, bands=lay["bands"])
+    ctx = build_context(spec, rings_by_nside={nside: rings}, _lib=EL)
+
+    def view(ptr, n):
+        return torch.from_numpy(np.ctypeslib.as_array(ctypes.cast(ptr, ctypes.POINTER(ctypes.c_double)), shape=(n,)))
+    ctx.set_allreduce(lambda ptr, n: dist.all_reduce(view(ptr, n)))
+    ctx.set_band_sharding(lambda ptr, n: dist.all_reduce(view(ptr, n), group=groups[rank // 2]), lay["ring_parts"])
+    ctx.initPrecond()
+    ctx.update_precond()
+    x = np.random.default_rng(5).standard_normal(ctx.ncr)
+    y = ctx.cr_matmulA(x)
+    pm = ctx.cr_invM(x)
+    resid, xi, eta = synth.draw_inputs(spec)
+    b = ctx.cr_computeRHS("sample", resid, xi, eta)
+    sol, n, stat, res = ctx.solve_cr_eqn_by_CG(b, "fixed_iter", 1e-8, 5, 12, 1)
+    np.savez(os.path.join(out_dir, "rank%d.npz" % rank), y=y, b=b, sol=sol, pm=pm, bands=np.array(lay["bands"]))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_four_rank_band_ring_hybrid_matches_single_rank(tmp_path):
+    import torch.multiprocessing as mp
+    from helpers import emul_lib, rel
+    from commander_amd import synth, shard
+    from commander_amd.cr import build_context
+    assert shard.plan_shards(9, 8) == (4, 2) and shard.plan_shards(9, 4) == (1, 4) and shard.plan_shards(9, 1) == (1, 1)
+    emul_lib()
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    mp.spawn(_hybrid_worker, args=(4, port, str(tmp_path)), nprocs=4, join=True)
+    EL = emul_lib()
+    spec = synth.make_problem("cfg2", nside=16, lmax=32)
+    ctx = build_context(spec, _lib=EL)
+    ctx.initPrecond()
+    ctx.update_precond()
+    x = np.random.default_rng(5).standard_normal(ctx.ncr)
+    y, pm = ctx.cr_matmulA(x), ctx.cr_invM(x)
+    resid, xi, eta = synth.draw_inputs(spec)
+    b = ctx.cr_computeRHS("sample", resid, xi, eta)
+    sol, n, stat, res = ctx.solve_cr_eqn_by_CG(b, "fixed_iter", 1e-8, 5, 12, 1)
+    seen = []
+    for r in range(4):
+        g = np.load(os.path.join(str(tmp_path), "rank%d.npz" % r))
+        seen += list(g["bands"])
+        assert rel(g["y"], y) < 1e-12
+        assert rel(g["pm"], pm) < 1e-12
+        assert rel(g["b"], b) < 1e-12
+        assert rel(g["sol"], sol) < 1e-10
+    assert sorted(set(seen)) == [0, 1, 2]

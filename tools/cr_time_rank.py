@@ -6,13 +6,21 @@ import numpy as np
 from commander_amd import synth, healpix
 from commander_amd.cr import build_context
 
+from commander_amd import shard
 cfg = sys.argv[1] if len(sys.argv) > 1 else "cfg3"
 world = int(sys.argv[2]) if len(sys.argv) > 2 else 8
 nside = synth.CONFIGS[cfg]["nside"]
-rings = healpix.rank_rings(nside, 0, world)
-pix = healpix.local_pixels(nside, rings)
-spec = synth.make_problem(cfg, pixels=pix)
-ctx = build_context(spec, rings_by_nside={nside: rings})
+nband = len(synth.CONFIGS[cfg]["nu"])
+if len(sys.argv) > 3:                       # "BxR": band groups x ring sets; time the most loaded rank
+    bp, rp = (int(v) for v in sys.argv[3].split("x"))
+else:
+    bp, rp = shard.plan_shards(nband, world)
+lay = max((shard.rank_layout(nband, world, r, bp, rp) for r in range(world)), key=lambda l: len(l["bands"]))
+rings = healpix.rank_rings(nside, lay["ring_index"], rp) if rp > 1 else None
+pix = healpix.local_pixels(nside, rings) if rings is not None else None
+spec = synth.make_problem(cfg, pixels=pix, bands=lay["bands"] if bp > 1 else None)
+ctx = build_context(spec, rings_by_nside={nside: rings} if rings is not None else None)
+print("layout: %d band groups x %d ring sets; this rank: %d bands" % (bp, rp, len(lay["bands"])), flush=True)
 ctx.initPrecond(); ctx.update_precond()
 x, y, b = ctx.dev(ctx.ncr, np.random.default_rng(0).standard_normal(ctx.ncr)), ctx.dev(ctx.ncr), ctx.dev(ctx.ncr)
 ctx.L.cmdr_profile_enable(ctx._h, 1)
