@@ -128,11 +128,15 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     dist = None
     force_dist = os.environ.get("CMDR_BENCH_FORCE_DIST") == "1"   # exercise the RCCL path on a 1-GPU box
+    # rehearsal of the N > 1 logic on a 1-GPU box: every rank on device 0, collectives through gloo on host copies
+    one_gpu = os.environ.get("CMDR_BENCH_ONE_GPU") == "1"
+    if one_gpu:
+        local_rank = 0
     if world > 1 or force_dist:
         import torch
         import torch.distributed as dist
         torch.cuda.set_device(local_rank)
-        dist.init_process_group(backend="nccl", rank=rank, world_size=world)
+        dist.init_process_group(backend="gloo" if one_gpu else "nccl", rank=rank, world_size=world)
     from commander_amd import synth, healpix, shard
     from commander_amd.cr import build_context
 
@@ -175,13 +179,23 @@ def main():
 
             def allreduce_rings(ptr, n):   # setup-time only (noise a_lm of a band over its ring sets)
                 t = torch.as_tensor(CudaView(ptr, n), device="cuda:%d" % local_rank)
-                dist.all_reduce(t, group=grp)
+                if one_gpu:
+                    h = t.cpu()
+                    dist.all_reduce(h, group=grp)
+                    t.copy_(h)
+                else:
+                    dist.all_reduce(t, group=grp)
                 torch.cuda.synchronize()
             ctx.set_band_sharding(allreduce_rings if grp is not None else None, lay["ring_parts"])
-        if os.environ.get("CMDR_BENCH_BLOCKING_ALLREDUCE") == "1":   # the MPI-style blocking callback, for comparison
+        if os.environ.get("CMDR_BENCH_BLOCKING_ALLREDUCE") == "1" or one_gpu:   # the MPI-style blocking callback
             def allreduce_blocking(ptr, n):
                 t = torch.as_tensor(CudaView(ptr, n), device="cuda:%d" % local_rank)
-                dist.all_reduce(t)
+                if one_gpu:
+                    h = t.cpu()
+                    dist.all_reduce(h)
+                    t.copy_(h)
+                else:
+                    dist.all_reduce(t)
                 torch.cuda.synchronize()
             ctx.set_allreduce(allreduce_blocking)
         else:
@@ -217,7 +231,7 @@ def main():
     dt = time.perf_counter() - t0
     if dist is not None:
         import torch
-        tt = torch.tensor([dt], dtype=torch.float64, device="cuda:%d" % local_rank)
+        tt = torch.tensor([dt], dtype=torch.float64, device="cpu" if one_gpu else "cuda:%d" % local_rank)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
     ms = (ctypes.c_double * 4)()
@@ -252,8 +266,9 @@ def main():
             "config": {"workload": "BASELINE.json configs[2]: 9 Planck-like bands, CMB T-only, Nside=%d lmax=%d, "
                                    "amp-sample = cr_computeRHS + %d fixed PCG iterations, diagonal preconditioner"
                                    % (nside, lmax, NITER),
-                       "parallelism": "%d band groups x %d ring sets (hybrid sharding), replicated a_lm, "
-                                      "1 all-reduce(ncr) per matvec" % (lay["band_parts"], lay["ring_parts"])
+                       "parallelism": ("%d band groups x %d ring sets (hybrid sharding)" % (lay["band_parts"], lay["ring_parts"])
+                                       if lay["band_parts"] > 1 else "ring-pair sharding x%d" % world)
+                                      + ", replicated a_lm, 1 all-reduce(ncr) per matvec"
                        if world > 1 else "single GPU", "ncr": ctx.ncr, "cg_iters_per_sec": args.steps * NITER / dt},
             "roofline": {"bound": "mfma", "achieved": achieved, "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s",
                          "frac": achieved / FP64_PEAK_TFLOPS, "traffic": traffic,
