@@ -278,9 +278,10 @@ __global__ void __launch_bounds__(256) k_leg_adj(LegArgs A, const WaveTask* __re
 
 // maps sharing one recursion per wave (register budget).  Tuning knobs: CMDR_LEG_NB caps both kernels,
 // CMDR_LEG_NB_S / CMDR_LEG_NB_A set the synthesis / adjoint value (up to the compiled maximum).
-static int leg_batch(int R, bool adjoint) {
-    const int cap = R == 1 ? 9 : (R == 2 ? 4 : (adjoint ? 3 : 4));
-    int nb = R == 1 ? 9 : (R == 2 ? 4 : 3);   // R = 4: 3 measured best for both kernels (9 maps: 3+3+3)
+static int leg_batch(int R, bool adjoint, bool wg = false) {
+    // R = 4: 3 measured best for both kernels (9 maps: 3+3+3); synthesis in the workgroup form at R = 2: 5 (9 = 5+4)
+    const int cap = R == 1 ? 9 : (R == 2 ? (wg && !adjoint ? 5 : 4) : (adjoint ? 3 : 4));
+    int nb = R == 1 ? 9 : (R == 2 ? (wg && !adjoint ? 5 : 4) : 3);
     if (const char* e = std::getenv(adjoint ? "CMDR_LEG_NB_A" : "CMDR_LEG_NB_S")) {
         const int v = std::atoi(e);
         if (v >= 1 && v <= cap) nb = v;
@@ -296,8 +297,8 @@ int leg_max_batch(int R) { return leg_batch(R, false); }
 template <int R, int NB>
 static void synth_RN(const LegArgs& A, const WaveTask* tasks, int ntasks, const double* ast, int nbs, int k0, int rep,
                      double* ph, int64_t ph_stride, hipStream_t s) {
-    if (A.wg && NB <= 4)
-        hipLaunchKernelGGL((k_leg_synth_wg<R, (NB <= 4 ? NB : 4)>), dim3((ntasks / 4) * rep), dim3(256), 0,
+    if (A.wg && NB <= 5)
+        hipLaunchKernelGGL((k_leg_synth_wg<R, (NB <= 5 ? NB : 5)>), dim3((ntasks / 4) * rep), dim3(256), 0,
                            s, A, tasks, ntasks, ast, nbs, k0, rep, ph, ph_stride);
     else
         hipLaunchKernelGGL((k_leg_synth<R, NB>), dim3((ntasks / 4) * rep), dim3(256), 0, s, A, tasks, ntasks, ast, nbs,
@@ -322,13 +323,13 @@ void launch_leg_synth(const LegArgs& A, const WaveTask* tasks, int ntasks, const
                       int64_t ph_stride, int nmaps, hipStream_t s, int nbs) {
     if (ntasks == 0 || nmaps == 0) return;
     if (nbs < 0) nbs = nmaps;
-    for_batches(nmaps, A.wg ? std::min(leg_batch(A.R, false), 4) : leg_batch(A.R, false), [&](int nb, int k0, int rep) {
+    for_batches(nmaps, A.wg ? std::min(leg_batch(A.R, false, true), 5) : leg_batch(A.R, false), [&](int nb, int k0, int rep) {
 #define CMDR_S(RR, NN) case NN: synth_RN<RR, NN>(A, tasks, ntasks, ast, nbs, k0, rep, ph, ph_stride, s); break;
         if (A.R == 1) {
             switch (nb) { CMDR_S(1, 1) CMDR_S(1, 2) CMDR_S(1, 3) CMDR_S(1, 4) CMDR_S(1, 5) CMDR_S(1, 6) CMDR_S(1, 7)
                           CMDR_S(1, 8) CMDR_S(1, 9) }
         } else if (A.R == 2) {
-            switch (nb) { CMDR_S(2, 1) CMDR_S(2, 2) CMDR_S(2, 3) CMDR_S(2, 4) }
+            switch (nb) { CMDR_S(2, 1) CMDR_S(2, 2) CMDR_S(2, 3) CMDR_S(2, 4) CMDR_S(2, 5) }
         } else {
             switch (nb) { CMDR_S(4, 1) CMDR_S(4, 2) CMDR_S(4, 3) CMDR_S(4, 4) }
         }
