@@ -307,3 +307,20 @@ def getSigmaL(alm, lmax, _lib=None):
     out = np.zeros((lmax + 1, nmaps * (nmaps + 1) // 2), order="F")
     check(L.cmdr_sigma_l(_p(a), int(lmax), nmaps, _p(out)), L)
     return out
+
+
+def alm_to_chain_order(alm, lmax, _lib=None):
+    """Packed a_lm (nalm[, nmaps]) -> the chain file's ``alm`` dataset: float32, index l^2 + l + m (comm_map_mod.f90:712-740)."""
+    L = _lib if _lib is not None else _libmod.lib()
+    a = _f(np.asarray(alm, dtype=np.float64).reshape((lmax + 1) ** 2, -1))
+    out = np.zeros(a.shape, dtype=np.float32, order="F")
+    check(L.cmdr_alm_to_chain_order(_p(a), int(lmax), a.shape[1], out.ctypes.data_as(ctypes.POINTER(ctypes.c_float))), L)
+    return out
+
+
+def alm_from_chain_order(chain32, lmax, _lib=None):
+    L = _lib if _lib is not None else _libmod.lib()
+    c = np.asfortranarray(np.asarray(chain32, dtype=np.float32).reshape((lmax + 1) ** 2, -1))
+    out = np.zeros(c.shape, order="F")
+    check(L.cmdr_alm_from_chain_order(c.ctypes.data_as(ctypes.POINTER(ctypes.c_float)), int(lmax), c.shape[1], _p(out)), L)
+    return out

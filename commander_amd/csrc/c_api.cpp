@@ -490,4 +490,31 @@ int cmdr_sigma_l_dev(const double* alm_dev, int64_t stride, int lmax, int nmaps,
     });
 }
 
+int cmdr_alm_to_chain_order(const double* alm, int lmax, int nmaps, float* chain32) {
+    return guarded([&] {
+        CMDR_REQUIRE(alm && chain32 && lmax >= 0 && nmaps >= 1, "bad arguments");
+        CMDR_REQUIRE(cmdr_device_count() > 0, "no HIP device available: libcmdr_hip has no CPU path");
+        const int64_t na = cmdr::nalm_packed(lmax);
+        cmdr::DevBuf<double> d((size_t)na * nmaps);
+        cmdr::DevBuf<float> o((size_t)na * nmaps);
+        CMDR_HIP_CHECK(hipMemcpy(d.get(), alm, sizeof(double) * na * nmaps, hipMemcpyHostToDevice));
+        cmdr::launch_alm_chain(d.get(), na, o.get(), lmax, nmaps, true, nullptr);
+        CMDR_HIP_CHECK(hipGetLastError());
+        CMDR_HIP_CHECK(hipMemcpy(chain32, o.get(), sizeof(float) * na * nmaps, hipMemcpyDeviceToHost));
+    });
+}
+int cmdr_alm_from_chain_order(const float* chain32, int lmax, int nmaps, double* alm) {
+    return guarded([&] {
+        CMDR_REQUIRE(alm && chain32 && lmax >= 0 && nmaps >= 1, "bad arguments");
+        CMDR_REQUIRE(cmdr_device_count() > 0, "no HIP device available: libcmdr_hip has no CPU path");
+        const int64_t na = cmdr::nalm_packed(lmax);
+        cmdr::DevBuf<double> d((size_t)na * nmaps);
+        cmdr::DevBuf<float> o((size_t)na * nmaps);
+        CMDR_HIP_CHECK(hipMemcpy(o.get(), chain32, sizeof(float) * na * nmaps, hipMemcpyHostToDevice));
+        cmdr::launch_alm_chain(d.get(), na, o.get(), lmax, nmaps, false, nullptr);
+        CMDR_HIP_CHECK(hipGetLastError());
+        CMDR_HIP_CHECK(hipMemcpy(alm, d.get(), sizeof(double) * na * nmaps, hipMemcpyDeviceToHost));
+    });
+}
+
 }  // extern "C"

@@ -233,6 +233,20 @@ CMDR_HD void pinv_prior_elem(const CompDev* __restrict__ comps, int ncomp, const
         }
 }
 
+// Chain-file order of a_lm (comm_map_mod.f90:712-719: ind = l^2 + l + m, m = -l..l, single precision) <-> packed.
+//   to_chain != 0: out32[l^2+l+m] = (float) alm[packed(l, m)]   ;   else: alm[packed(l, m)] = in32[l^2+l+m]
+CMDR_HD void alm_chain_elem(double* __restrict__ alm, float* __restrict__ c32, int lmax, int to_chain, int m, int l) {
+    const int64_t i = d_packed_index(lmax, l, m);
+    const int64_t ip = (int64_t)l * l + l + m, im = (int64_t)l * l + l - m;
+    if (to_chain) {
+        c32[ip] = (float)alm[i];
+        if (m > 0) c32[im] = (float)alm[i + 1];
+    } else {
+        alm[i] = (double)c32[ip];
+        if (m > 0) alm[i + 1] = (double)c32[im];
+    }
+}
+
 // Diagonal preconditioner (applyDiffPrecond_diagonal, comm_diffuse_comp_mod.f90:2186-2235): per (l, m, stokes)
 // a dense npre x npre block (same for +m and -m).  P layout: [stokes][k1][k2][ntri(lmax_pre)] (unpadded triangle).
 CMDR_HD int64_t d_moff(int lmax, int m) { return (int64_t)m * (lmax + 1) - (int64_t)m * (m - 1) / 2; }

@@ -268,6 +268,18 @@ void launch_axpby(const double* a, const double* b, double cb, double* out, int6
 }
 
 // ----------------------------------------------------------------------------- sigma_l (K13)
+__global__ void k_alm_chain(double* __restrict__ alm, int64_t alm_stride, float* __restrict__ c32, int lmax,
+                            int to_chain) {
+    const int m = blockIdx.y, l = m + blockIdx.x * 256 + threadIdx.x;
+    if (l > lmax) return;
+    const int64_t na = (int64_t)(lmax + 1) * (lmax + 1);
+    alm_chain_elem(alm + blockIdx.z * alm_stride, c32 + blockIdx.z * na, lmax, to_chain, m, l);
+}
+void launch_alm_chain(double* alm, int64_t alm_stride, float* c32, int lmax, int nmaps, bool to_chain, hipStream_t s) {
+    dim3 grid((lmax + 1 + 255) / 256, lmax + 1, nmaps);
+    hipLaunchKernelGGL(k_alm_chain, grid, dim3(256), 0, s, alm, alm_stride, c32, lmax, to_chain ? 1 : 0);
+}
+
 // getSigmaL (commander3/src/comm_map_mod.f90:1302-1351): sigma_l(l, k) = sum_{m=-l..l} a_lm^i a_lm^j / (2l+1) for
 // the nspec = nmaps(nmaps+1)/2 pairs (i<=j) in Commander's order.  One workgroup per l; fixed-order block reduction.
 __global__ void __launch_bounds__(256) k_sigma_l(const double* __restrict__ alm, int64_t stride, int lmax, int nmaps,

@@ -72,6 +72,7 @@ void launch_cg_xr(double* x, double* r, const double* d, const double* q, int64_
                   int den, hipStream_t s);
 void launch_cg_d(double* d, const double* sv, int64_t n, const double* scal, int num, int den, hipStream_t s);
 void launch_axpby(const double* a, const double* b, double cb, double* out, int64_t n, hipStream_t s);
+void launch_alm_chain(double* alm, int64_t alm_stride, float* c32, int lmax, int nmaps, bool to_chain, hipStream_t s);
 void launch_sigma_l(const double* alm, int64_t stride, int lmax, int nmaps, double* out, hipStream_t s);
 
 }  // namespace cmdr

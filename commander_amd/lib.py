@@ -79,6 +79,8 @@ def _sig(L):
     L.cmdr_sigma_l_dev.argtypes = [c_vp, c_i64, c_int, c_int, c_vp]
     L.cmdr_profile_enable.argtypes = [c_vp, c_int]
     L.cmdr_profile_read.argtypes = [c_vp, dp, ctypes.POINTER(ctypes.c_longlong)]
+    L.cmdr_alm_to_chain_order.argtypes = [dp, c_int, c_int, ctypes.POINTER(ctypes.c_float)]
+    L.cmdr_alm_from_chain_order.argtypes = [ctypes.POINTER(ctypes.c_float), c_int, c_int, dp]
     L.cmdr_problem_info.argtypes = [c_vp, ctypes.POINTER(c_i64)]
     L.cmdr_solve.argtypes = [c_vp, dp, dp, c_int, c_dbl, c_int, c_int, c_int, dp, pint, dp, pint]
     L.cmdr_solve_dev.argtypes = [c_vp, c_vp, c_vp, c_int, c_dbl, c_int, c_int, c_int, c_vp, pint, dp, pint]

@@ -209,6 +209,23 @@ module cmdr_hip_mod
        real(c_double), intent(out) :: res(2)
        integer(c_int)              :: ierr
      end function cmdr_solve
+     ! chain-file order of a_lm (float32, index l^2+l+m; comm_map_mod.f90:712-740) <-> packed columns
+     function cmdr_alm_to_chain_order(alm, lmax, nmaps, chain32) bind(c, name='cmdr_alm_to_chain_order') result(ierr)
+       import :: c_int, c_double, c_float
+       real(c_double), intent(in)  :: alm(*)
+       integer(c_int), value       :: lmax, nmaps
+       real(c_float),  intent(out) :: chain32(*)
+       integer(c_int)              :: ierr
+     end function cmdr_alm_to_chain_order
+
+     function cmdr_alm_from_chain_order(chain32, lmax, nmaps, alm) bind(c, name='cmdr_alm_from_chain_order') result(ierr)
+       import :: c_int, c_double, c_float
+       real(c_float),  intent(in)  :: chain32(*)
+       integer(c_int), value       :: lmax, nmaps
+       real(c_double), intent(out) :: alm(*)
+       integer(c_int)              :: ierr
+     end function cmdr_alm_from_chain_order
+
   end interface
 
 contains

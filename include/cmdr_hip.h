@@ -179,6 +179,13 @@ int cmdr_profile_read(cmdr_ctx* ctx, double* ms_sum, long long* count);
  * recursion steps one Legendre launch of the first plan performs for ONE map (algorithmic work, mlim-pruned) */
 int cmdr_problem_info(cmdr_ctx* ctx, int64_t* out);
 
+/* Chain-file order of component amplitudes (the "alm" dataset written by comm_map%writeFITS into the HDF chain file,
+ * comm_map_mod.f90:712-740: single precision, index l^2 + l + m with m = -l..l, nmaps columns) <-> Commander's packed
+ * a_lm columns; lets chains produced through this library be diffed against reference chains and be restarted from
+ * them.  Host pointers; alm: (lmax+1)^2 x nmaps doubles, chain32: (lmax+1)^2 x nmaps floats. */
+int cmdr_alm_to_chain_order(const double* alm, int lmax, int nmaps, float* chain32);
+int cmdr_alm_from_chain_order(const float* chain32, int lmax, int nmaps, double* alm);
+
 #ifdef __cplusplus
 }
 #endif

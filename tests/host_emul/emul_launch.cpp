@@ -325,6 +325,12 @@ void launch_axpby(const double* a, const double* b, double cb, double* out, int6
     for (int64_t i = 0; i < n; ++i) out[i] = a[i] + cb * b[i];
 }
 
+void launch_alm_chain(double* alm, int64_t alm_stride, float* c32, int lmax, int nmaps, bool to_chain, hipStream_t) {
+    const int64_t na = (int64_t)(lmax + 1) * (lmax + 1);
+    for (int k = 0; k < nmaps; ++k)
+        for (int m = 0; m <= lmax; ++m)
+            for (int l = m; l <= lmax; ++l) alm_chain_elem(alm + k * alm_stride, c32 + k * na, lmax, to_chain ? 1 : 0, m, l);
+}
 void launch_sigma_l(const double* alm, int64_t stride, int lmax, int nmaps, double* out, hipStream_t) {
     const int nspec = nmaps * (nmaps + 1) / 2;
     for (int l = 0; l <= lmax; ++l) {

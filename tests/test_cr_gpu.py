@@ -195,3 +195,17 @@ def test_varying_mixing_polarised_gpu():
 def test_edge_cases_gpu():
     from helpers import edge_case_checks
     edge_case_checks()
+
+
+def test_chain_order_gpu():
+    from commander_amd.cr import alm_to_chain_order, alm_from_chain_order
+    from oracle import healpix
+    rng = np.random.default_rng(12)
+    for lmax, nmaps in [(0, 1), (33, 1), (300, 3)]:
+        info = healpix.AlmInfo(lmax)
+        a = rng.standard_normal((info.nalm, nmaps))
+        c = alm_to_chain_order(a, lmax)
+        ref = np.zeros_like(a, dtype=np.float32)
+        ref[info.l ** 2 + info.l + info.m] = a.astype(np.float32)
+        assert np.array_equal(c, ref)
+        assert np.array_equal(alm_from_chain_order(c, lmax), a.astype(np.float32).astype(np.float64))

@@ -291,3 +291,19 @@ def test_emul_vs_golden_vectors(EL):
     from helpers import golden_checks, golden_kat
     golden_checks(_lib=EL)
     golden_kat(_lib=EL)
+
+
+def test_emul_chain_order(EL):
+    """a_lm in the chain file's order (float32, l^2 + l + m) and back, against the oracle's (l, m) tables."""
+    from commander_amd.cr import alm_to_chain_order, alm_from_chain_order
+    from oracle import healpix
+    rng = np.random.default_rng(12)
+    for lmax, nmaps in [(0, 1), (7, 1), (12, 3)]:
+        info = healpix.AlmInfo(lmax)
+        a = rng.standard_normal((info.nalm, nmaps))
+        c = alm_to_chain_order(a, lmax, _lib=EL)
+        ref = np.zeros_like(a, dtype=np.float32)
+        ref[info.l ** 2 + info.l + info.m] = a.astype(np.float32)
+        assert np.array_equal(c, ref)
+        back = alm_from_chain_order(c, lmax, _lib=EL)
+        assert np.array_equal(back, a.astype(np.float32).astype(np.float64))
