@@ -209,3 +209,31 @@ def test_chain_order_gpu():
         ref[info.l ** 2 + info.l + info.m] = a.astype(np.float32)
         assert np.array_equal(c, ref)
         assert np.array_equal(alm_from_chain_order(c, lmax), a.astype(np.float32).astype(np.float64))
+
+
+def test_cfg5_full_size_properties():
+    """BASELINE.json configs[4] shape at full size (9 bands, Nside 1024, lmax 2000, five components, synchrotron and
+    dust with spatially varying mixing, pseudo-inverse preconditioner): size-independent properties.  With unit ring
+    weights YtW = (4pi/Npix) Yt, so even the varying-mixing operator is symmetric; A = 1 + positive semi-definite;
+    a short pseudo-inverse-preconditioned PCG reduces the preconditioned residual monotonically."""
+    from commander_amd import synth
+    from commander_amd.cr import build_context
+    spec = synth.make_problem("cfg5")
+    ctx = build_context(spec)
+    rng = np.random.default_rng(17)
+    x, y = rng.standard_normal(ctx.ncr), rng.standard_normal(ctx.ncr)
+    Ax, Ay = ctx.cr_matmulA(x), ctx.cr_matmulA(y)
+    lhs, rhs = float(y @ Ax), float(x @ Ay)
+    assert abs(lhs - rhs) <= 1e-10 * np.linalg.norm(y) * np.linalg.norm(Ax)
+    assert float(x @ Ax) > float(x @ x) * (1 - 1e-12)
+    ctx.initPrecond("pseudoinv")
+    ctx.update_precond()
+    Mx, My = ctx.cr_invM(x), ctx.cr_invM(y)
+    assert abs(float(y @ Mx) - float(x @ My)) <= 1e-10 * np.linalg.norm(y) * np.linalg.norm(Mx)   # M^-1 symmetric
+    assert float(x @ Mx) > 0.0
+    res = []
+    for nit in (1, 4):
+        _, niter, stat, r = ctx.solve_cr_eqn_by_CG(Ax, conv_crit="fixed_iter", maxiter=nit)
+        assert stat == 0 and niter == nit
+        res.append(r[0] / r[1])
+    assert res[1] < res[0] < 1.0
