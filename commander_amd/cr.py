@@ -184,6 +184,23 @@ class CRContext:
         check(self.L.cmdr_get_alpha_nu(self._h, int(band), _p(out)), self.L)
         return out
 
+    def add_compact(self, nparam, sigma, mean, P, active=True):
+        """Compact block (templates / point sources): P = {band: scipy.sparse or dense (ncell_b, nparam)} with
+        cell = pix_local + npix_local * stokes.  Call in compList order relative to add_comp."""
+        import scipy.sparse as sp
+        sg = np.ascontiguousarray(np.broadcast_to(np.asarray(sigma, dtype=np.float64), (nparam,)))
+        mn = np.ascontiguousarray(np.broadcast_to(np.asarray(mean, dtype=np.float64), (nparam,)))
+        blk = check(self.L.cmdr_compact_add(self._h, int(nparam), _p(sg), _p(mn), int(bool(active))), self.L)
+        for band, M in P.items():
+            coo = sp.coo_matrix(M)
+            cell = np.ascontiguousarray(coo.row, dtype=np.int64)
+            par = np.ascontiguousarray(coo.col, dtype=np.int32)
+            val = np.ascontiguousarray(coo.data, dtype=np.float64)
+            check(self.L.cmdr_compact_set_band(self._h, blk, int(band), int(val.size),
+                                               cell.ctypes.data_as(ctypes.POINTER(ctypes.c_int64)),
+                                               par.ctypes.data_as(ctypes.POINTER(ctypes.c_int)), _p(val)), self.L)
+        return blk
+
     def set_mixing_map(self, comp, band, F):
         """``F(band,0)%p%map`` of a component with spatially varying mixing (npix_local[, nmaps]); None = F_mean path."""
         if F is None:
@@ -289,12 +306,16 @@ def build_context(spec, device=0, rings_by_nside=None, _lib=None):
             ctx.set_rings(ns, r)
     for b in spec["bands"]:
         ctx.add_band(b["nside"], b["lmax"], b["siN"], b["b_l"], b.get("mb_eff", 1.0), b.get("sg_mask"), b.get("wring"))
-    for c in spec["comps"]:
+    kd = 0
+    for c in spec["comps"]:      # compList order == stacked-vector order; entries with kind == "compact" are compact blocks
+        if c.get("kind") == "compact":
+            ctx.add_compact(c["nparam"], c["sigma"], c["mean"], c["P"], c.get("active", True))
+            continue
         ctx.add_comp(c["lmax"], c["nmaps"], c["F_mean"], c.get("sqrtS_mat"), c.get("sqrtInvS_mat"), c.get("S_mat"),
                      c.get("active", True))
-    for k, c in enumerate(spec["comps"]):
         for ib, F in (c.get("F_map") or {}).items():
-            ctx.set_mixing_map(k, ib, F)
+            ctx.set_mixing_map(kd, ib, F)
+        kd += 1
     ctx.finalize()
     return ctx
 

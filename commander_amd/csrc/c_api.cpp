@@ -315,6 +315,21 @@ int cmdr_get_alpha_nu(cmdr_ctx* ctx, int band, double* out_host) {
         std::copy(a.begin(), a.end(), out_host);
     });
 }
+int cmdr_compact_add(cmdr_ctx* ctx, int nparam, const double* sigma, const double* mean, int active) {
+    int idx = -1;
+    const int rc = guarded([&] {
+        CMDR_REQUIRE(ctx, "ctx is NULL");
+        idx = ctx->sys->add_compact(nparam, sigma, mean, active);
+    });
+    return rc == 0 ? idx : rc;
+}
+int cmdr_compact_set_band(cmdr_ctx* ctx, int block, int band, int64_t nnz, const int64_t* cell, const int* param,
+                          const double* val) {
+    return guarded([&] {
+        CMDR_REQUIRE(ctx, "ctx is NULL");
+        ctx->sys->set_compact_band(block, band, nnz, cell, param, val);
+    });
+}
 int cmdr_comp_set_mixing_map(cmdr_ctx* ctx, int comp, int band, const double* F, int nmaps) {
     return guarded([&] {
         CMDR_REQUIRE(ctx, "ctx is NULL");

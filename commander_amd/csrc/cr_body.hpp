@@ -233,6 +233,31 @@ CMDR_HD void pinv_prior_elem(const CompDev* __restrict__ comps, int ncomp, const
         }
 }
 
+// Compact components (templates, point sources; comm_template_comp_mod.f90:210-270, comm_ptsrc_comp_mod.f90:336-428):
+// parameter p adds val * a_p to the cells listed for it.  cell = pix + npix * stokes of ONE band; the band's Stokes
+// maps live at base[stokes] inside a plan's map buffer (T maps first, then the (Q,U) pairs).
+struct CellBase {
+    int64_t np;         // pixels per map
+    int64_t off[3];     // map offsets (in doubles) of the band's T, Q, U maps inside the buffer
+};
+CMDR_HD int64_t cell_addr(const CellBase& B, int64_t cell) {
+    const int64_t st = cell / B.np;
+    return B.off[st] + (cell - st * B.np);
+}
+// CSR row (= cell): z[cell] += sum_k val[k] a[col[k]]
+CMDR_HD void compact_fwd_row(double* __restrict__ z, const CellBase& B, const int64_t* __restrict__ rows,
+                             const int64_t* __restrict__ ptr, const int* __restrict__ col,
+                             const double* __restrict__ val, const double* __restrict__ a, int64_t r) {
+    double s = 0.0;
+    for (int64_t k = ptr[r]; k < ptr[r + 1]; ++k) s += val[k] * a[col[k]];
+    z[cell_addr(B, rows[r])] += s;
+}
+// one CSC entry of column p: val * u[cell]
+CMDR_HD double compact_adj_term(const double* __restrict__ u, const CellBase& B, const int64_t* __restrict__ cell,
+                                const double* __restrict__ val, int64_t k) {
+    return val[k] * u[cell_addr(B, cell[k])];
+}
+
 // Chain-file order of a_lm (comm_map_mod.f90:712-719: ind = l^2 + l + m, m = -l..l, single precision) <-> packed.
 //   to_chain != 0: out32[l^2+l+m] = (float) alm[packed(l, m)]   ;   else: alm[packed(l, m)] = in32[l^2+l+m]
 CMDR_HD void alm_chain_elem(double* __restrict__ alm, float* __restrict__ c32, int lmax, int to_chain, int m, int l) {

@@ -268,6 +268,64 @@ void launch_axpby(const double* a, const double* b, double cb, double* out, int6
 }
 
 // ----------------------------------------------------------------------------- sigma_l (K13)
+__global__ void k_compact_fwd(double* __restrict__ z, CellBase B, const int64_t* __restrict__ rows,
+                              const int64_t* __restrict__ ptr, const int* __restrict__ col,
+                              const double* __restrict__ val, const double* __restrict__ a, int64_t nrows) {
+    const int64_t r = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (r < nrows) compact_fwd_row(z, B, rows, ptr, col, val, a, r);
+}
+void launch_compact_fwd(double* z, const CellBase& B, const int64_t* rows, const int64_t* ptr, const int* col,
+                        const double* val, const double* a, int64_t nrows, hipStream_t s) {
+    if (nrows == 0) return;
+    hipLaunchKernelGGL(k_compact_fwd, dim3((unsigned)((nrows + 255) / 256)), dim3(256), 0, s, z, B, rows, ptr, col, val, a,
+                       nrows);
+}
+// one workgroup per parameter; fixed-order block reduction (deterministic)
+__global__ void __launch_bounds__(256) k_compact_adj(const double* __restrict__ u, CellBase B,
+                                                     const int64_t* __restrict__ cptr, const int64_t* __restrict__ cell,
+                                                     const double* __restrict__ val, const double* __restrict__ scale,
+                                                     double* __restrict__ y, int accumulate) {
+    const int p = blockIdx.x;
+    double acc = 0.0;
+    for (int64_t k = cptr[p] + threadIdx.x; k < cptr[p + 1]; k += 256) acc += compact_adj_term(u, B, cell, val, k);
+    const double r = block_sum_256(acc);
+    if (threadIdx.x == 0) {
+        const double v = r * (scale ? scale[p] : 1.0);
+        y[p] = accumulate ? y[p] + v : v;
+    }
+}
+void launch_compact_adj(const double* u, const CellBase& B, const int64_t* cptr, const int64_t* cell, const double* val,
+                        const double* scale, double* y, int nparam, bool accumulate, hipStream_t s) {
+    if (nparam == 0) return;
+    hipLaunchKernelGGL(k_compact_adj, dim3(nparam), dim3(256), 0, s, u, B, cptr, cell, val, scale, y, accumulate ? 1 : 0);
+}
+__global__ void __launch_bounds__(256) k_dense_mv(const double* __restrict__ M, const double* __restrict__ x,
+                                                  double* __restrict__ y, int n) {
+    const int i = blockIdx.x;
+    double acc = 0.0;
+    for (int j = threadIdx.x; j < n; j += 256) acc += M[(int64_t)i * n + j] * x[j];
+    const double r = block_sum_256(acc);
+    if (threadIdx.x == 0) y[i] = r;
+}
+void launch_dense_mv(const double* M, const double* x, double* y, int n, hipStream_t s) {
+    if (n == 0) return;
+    hipLaunchKernelGGL(k_dense_mv, dim3(n), dim3(256), 0, s, M, x, y, n);
+}
+__global__ void k_vec_scale(int mode, const double* __restrict__ a, const double* __restrict__ sc,
+                            const double* __restrict__ b, const double* __restrict__ c, double* __restrict__ out, int n) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    double v = mode == 1 ? a[i] / sc[i] : a[i] * sc[i];
+    if (mode >= 2 && b) v += b[i];
+    if (mode == 3 && c) v += c[i] / sc[i];
+    out[i] = v;
+}
+void launch_vec_scale(int mode, const double* a, const double* sc, const double* b, const double* c, double* out, int n,
+                      hipStream_t s) {
+    if (n == 0) return;
+    hipLaunchKernelGGL(k_vec_scale, dim3((n + 255) / 256), dim3(256), 0, s, mode, a, sc, b, c, out, n);
+}
+
 __global__ void k_alm_chain(double* __restrict__ alm, int64_t alm_stride, float* __restrict__ c32, int lmax,
                             int to_chain) {
     const int m = blockIdx.y, l = m + blockIdx.x * 256 + threadIdx.x;

@@ -22,7 +22,9 @@ CrSystem::~CrSystem() {
     if (stream_) (void)hipStreamDestroy(stream_);
 }
 
-bool CrSystem::pipelined(const Group& G) const { return pipeline_ && G.npol == 0 && G.nT > kPipeBatch; }
+bool CrSystem::pipelined(const Group& G) const {
+    return pipeline_ && G.npol == 0 && G.nT > kPipeBatch && compacts_.empty();
+}
 
 void CrSystem::pipeline_events(Group& G, int nbatch) {
     while ((int)G.ev_synth.size() < nbatch) {
@@ -168,7 +170,42 @@ int CrSystem::add_comp(int lmax_amp, int nmaps, int lmax_cl, const double* sqrtS
     C.F_map.resize(bands_.size());
     C.F_map_nm.assign(bands_.size(), 0);
     C.mulF.resize(bands_.size());
+    order_.push_back({0, (int)comps_.size() - 1});
     return (int)comps_.size() - 1;
+}
+
+int CrSystem::add_compact(int nparam, const double* sigma, const double* mean, int active) {
+    CMDR_REQUIRE(!finalized_, "add_compact after finalize");
+    CMDR_REQUIRE(!bands_.empty(), "add bands first");
+    CMDR_REQUIRE(nparam >= 1 && sigma && mean, "bad arguments");
+    compacts_.emplace_back();
+    Compact& K = compacts_.back();
+    K.nparam = nparam;
+    K.active = active ? 1 : 0;
+    K.sigma.assign(sigma, sigma + nparam);
+    K.mean.assign(mean, mean + nparam);
+    for (double v : K.sigma) CMDR_REQUIRE(v > 0.0, "compact component: prior sigma must be > 0");
+    order_.push_back({1, (int)compacts_.size() - 1});
+    return (int)compacts_.size() - 1;
+}
+
+void CrSystem::set_compact_band(int block, int band, int64_t nnz, const int64_t* cell, const int* param,
+                                const double* val) {
+    CMDR_REQUIRE(!finalized_, "set_compact_band after finalize");
+    CMDR_REQUIRE(block >= 0 && block < (int)compacts_.size() && band >= 0 && band < (int)bands_.size(), "bad block / band");
+    CMDR_REQUIRE(nnz >= 0 && (nnz == 0 || (cell && param && val)), "bad arguments");
+    Compact& K = compacts_[block];
+    const int64_t ncell = band_npix(band) * bands_[band].nmaps;
+    for (CompactBand& B : K.P) CMDR_REQUIRE(B.band != band, "compact band set twice");
+    K.P.emplace_back();
+    CompactBand& B = K.P.back();
+    B.band = band;
+    for (int64_t i = 0; i < nnz; ++i) {
+        CMDR_REQUIRE(cell[i] >= 0 && cell[i] < ncell && param[i] >= 0 && param[i] < K.nparam, "compact entry out of range");
+        B.h_cell.push_back(cell[i]);
+        B.h_param.push_back(param[i]);
+        B.h_val.push_back(val[i]);
+    }
 }
 
 void CrSystem::finalize() {
@@ -178,9 +215,41 @@ void CrSystem::finalize() {
     int64_t pos = 0;
     std::vector<double> smat;
     lmax_max_ = -1;
+    for (auto& o : order_) {   // stacked-vector order = order of the add_comp / add_compact calls (compList order)
+        if (o.first == 0) { comps_[o.second].d.pos = pos; pos += comps_[o.second].d.nalm * comps_[o.second].d.nmaps; }
+        else { compacts_[o.second].pos = pos; pos += compacts_[o.second].nparam; }
+    }
+    for (Compact& K : compacts_) {
+        K.sigma_dev.upload(K.sigma);
+        K.mean_dev.upload(K.mean);
+        for (CompactBand& B : K.P) {   // COO -> CSR over the touched cells (sorted) and CSC by parameter
+            const size_t nnz = B.h_val.size();
+            std::vector<size_t> idx(nnz);
+            for (size_t i = 0; i < nnz; ++i) idx[i] = i;
+            std::stable_sort(idx.begin(), idx.end(), [&](size_t a, size_t b) { return B.h_cell[a] < B.h_cell[b]; });
+            std::vector<int64_t> rows, rptr;
+            std::vector<int> rcol;
+            std::vector<double> rval;
+            for (size_t i : idx) {
+                if (rows.empty() || rows.back() != B.h_cell[i]) { rows.push_back(B.h_cell[i]); rptr.push_back((int64_t)rcol.size()); }
+                rcol.push_back(B.h_param[i]);
+                rval.push_back(B.h_val[i]);
+            }
+            rptr.push_back((int64_t)rcol.size());
+            B.nrows = (int64_t)rows.size();
+            std::stable_sort(idx.begin(), idx.end(), [&](size_t a, size_t b) { return B.h_param[a] < B.h_param[b]; });
+            std::vector<int64_t> cptr(K.nparam + 1, 0), ccell;
+            std::vector<double> cval;
+            for (size_t i : idx) { cptr[B.h_param[i] + 1]++; ccell.push_back(B.h_cell[i]); cval.push_back(B.h_val[i]); }
+            for (int p = 0; p < K.nparam; ++p) cptr[p + 1] += cptr[p];
+            if (rows.empty()) { rows.push_back(0); }
+            if (ccell.empty()) { ccell.push_back(0); cval.push_back(0.0); rcol.push_back(0); rval.push_back(0.0); }
+            B.rows.upload(rows); B.rptr.upload(rptr); B.rcol.upload(rcol); B.rval.upload(rval);
+            B.cptr.upload(cptr); B.ccell.upload(ccell); B.cval.upload(cval);
+            B.h_cell.clear(); B.h_param.clear(); B.h_val.clear();
+        }
+    }
     for (Comp& C : comps_) {
-        C.d.pos = pos;
-        pos += C.d.nalm * C.d.nmaps;
         C.d.smat_off = (long long)smat.size();
         smat.insert(smat.end(), C.sqrtS.begin(), C.sqrtS.end());
         smat.insert(smat.end(), C.sqrtInvS.begin(), C.sqrtInvS.end());
@@ -427,6 +496,110 @@ void CrSystem::mix_adjoint(Group& G, bool rhs) {
     }
 }
 
+// ------------------------------------------------------------------------------------------------- compact components
+bool CrSystem::group_has_compact(const Group& G) const {
+    for (const Compact& K : compacts_)
+        if (K.active)
+            for (const CompactBand& B : K.P)
+                if (bands_[B.band].group >= 0 && &groups_[bands_[B.band].group] == &G) return true;
+    return false;
+}
+
+CellBase CrSystem::cell_base(int band) const {   // where the band's Stokes maps sit in its plan's [nbm][npix] buffers
+    const Group& G = groups_[bands_[band].group];
+    CellBase C;
+    C.np = G.plan->npix_local();
+    C.off[0] = C.off[1] = C.off[2] = 0;
+    for (int bm = 0; bm < G.nbm; ++bm)
+        if (G.bm_band[bm] == band) C.off[G.bm_stokes[bm]] = (int64_t)bm * C.np;
+    return C;
+}
+
+void CrSystem::compact_forward(Group& G, const double* sx, double* maps) {   // evalPtsrcBand / evalTemplateBand
+    for (Compact& K : compacts_) {
+        if (!K.active) continue;
+        for (CompactBand& B : K.P) {
+            if (&groups_[bands_[B.band].group] != &G) continue;
+            launch_compact_fwd(maps, cell_base(B.band), B.rows.get(), B.rptr.get(), B.rcol.get(), B.rval.get(), sx + K.pos,
+                               B.nrows, stream_);
+        }
+    }
+}
+
+void CrSystem::compact_adjoint(Group& G, const double* maps, double* yc) {   // projectPtsrcBand / projectTemplateBand
+    for (Compact& K : compacts_) {
+        if (!K.active) continue;
+        for (CompactBand& B : K.P) {
+            if (&groups_[bands_[B.band].group] != &G) continue;
+            launch_compact_adj(maps, cell_base(B.band), B.cptr.get(), B.ccell.get(), B.cval.get(), nullptr, yc + K.pos,
+                               K.nparam, true, stream_);
+        }
+    }
+}
+
+// Dense block of A on every compact block, inverted on the host: delta + sigma (sum_b P_b^t N_b^-1 P_b) sigma.
+// (initPtsrcPrecond / initTemplatePrecond build approximations of this block; the exact one is used here.)
+void CrSystem::compact_precond_init() {
+    for (Compact& K : compacts_) {
+        const int n = K.nparam;
+        std::vector<double> M((size_t)n * n, 0.0);
+        if (K.active) {
+            DevBuf<double> e(n), col(n);
+            std::vector<double> he(n, 0.0), hc(n);
+            for (int j = 0; j < n; ++j) {
+                he.assign(n, 0.0);
+                he[j] = 1.0;
+                e.upload(he, stream_);
+                CMDR_HIP_CHECK(hipMemsetAsync(col.get(), 0, sizeof(double) * n, stream_));
+                for (CompactBand& B : K.P) {
+                    Group& G = groups_[bands_[B.band].group];
+                    const int64_t np = G.plan->npix_local();
+                    G.tmpmap.ensure((size_t)G.nbm * np);
+                    const CellBase cb = cell_base(B.band);
+                    for (int st = 0; st < bands_[B.band].nmaps; ++st)
+                        CMDR_HIP_CHECK(hipMemsetAsync(G.tmpmap.get() + cb.off[st], 0, sizeof(double) * np, stream_));
+                    launch_compact_fwd(G.tmpmap.get(), cb, B.rows.get(), B.rptr.get(), B.rcol.get(), B.rval.get(), e.get(),
+                                       B.nrows, stream_);
+                    for (int st = 0; st < bands_[B.band].nmaps; ++st)
+                        launch_pix(0, bands_[B.band].mul.get() + (int64_t)st * np, G.tmpmap.get() + cb.off[st], nullptr,
+                                   G.tmpmap.get() + cb.off[st], np, stream_);
+                    launch_compact_adj(G.tmpmap.get(), cb, B.cptr.get(), B.ccell.get(), B.cval.get(), nullptr, col.get(), n,
+                                       true, stream_);
+                }
+                sync();
+                CMDR_HIP_CHECK(hipMemcpy(hc.data(), col.get(), sizeof(double) * n, hipMemcpyDeviceToHost));
+                for (int i = 0; i < n; ++i) M[(size_t)i * n + j] = hc[i];
+            }
+            DevBuf<double> dm(M.size());                        // sum over ring sets and band groups
+            dm.upload(M, stream_);
+            reduce(dm.get(), (int64_t)M.size());
+            sync();
+            CMDR_HIP_CHECK(hipMemcpy(M.data(), dm.get(), sizeof(double) * M.size(), hipMemcpyDeviceToHost));
+            for (int i = 0; i < n; ++i)
+                for (int j = 0; j < n; ++j) M[(size_t)i * n + j] *= K.sigma[i] * K.sigma[j];
+        }
+        for (int i = 0; i < n; ++i) M[(size_t)i * n + i] += 1.0;
+        // Gauss-Jordan inverse (SPD block, small)
+        std::vector<double> I((size_t)n * n, 0.0);
+        for (int i = 0; i < n; ++i) I[(size_t)i * n + i] = 1.0;
+        for (int c = 0; c < n; ++c) {
+            int piv = c;
+            for (int r = c + 1; r < n; ++r) if (std::fabs(M[(size_t)r * n + c]) > std::fabs(M[(size_t)piv * n + c])) piv = r;
+            CMDR_REQUIRE(M[(size_t)piv * n + c] != 0.0, "singular compact preconditioner block");
+            if (piv != c) for (int k = 0; k < n; ++k) { std::swap(M[(size_t)c * n + k], M[(size_t)piv * n + k]); std::swap(I[(size_t)c * n + k], I[(size_t)piv * n + k]); }
+            const double inv = 1.0 / M[(size_t)c * n + c];
+            for (int k = 0; k < n; ++k) { M[(size_t)c * n + k] *= inv; I[(size_t)c * n + k] *= inv; }
+            for (int r = 0; r < n; ++r) {
+                if (r == c) continue;
+                const double f = M[(size_t)r * n + c];
+                if (f == 0.0) continue;
+                for (int k = 0; k < n; ++k) { M[(size_t)r * n + k] -= f * M[(size_t)c * n + k]; I[(size_t)r * n + k] -= f * I[(size_t)c * n + k]; }
+            }
+        }
+        K.Minv.upload(I, stream_);
+    }
+}
+
 void CrSystem::reduce_rings(double* v, int64_t n) {
     if (!band_sharded_) { reduce(v, n); return; }
     if (!allreduce_rings_) return;           // one rank per ring group
@@ -482,6 +655,10 @@ void CrSystem::matmulA(const double* x, double* y) {
     span_begin(3);
     // sqrtS_x = S^1/2 x  (comm_cr_mod.f90:792-836)
     launch_sqrtS(comps_dev_.get(), ncomp, lmax_max_, smat_.get(), 0, x, nullptr, sx_.get(), false, stream_);
+    for (Compact& K : compacts_) {                                                   // pamp * P_cg(2)  :817-833
+        if (K.active) launch_vec_scale(0, x + K.pos, K.sigma_dev.get(), nullptr, nullptr, sx_.get() + K.pos, K.nparam, stream_);
+        CMDR_HIP_CHECK(hipMemsetAsync(yc_.get() + K.pos, 0, sizeof(double) * K.nparam, stream_));
+    }
     for (Group& G : groups_) {   // per-band loop :843-954, all bands of a geometry batched
         ShtPlan& P = *G.plan;
         const double* extra = nullptr;
@@ -491,6 +668,26 @@ void CrSystem::matmulA(const double* x, double* y) {
         if (G.npol)
             launch_band_prep2(comps_dev_.get(), ncomp, sx_.get(), G.w.get(), G.nT, P.stream2(), G.npol,
                               P.leg2().cnorm.get(), G.lmax, stream_, extra);
+        if (group_has_compact(G)) {
+            // compact objects live in pixel space (:872-897, :935-948): the map has to exist, so this plan runs the ring
+            // stage unfused: phases -> map, + P a, * N^-1, P^t ., map -> phases
+            const int64_t np = P.npix_local();
+            G.tmpmap.ensure((size_t)G.nbm * np);
+            span_begin(0);
+            P.synth_from_stream(G.nT, stream_);
+            if (G.npol) P.synth2_from_stream(G.npol, G.nT, stream_);
+            span_end();
+            span_begin(1);
+            P.rings(0, G.tmpmap.get(), np, nullptr, false, G.nbm, stream_);
+            compact_forward(G, sx_.get(), G.tmpmap.get());
+            for (int bm = 0; bm < G.nbm; ++bm)
+                launch_pix(0, bands_[G.bm_band[bm]].mul.get() + (int64_t)G.bm_stokes[bm] * np, G.tmpmap.get() + (int64_t)bm * np,
+                           nullptr, G.tmpmap.get() + (int64_t)bm * np, np, stream_);
+            compact_adjoint(G, G.tmpmap.get(), yc_.get());
+            P.rings(1, G.tmpmap.get(), np, nullptr, false, G.nbm, stream_);
+            span_end();
+            continue;
+        }
         if (pipelined(G)) {
             // batches of 3 maps: Y of batch j+1 (main stream, VALU-bound) beside N^-1 of batch j (ring stream, LDS-bound)
             const int nbatch = (G.nT + kPipeBatch - 1) / kPipeBatch;
@@ -521,6 +718,10 @@ void CrSystem::matmulA(const double* x, double* y) {
     adjoint_groups_to_yc(false);                                                     // Yt :915, projectBand :920-948
     // y = S^1/2 yc + x  (:957-1008)
     launch_sqrtS(comps_dev_.get(), ncomp, lmax_max_, smat_.get(), 0, yc_.get(), x, y, false, stream_);
+    for (Compact& K : compacts_) {                                                   // :985-1003
+        if (K.active) launch_vec_scale(2, yc_.get() + K.pos, K.sigma_dev.get(), x + K.pos, nullptr, y + K.pos, K.nparam, stream_);
+        else CMDR_HIP_CHECK(hipMemsetAsync(y + K.pos, 0, sizeof(double) * K.nparam, stream_));
+    }
     span_end();
 }
 
@@ -529,6 +730,7 @@ void CrSystem::compute_rhs(bool sample, const double* const* resid, const double
                            const double* mu, double* rhs) {
     CMDR_REQUIRE(finalized_, "finalize first");
     const int ncomp = (int)comps_.size();
+    for (Compact& K : compacts_) CMDR_HIP_CHECK(hipMemsetAsync(yc_.get() + K.pos, 0, sizeof(double) * K.nparam, stream_));
     for (Group& G : groups_) {
         ShtPlan& P = *G.plan;
         const int64_t np = P.npix_local();
@@ -543,6 +745,7 @@ void CrSystem::compute_rhs(bool sample, const double* const* resid, const double
             else         // invN (:611)
                 launch_pix(0, B.mul.get() + (int64_t)j * np, dmap, nullptr, out, np, stream_);
         }
+        compact_adjoint(G, G.tmpmap.get(), yc_.get());                               // projectBand of compact objects :661-680
         P.rings(1, G.tmpmap.get(), np, nullptr, false, G.nbm, stream_);              // Yt :615
     }
     adjoint_groups_to_yc(true);                                                      // beam, F_mean :616-639
@@ -562,6 +765,12 @@ void CrSystem::compute_rhs(bool sample, const double* const* resid, const double
         add = eta;
     }
     launch_sqrtS(comps_dev_.get(), ncomp, lmax_max_, smat_.get(), 0, yc_.get(), add, rhs, false, stream_);
+    for (Compact& K : compacts_) {   // sigma * P^t(...) + eta + P(1)/P(2)   (:676-679, :750-761)
+        if (K.active)
+            launch_vec_scale(3, yc_.get() + K.pos, K.sigma_dev.get(), sample ? eta + K.pos : nullptr, K.mean_dev.get(),
+                             rhs + K.pos, K.nparam, stream_);
+        else CMDR_HIP_CHECK(hipMemsetAsync(rhs + K.pos, 0, sizeof(double) * K.nparam, stream_));
+    }
 }
 
 // ------------------------------------------------------------------------------------------------- preconditioner
@@ -701,6 +910,7 @@ void CrSystem::precond_init_diag() {
                     }
                 }
         }
+    compact_precond_init();
     if (band_sharded_) {   // M0 is a sum over bands: complete it over the ranks; every ring group contributes its bands
                            // ring_replicas_ times
         DevBuf<double> tmp(M0_.size());
@@ -820,6 +1030,7 @@ void pseudo_inverse(const std::vector<double>& A, int m, int n, double thr, std:
 void CrSystem::precond_init_pseudoinv() {
     CMDR_REQUIRE(finalized_, "finalize first");
     CMDR_REQUIRE(!band_sharded_, "the pseudo-inverse preconditioner needs every band on every rank (ring sharding only)");
+    CMDR_REQUIRE(compacts_.empty(), "compact components are supported with the diagonal preconditioner type only");
     for (Group& G : groups_) {
         ShtPlan& P = *G.plan;
         const int64_t np = P.npix_local(), na = P.nalm();
@@ -967,6 +1178,8 @@ void CrSystem::invM(const double* x, double* y) {
     CMDR_REQUIRE(precond_ready_, "preconditioner not initialised (precond_init_* + precond_update_*)");
     if (precond_type_ == 1) { apply_pseudoinv(x, y); return; }
     launch_precond_diag(comps_dev_.get(), (int)comps_.size(), P_.get(), lmax_pre_, nmaps_pre_, x, y, stream_);
+    for (Compact& K : compacts_)   // applyPtsrcPrecond / applyTemplatePrecond: the block's own dense inverse
+        launch_dense_mv(K.Minv.get(), x + K.pos, y + K.pos, K.nparam, stream_);
 }
 
 // ------------------------------------------------------------------------------------------------- PCG
@@ -984,6 +1197,10 @@ SolveResult CrSystem::solve(const double* b, double* x, int crit, double tol, in
         CMDR_HIP_CHECK(hipMemcpyAsync(r_.get(), b, n * sizeof(double), hipMemcpyDeviceToDevice, stream_));  // r = b - A 0
     } else {                                                                            // :136-173
         launch_sqrtS(comps_dev_.get(), ncomp, lmax_max_, smat_.get(), 1, x0, nullptr, x, true, stream_);
+        for (Compact& K : compacts_) {                                                  // :160-170
+            if (K.active) launch_vec_scale(1, x0 + K.pos, K.sigma_dev.get(), nullptr, nullptr, x + K.pos, K.nparam, stream_);
+            else CMDR_HIP_CHECK(hipMemcpyAsync(x + K.pos, x0 + K.pos, sizeof(double) * K.nparam, hipMemcpyDeviceToDevice, stream_));
+        }
         matmulA(x, q_.get());
         launch_axpby(b, q_.get(), -1.0, r_.get(), n, stream_);                           // :201
     }
@@ -1016,6 +1233,10 @@ SolveResult CrSystem::solve(const double* b, double* x, int crit, double tol, in
     }
     // x <- S^1/2 x  (:350-389)
     launch_sqrtS(comps_dev_.get(), ncomp, lmax_max_, smat_.get(), 0, x, nullptr, tmp_.get(), true, stream_);
+    for (Compact& K : compacts_) {                                                      // :376-388
+        if (K.active) launch_vec_scale(0, x + K.pos, K.sigma_dev.get(), nullptr, nullptr, tmp_.get() + K.pos, K.nparam, stream_);
+        else CMDR_HIP_CHECK(hipMemcpyAsync(tmp_.get() + K.pos, x + K.pos, sizeof(double) * K.nparam, hipMemcpyDeviceToDevice, stream_));
+    }
     CMDR_HIP_CHECK(hipMemcpyAsync(x, tmp_.get(), n * sizeof(double), hipMemcpyDeviceToDevice, stream_));
     fetch();
     R.delta_new = h[0];

@@ -43,6 +43,12 @@ class CrSystem {
                  const double* sg_mask, const double* wring);
     int add_comp(int lmax_amp, int nmaps, int lmax_cl, const double* sqrtS, const double* sqrtInvS,
                  const double* S, const double* F_mean, int active);
+    // Compact components (templates, point sources): nparam scalar amplitudes with Gaussian prior (mean, sigma); call in
+    // compList order relative to add_comp (that order is the stacked-vector order).  Then one sparse matrix per band:
+    // COO triplets (cell = pix_local + npix_local * stokes, param, value) = what evalTemplateBand / evalPtsrcBand add
+    // to the band's map per unit amplitude.
+    int add_compact(int nparam, const double* sigma, const double* mean, int active);
+    void set_compact_band(int block, int band, int64_t nnz, const int64_t* cell, const int* param, const double* val);
     void finalize();
     // F(band,0)%p%map of a component with spatially varying mixing: npix_local x nmaps (nmaps = min of the band's and
     // the component's), or nullptr to go back to the F_mean fast path.  Callable before or after finalize.
@@ -112,6 +118,21 @@ class CrSystem {
         std::vector<DevBuf<double>> mulF;        // [nband]: F * W_ring 4pi/Npix (device), built by rebuild_mixing
         std::vector<double> cl_diag;             // optional getCl table
     };
+    struct CompactBand {                         // P_b of one block on one band, both orientations
+        int band = -1;
+        int64_t nrows = 0;
+        std::vector<int64_t> h_cell; std::vector<int> h_param; std::vector<double> h_val;   // COO until finalize
+        DevBuf<int64_t> rows, rptr, cptr, ccell;   // CSR over touched cells; CSC by parameter
+        DevBuf<int> rcol;
+        DevBuf<double> rval, cval;
+    };
+    struct Compact {
+        int nparam = 0, active = 1;
+        int64_t pos = 0;
+        std::vector<double> sigma, mean;
+        DevBuf<double> sigma_dev, mean_dev, Minv;
+        std::vector<CompactBand> P;
+    };
     struct MixCol { int bm, comp, stokes; };     // one scalar column / first column of a (Q,U) pair of a mixing batch
     struct MixBatch {
         std::vector<MixCol> T, P;
@@ -137,6 +158,11 @@ class CrSystem {
         DevBuf<double> w_pin, w_pout;       // [nbm][ncomp][lmax+1]
         DevBuf<const double*> mulP_ptrs;    // [nbm]
     };
+    CellBase cell_base(int band) const;
+    void compact_forward(Group& G, const double* sx, double* maps);     // maps += P (sigma already applied: sx)
+    void compact_adjoint(Group& G, const double* maps, double* yc);      // yc[block] += P^t maps
+    void compact_precond_init();
+    bool group_has_compact(const Group& G) const;
     void rebuild_weights();
     void rebuild_mixing();
     void mix_forward(Group& G, const double* sx);
@@ -165,6 +191,8 @@ class CrSystem {
     hipStream_t stream_ = nullptr;
     std::vector<Band> bands_;
     std::vector<Comp> comps_;
+    std::vector<Compact> compacts_;
+    std::vector<std::pair<int, int>> order_;   // stacked-vector order: (0, diffuse index) | (1, compact index)
     std::vector<Group> groups_;
     std::vector<std::pair<int, std::vector<int>>> ring_sets_;
     bool finalized_ = false, only_pol_ = false, profile_ = false;

@@ -72,6 +72,15 @@ void launch_cg_xr(double* x, double* r, const double* d, const double* q, int64_
                   int den, hipStream_t s);
 void launch_cg_d(double* d, const double* sv, int64_t n, const double* scal, int num, int den, hipStream_t s);
 void launch_axpby(const double* a, const double* b, double cb, double* out, int64_t n, hipStream_t s);
+// compact components: z += P a (CSR over the touched cells), y[p] (+)= scale[p] * (P^t u)[p] (CSC), small dense y = M x
+void launch_compact_fwd(double* z, const CellBase& B, const int64_t* rows, const int64_t* ptr, const int* col,
+                        const double* val, const double* a, int64_t nrows, hipStream_t s);
+void launch_compact_adj(const double* u, const CellBase& B, const int64_t* cptr, const int64_t* cell, const double* val,
+                        const double* scale, double* y, int nparam, bool accumulate, hipStream_t s);
+void launch_dense_mv(const double* M, const double* x, double* y, int n, hipStream_t s);
+// mode 0: out = a * s ; 1: out = a / s ; 2: out = a * s + b ; 3: out = a * s + b + c / s  (b, c nullable -> 0)
+void launch_vec_scale(int mode, const double* a, const double* sc, const double* b, const double* c, double* out, int n,
+                      hipStream_t s);
 void launch_alm_chain(double* alm, int64_t alm_stride, float* c32, int lmax, int nmaps, bool to_chain, hipStream_t s);
 void launch_sigma_l(const double* alm, int64_t stride, int lmax, int nmaps, double* out, hipStream_t s);
 

@@ -143,7 +143,53 @@ def make_problem(cfg, nside=None, lmax=None, comp_lmax=None, pixels=None, pol=No
 
 
 def ncr_of(spec):
-    return sum((c["lmax"] + 1) ** 2 * c["nmaps"] for c in spec["comps"])
+    return sum(c["nparam"] if c.get("kind") == "compact" else (c["lmax"] + 1) ** 2 * c["nmaps"] for c in spec["comps"])
+
+
+def add_compact_blocks(spec, nsrc=5, seed=77):
+    """Append synthetic compact components to a problem spec: a monopole + dipole template block
+    on every band (comm_md_comp-like: 4 amplitudes per band, dense columns) inserted after the first diffuse component,
+    and ``nsrc`` point sources (sparse beam-sized footprints on every band, flat spectrum) at the end."""
+    import scipy.sparse as sp
+    nside = spec["nside"]
+    npix_full = 12 * nside * nside
+    pix = spec["pixels"] if spec["pixels"] is not None else np.arange(npix_full)
+    # unit vectors of the local pixels (RING): z from pix_z, phi from the ring geometry
+    z = healpix.pix_z(nside)
+    phi = np.concatenate([healpix.ring_info(nside, r)[2] + 2.0 * np.pi * np.arange(healpix.ring_info(nside, r)[0])
+                          / healpix.ring_info(nside, r)[0] for r in range(1, 4 * nside)])
+    sth = np.sqrt(1.0 - z * z)
+    vec = np.stack([np.ones(npix_full), sth * np.cos(phi), sth * np.sin(phi), z], axis=1)[pix]
+    np_loc = pix.size
+    blocks = []
+    for ib, b in enumerate(spec["bands"]):
+        nm = b["siN"].shape[1] if np.ndim(b["siN"]) > 1 else 1
+        T = np.zeros((np_loc * nm, 4))
+        T[:np_loc, :] = vec                          # temperature-only templates (Stokes 0 cells)
+        blocks.append(dict(kind="compact", nparam=4, sigma=[30.0, 10.0, 10.0, 10.0], mean=[1.0, 0.0, 0.5, -0.5],
+                           P={ib: sp.csr_matrix(T)}))
+    g = np.random.Generator(np.random.Philox(key=BASE_SEED, counter=[0, 0, 9, seed]))
+    centres = g.choice(npix_full, nsrc, replace=False)
+    P = {}
+    for ib, b in enumerate(spec["bands"]):
+        nm = b["siN"].shape[1] if np.ndim(b["siN"]) > 1 else 1
+        rows, cols, vals = [], [], []
+        for s_, c0 in enumerate(centres):
+            d2 = 2.0 - 2.0 * (vec_full_dot(z, phi, c0))        # squared chord distance to the source
+            sig = max(np.radians(b["fwhm"] / 60.0) / np.sqrt(8.0 * np.log(2.0)), 1.5 * np.sqrt(4.0 * np.pi / npix_full))
+            near = np.nonzero(d2[pix] < (3.0 * sig) ** 2)[0]
+            rows += list(near)
+            cols += [s_] * near.size
+            vals += list(np.exp(-0.5 * d2[pix][near] / sig ** 2))
+        P[ib] = sp.csr_matrix((vals, (rows, cols)), shape=(np_loc * nm, nsrc))
+    src = dict(kind="compact", nparam=nsrc, sigma=5.0, mean=0.0, P=P)
+    spec["comps"] = spec["comps"][:1] + blocks + spec["comps"][1:] + [src]
+    return spec
+
+
+def vec_full_dot(z, phi, p0):
+    sth, s0 = np.sqrt(1.0 - z * z), np.sqrt(1.0 - z[p0] ** 2)
+    return sth * s0 * np.cos(phi - phi[p0]) + z * z[p0]
 
 
 def draw_inputs(spec):

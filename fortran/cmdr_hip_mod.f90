@@ -226,6 +226,26 @@ module cmdr_hip_mod
        integer(c_int)              :: ierr
      end function cmdr_alm_from_chain_order
 
+     ! compact components (templates, point sources): scalar amplitudes with Gaussian prior; one sparse matrix per band
+     function cmdr_compact_add(ctx, nparam, sigma, mean, active) bind(c, name='cmdr_compact_add') result(idx)
+       import :: c_int, c_ptr, c_double
+       type(c_ptr),    value      :: ctx
+       integer(c_int), value      :: nparam, active
+       real(c_double), intent(in) :: sigma(*), mean(*)
+       integer(c_int)             :: idx
+     end function cmdr_compact_add
+
+     function cmdr_compact_set_band(ctx, block, band, nnz, cell, param, val) bind(c, name='cmdr_compact_set_band') result(ierr)
+       import :: c_int, c_int64_t, c_ptr, c_double
+       type(c_ptr),        value      :: ctx
+       integer(c_int),     value      :: block, band
+       integer(c_int64_t), value      :: nnz
+       integer(c_int64_t), intent(in) :: cell(*)     ! pix_local + npix_local * stokes, 0-based
+       integer(c_int),     intent(in) :: param(*)    ! 0-based
+       real(c_double),     intent(in) :: val(*)
+       integer(c_int)                 :: ierr
+     end function cmdr_compact_set_band
+
   end interface
 
 contains

@@ -116,6 +116,16 @@ int cmdr_band_add(cmdr_ctx* ctx, int nside, int lmax, int nmaps, const double* s
 int cmdr_comp_add(cmdr_ctx* ctx, int lmax_amp, int nmaps, int lmax_cl, const double* sqrtS_mat,
                   const double* sqrtInvS_mat, const double* S_mat, const double* F_mean, int active);
 int cmdr_finalize(cmdr_ctx* ctx);
+/* Compact components in the solve (templates: comm_template_comp_mod.f90:210-270; point sources:
+ * comm_ptsrc_comp_mod.f90:336-428): a block of nparam scalar amplitudes with Gaussian prior (mean, sigma) = P_cg / P_x,
+ * i.e. S^1/2 = sigma (comm_cr_mod.f90:817-833).  Call cmdr_compact_add in compList order relative to cmdr_comp_add:
+ * that order is the stacked-vector order.  cmdr_compact_set_band gives, for one band, what evalTemplateBand /
+ * evalPtsrcBand add to the band's map per unit amplitude, as COO triplets (cell = pix_local + npix_local * stokes,
+ * param, value); projectTemplateBand / projectPtsrcBand are its transpose.  Both before cmdr_finalize.  The
+ * preconditioner block of a compact block is its exact dense sub-matrix of A (diagonal preconditioner type only). */
+int cmdr_compact_add(cmdr_ctx* ctx, int nparam, const double* sigma, const double* mean, int active);
+int cmdr_compact_set_band(cmdr_ctx* ctx, int block, int band, int64_t nnz, const int64_t* cell, const int* param,
+                          const double* val);
 /* Spatially varying mixing matrix F(band,0)%p%map of one component at one band (producer: updateDiffuseMixmat,
  * comm_diffuse_comp_mod.f90:1662-2023; stays on the Fortran side): npix_local x nmaps, nmaps = min(component, band).
  * The pair then takes the Y . F . YtW branch of evalDiffuseBand / projectDiffuseBand / cr_computeRHS

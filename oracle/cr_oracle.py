@@ -191,6 +191,24 @@ class DiffuseComp:
         self.cltype = cl.type
 
 
+class CompactBlock:
+    """Pixel-space components with scalar amplitudes: ``comm_template_comp`` (one dense column on one band,
+    comm_template_comp_mod.f90:210-270) and ``comm_ptsrc_comp`` (one sparse column per source and Stokes parameter on
+    every band, comm_ptsrc_comp_mod.f90:336-428) in one form: parameter p contributes  sum_p P_b[cell, p] a_p  to the
+    cell = pix + npix * stokes of band b (evalTemplateBand / evalPtsrcBand) and receives  P_b^t map  (project*Band).
+    sigma, mean: the Gaussian prior P_cg / P_x (S^1/2 = sigma, comm_cr_mod.f90:817-833)."""
+
+    def __init__(self, nparam, sigma, mean, P, active=True):
+        import scipy.sparse as sp
+        self.nparam = int(nparam)
+        self.sigma = np.broadcast_to(np.asarray(sigma, dtype=np.float64), (self.nparam,)).copy()
+        self.mean = np.broadcast_to(np.asarray(mean, dtype=np.float64), (self.nparam,)).copy()
+        self.P = {int(b): sp.csr_matrix(m) for b, m in P.items()}   # band index -> (ncell_b, nparam)
+        self.active = active
+        self.nmaps = 1
+        self.cltype = "compact"
+
+
 class CRSystem:
     """The stacked linear system: ``ncr`` / ``ind_comp`` (comm_signal_mod.f90:113-125, comm_cr_utils.f90:25-33)."""
 
@@ -200,7 +218,7 @@ class CRSystem:
         self.ind_comp = []
         pos = 0
         for c in self.comps:
-            n = c.info.nalm * c.nmaps
+            n = c.nparam if isinstance(c, CompactBlock) else c.info.nalm * c.nmaps
             self.ind_comp.append((pos, n, c.nmaps))
             pos += n
         self.ncr = pos
@@ -263,7 +281,7 @@ class CRSystem:
     def _lmax_all(self):
         lm = -1
         for c in self.comps:
-            if c.active:
+            if c.active and not isinstance(c, CompactBlock):
                 lm = max(max(lm, c.lmax_amp), 2)  # comm_cr_mod.f90:815
         return lm
 
@@ -304,14 +322,23 @@ class CRSystem:
         for k, c in enumerate(self.comps):  # :797-836
             if not c.active:
                 continue
-            if c.cltype != "none":
+            if isinstance(c, CompactBlock):                          # :817-833  pamp * P_cg(2)
+                pos, n, _ = self.ind_comp[k]
+                sqrtS_x[pos:pos + n] *= c.sigma
+            elif c.cltype != "none":
                 alm = self.extract(k, sqrtS_x)
                 self.insert(k, False, c.Cl.sqrtS(alm, c.info), sqrtS_x)
         lmax = self._lmax_all()
         for ib, b in enumerate(self.bands):  # :843
             map_alm = np.zeros((b.info.nalm, b.nmaps))
+            pmap = np.zeros(b.npix * b.nmaps)                        # compact objects, pixel space (:872-882)
             for k, c in enumerate(self.comps):
                 if not c.active:
+                    continue
+                if isinstance(c, CompactBlock):
+                    if ib in c.P:
+                        pos, n, _ = self.ind_comp[k]
+                        pmap += c.P[ib] @ sqrtS_x[pos:pos + n]
                     continue
                 alm = self.extract(k, sqrtS_x)
                 alm[c.info.l > b.lmax, :] = 0.0                      # :858-860
@@ -323,6 +350,7 @@ class CRSystem:
                 mp = self._Y(b, buff, lmax)
             else:
                 mp = np.zeros((b.npix, b.nmaps))
+            mp = mp + pmap.reshape(b.nmaps, b.npix).T                # :897  add compact objects
             mp = b.invN(mp)                                          # :905
             if lmax > -1:
                 buff = self._Yt(b, mp, lmax)                         # :914-916
@@ -330,11 +358,20 @@ class CRSystem:
             for k, c in enumerate(self.comps):                       # :920-948
                 if not c.active:
                     continue
+                if isinstance(c, CompactBlock):                      # projectPtsrcBand / projectTemplateBand
+                    if ib in c.P:
+                        pos, n, _ = self.ind_comp[k]
+                        y[pos:pos + n] += c.P[ib].T @ mp.T.reshape(-1)
+                    continue
                 alm = self.projectBand_alm(c, ib, map_alm)
                 alm[c.info.l > b.lmax, :] = 0.0                      # :931-933
                 self.insert(k, True, alm, y)
         for k, c in enumerate(self.comps):                           # :957-1008
             if not c.active:
+                continue
+            if isinstance(c, CompactBlock):                          # :985-1003  sqrtS, then the unit prior term
+                pos, n, _ = self.ind_comp[k]
+                y[pos:pos + n] = y[pos:pos + n] * c.sigma + x[pos:pos + n]
                 continue
             if c.cltype != "none":
                 alm = self.extract(k, y)
@@ -364,6 +401,11 @@ class CRSystem:
             for k, c in enumerate(self.comps):
                 if not c.active:
                     continue
+                if isinstance(c, CompactBlock):                      # :661-680  Tp = projectBand(map) * sqrtS
+                    if ib in c.P:
+                        pos, n, _ = self.ind_comp[k]
+                        rhs[pos:pos + n] += c.sigma * (c.P[ib].T @ mp.T.reshape(-1))
+                    continue
                 if c.F_null[ib]:
                     Tm = np.zeros((c.info.nalm, c.nmaps))            # :631-632
                 else:
@@ -382,6 +424,12 @@ class CRSystem:
         for k, c in enumerate(self.comps):                           # :690-728
             if not c.active or c.cltype == "none":
                 continue
+            if isinstance(c, CompactBlock):                          # :730-764  eta + P(1)/P(2)
+                pos, n, _ = self.ind_comp[k]
+                if operation == "sample":
+                    rhs[pos:pos + n] += np.asarray(eta, dtype=np.float64)[pos:pos + n]
+                rhs[pos:pos + n] += c.mean / c.sigma
+                continue
             e = np.zeros((c.info.nalm, c.nmaps))
             if operation == "sample":
                 e = self.extract(k, np.asarray(eta, dtype=np.float64))
@@ -393,9 +441,34 @@ class CRSystem:
         return rhs
 
     # ------------------------------------------------------------------ diagonal preconditioner
+    def _diffuse(self):
+        return [c for c in self.comps if not isinstance(c, CompactBlock)]
+
+    def _compact_precond(self):
+        """Dense block of A on every compact block, inverted: delta + sigma (sum_b P_b^t N_b^-1 P_b) sigma.  (The
+        reference's initPtsrcPrecond / initTemplatePrecond build approximations of this block -- and the template one
+        multiplies maps of different bands, comm_template_comp_mod.f90:356-372; the exact block is used here: a
+        preconditioner changes the iterates, not the solution.)"""
+        out = {}
+        for k, c in enumerate(self.comps):
+            if not isinstance(c, CompactBlock):
+                continue
+            M = np.eye(c.nparam)
+            if c.active:
+                for ib, P in c.P.items():
+                    b = self.bands[ib]
+                    w = (b.siN ** 2 * (b.sg_mask if b.sg_mask is not None else 1.0)).T.reshape(-1)
+                    Pd = P.toarray()
+                    M += c.sigma[:, None] * (Pd.T @ (w[:, None] * Pd)) * c.sigma[None, :]
+            out[k] = np.linalg.inv(M)
+        return out
+
     def init_precond_diag(self):
         """initDiffPrecond_diagonal: comm_diffuse_comp_mod.f90:1167-1252."""
-        comps = self.comps
+        self._compact_inv = self._compact_precond()
+        self._all_comps = self.comps
+        comps = [c for c in self.comps if not isinstance(c, CompactBlock)]
+        self._diff_index = [k for k, c in enumerate(self.comps) if not isinstance(c, CompactBlock)]
         npre = len(comps)
         lmax_pre = max(c.lmax_amp for c in comps)                    # :212
         nmaps_pre = max(c.nmaps for c in comps)                      # :214
@@ -431,7 +504,7 @@ class CRSystem:
         # comp2ind: only components with mat(k,k) > 0 take part (:1232-1239)
         present = np.stack([M0[:, :, k, k] > 0.0 for k in range(npre)], axis=2)  # (nalm, nmaps, npre)
         M = M0.copy()
-        for k1, c in enumerate(self.comps):                          # right- and left-multiply with sqrt(S), diag form
+        for k1, c in enumerate(self._diffuse()):                          # right- and left-multiply with sqrt(S), diag form
             if c.cltype == "none":
                 continue
             lc = np.minimum(info_pre.l, c.Cl.lmax)
@@ -443,12 +516,12 @@ class CRSystem:
             M[:, :, k1, :] *= d[:, :, None]
         if self.only_pol:
             M[:, 0, :, :] = 0.0                                      # :1428-1433
-        for k1, c in enumerate(self.comps):                          # add unity :1452-1470
+        for k1, c in enumerate(self._diffuse()):                          # add unity :1452-1470
             if c.cltype == "none":
                 continue
             sel = (info_pre.l <= c.lmax_amp)[:, None] & present[:, :, k1]
             M[:, :, k1, k1] += np.where(sel, 1.0, 0.0)
-        for k1, c in enumerate(self.comps):                          # :1484-1495
+        for k1, c in enumerate(self._diffuse()):                          # :1484-1495
             if c.active:
                 continue
             M[:, :, k1, :] = 0.0
@@ -569,9 +642,10 @@ class CRSystem:
         if P.get("type") == "pseudoinv":
             return self._invM_pseudoinv(x)
         info_pre, nmaps_pre, npre = P["info"], P["nmaps"], P["npre"]
+        gidx = [k for k, c in enumerate(self.comps) if not isinstance(c, CompactBlock)]   # diffuse -> global index
         yv = np.zeros((npre, info_pre.nalm, nmaps_pre))
-        for k, c in enumerate(self.comps):
-            alm = self.extract(k, x)
+        for k, c in enumerate(self._diffuse()):
+            alm = self.extract(gidx[k], x)
             kidx = info_pre.lm2i_vec(c.info.l, c.info.m)
             yv[k][kidx, : c.nmaps] = alm
         out = yv.copy()
@@ -582,9 +656,12 @@ class CRSystem:
         for k in range(npre):
             out[k] = np.where(present[:, :, k] & anyp, mv[k], yv[k])
         res = np.zeros(self.ncr)
-        for k, c in enumerate(self.comps):
+        for k, c in enumerate(self._diffuse()):
             kidx = info_pre.lm2i_vec(c.info.l, c.info.m)
-            self.insert(k, False, out[k][kidx, : c.nmaps], res)
+            self.insert(gidx[k], False, out[k][kidx, : c.nmaps], res)
+        for k, Minv in getattr(self, "_compact_inv", {}).items():    # applyPtsrcPrecond / applyTemplatePrecond
+            pos, n, _ = self.ind_comp[k]
+            res[pos:pos + n] = Minv @ np.asarray(x)[pos:pos + n]
         return res
 
     # ------------------------------------------------------------------ solve_cr_eqn_by_CG
@@ -596,7 +673,11 @@ class CRSystem:
         else:                                                        # :136-173
             x = np.asarray(x0, dtype=np.float64).copy()
             for k, c in enumerate(self.comps):
-                if c.active and c.cltype != "none":
+                if isinstance(c, CompactBlock):
+                    if c.active:
+                        pos, n, _ = self.ind_comp[k]
+                        x[pos:pos + n] /= c.sigma                      # :160-170
+                elif c.active and c.cltype != "none":
                     self.insert(k, False, c.Cl.sqrtInvS(self.extract(k, x), c.info), x)
         r = b - self.matmulA(x)                                      # :201
         d = self.invM(r)                                             # :203
@@ -626,7 +707,11 @@ class CRSystem:
             niter = i
             i += 1
         for k, c in enumerate(self.comps):                           # :350-389
-            if c.active and c.cltype != "none":
+            if isinstance(c, CompactBlock):
+                if c.active:
+                    pos, n, _ = self.ind_comp[k]
+                    x[pos:pos + n] *= c.sigma
+            elif c.active and c.cltype != "none":
                 self.insert(k, False, c.Cl.sqrtS(self.extract(k, x), c.info), x)
         if i >= maxiter and conv_crit != "fixed_iter":               # :392-395 (Fortran: i == maxiter+1 after a full loop)
             stat = 1

@@ -18,6 +18,9 @@ def oracle_system(spec, only_pol=False):
              for b in spec["bands"]]
     comps = []
     for c in spec["comps"]:
+        if c.get("kind") == "compact":
+            comps.append(cro.CompactBlock(c["nparam"], c["sigma"], c["mean"], c["P"], active=c.get("active", True)))
+            continue
         if c.get("sqrtS_mat") is None:
             cl = cro.Cl(c["lmax"], c["nmaps"], np.zeros((c["lmax"] + 1, c["nmaps"] * (c["nmaps"] + 1) // 2)), cltype="none")
         else:

@@ -325,6 +325,35 @@ void launch_axpby(const double* a, const double* b, double cb, double* out, int6
     for (int64_t i = 0; i < n; ++i) out[i] = a[i] + cb * b[i];
 }
 
+void launch_compact_fwd(double* z, const CellBase& B, const int64_t* rows, const int64_t* ptr, const int* col,
+                        const double* val, const double* a, int64_t nrows, hipStream_t) {
+    for (int64_t r = 0; r < nrows; ++r) compact_fwd_row(z, B, rows, ptr, col, val, a, r);
+}
+void launch_compact_adj(const double* u, const CellBase& B, const int64_t* cptr, const int64_t* cell, const double* val,
+                        const double* scale, double* y, int nparam, bool accumulate, hipStream_t) {
+    for (int p = 0; p < nparam; ++p) {
+        double acc = 0.0;
+        for (int64_t k = cptr[p]; k < cptr[p + 1]; ++k) acc += compact_adj_term(u, B, cell, val, k);
+        const double v = acc * (scale ? scale[p] : 1.0);
+        y[p] = accumulate ? y[p] + v : v;
+    }
+}
+void launch_dense_mv(const double* M, const double* x, double* y, int n, hipStream_t) {
+    for (int i = 0; i < n; ++i) {
+        double acc = 0.0;
+        for (int j = 0; j < n; ++j) acc += M[(int64_t)i * n + j] * x[j];
+        y[i] = acc;
+    }
+}
+void launch_vec_scale(int mode, const double* a, const double* sc, const double* b, const double* c, double* out, int n,
+                      hipStream_t) {
+    for (int i = 0; i < n; ++i) {
+        double v = mode == 1 ? a[i] / sc[i] : a[i] * sc[i];
+        if (mode >= 2 && b) v += b[i];
+        if (mode == 3 && c) v += c[i] / sc[i];
+        out[i] = v;
+    }
+}
 void launch_alm_chain(double* alm, int64_t alm_stride, float* c32, int lmax, int nmaps, bool to_chain, hipStream_t) {
     const int64_t na = (int64_t)(lmax + 1) * (lmax + 1);
     for (int k = 0; k < nmaps; ++k)

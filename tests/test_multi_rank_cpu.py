@@ -19,6 +19,8 @@ def _spec(nside, lmax, pix, mode):
         if pix is not None:
             z = z[pix]
         spec["comps"][1]["F_map"] = {ib: (b["nu"] / 30.0) ** (-3.1 + 0.1 * z) for ib, b in enumerate(spec["bands"])}
+    if mode == "compact":   # templates + point sources (pixel-space components): local rows of the sparse matrices
+        synth.add_compact_blocks(spec, nsrc=4)
     return spec
 
 
@@ -61,7 +63,7 @@ def _worker(rank, world, port, out_dir, mode):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("mode", ["const", "varying", "stream"])
+@pytest.mark.parametrize("mode", ["const", "varying", "stream", "compact"])
 def test_two_rank_ring_sharding_matches_single_rank(tmp_path, mode):
     import torch.multiprocessing as mp
     from helpers import emul_lib, rel
