@@ -280,25 +280,38 @@ void launch_compact_fwd(double* z, const CellBase& B, const int64_t* rows, const
     hipLaunchKernelGGL(k_compact_fwd, dim3((unsigned)((nrows + 255) / 256)), dim3(256), 0, s, z, B, rows, ptr, col, val, a,
                        nrows);
 }
-// one workgroup per parameter; fixed-order block reduction (deterministic)
+// kCadjSlices workgroups per parameter, each over a contiguous slice of the column (dense template columns have
+// 10^7 entries), then one pass that adds the slice sums in a fixed order (deterministic)
+constexpr int kCadjSlices = 64;
 __global__ void __launch_bounds__(256) k_compact_adj(const double* __restrict__ u, CellBase B,
                                                      const int64_t* __restrict__ cptr, const int64_t* __restrict__ cell,
-                                                     const double* __restrict__ val, const double* __restrict__ scale,
-                                                     double* __restrict__ y, int accumulate) {
-    const int p = blockIdx.x;
+                                                     const double* __restrict__ val, double* __restrict__ partial) {
+    const int p = blockIdx.x, sl = blockIdx.y;
+    const int64_t k0 = cptr[p], len = cptr[p + 1] - k0;
+    const int64_t chunk = (len + kCadjSlices - 1) / kCadjSlices;
+    const int64_t lo = k0 + sl * chunk, hi = min(k0 + len, lo + chunk);
     double acc = 0.0;
-    for (int64_t k = cptr[p] + threadIdx.x; k < cptr[p + 1]; k += 256) acc += compact_adj_term(u, B, cell, val, k);
+    for (int64_t k = lo + threadIdx.x; k < hi; k += 256) acc += compact_adj_term(u, B, cell, val, k);
     const double r = block_sum_256(acc);
-    if (threadIdx.x == 0) {
-        const double v = r * (scale ? scale[p] : 1.0);
-        y[p] = accumulate ? y[p] + v : v;
-    }
+    if (threadIdx.x == 0) partial[(int64_t)p * kCadjSlices + sl] = r;
+}
+__global__ void k_compact_adj_final(const double* __restrict__ partial, const double* __restrict__ scale,
+                                    double* __restrict__ y, int nparam, int accumulate) {
+    const int p = blockIdx.x * 256 + threadIdx.x;
+    if (p >= nparam) return;
+    double r = 0.0;
+    for (int sl = 0; sl < kCadjSlices; ++sl) r += partial[(int64_t)p * kCadjSlices + sl];
+    const double v = r * (scale ? scale[p] : 1.0);
+    y[p] = accumulate ? y[p] + v : v;
 }
 void launch_compact_adj(const double* u, const CellBase& B, const int64_t* cptr, const int64_t* cell, const double* val,
-                        const double* scale, double* y, int nparam, bool accumulate, hipStream_t s) {
+                        const double* scale, double* y, int nparam, bool accumulate, double* scratch, hipStream_t s) {
     if (nparam == 0) return;
-    hipLaunchKernelGGL(k_compact_adj, dim3(nparam), dim3(256), 0, s, u, B, cptr, cell, val, scale, y, accumulate ? 1 : 0);
+    hipLaunchKernelGGL(k_compact_adj, dim3(nparam, kCadjSlices), dim3(256), 0, s, u, B, cptr, cell, val, scratch);
+    hipLaunchKernelGGL(k_compact_adj_final, dim3((nparam + 255) / 256), dim3(256), 0, s, scratch, scale, y, nparam,
+                       accumulate ? 1 : 0);
 }
+int compact_adj_scratch(int nparam) { return nparam * kCadjSlices; }
 __global__ void __launch_bounds__(256) k_dense_mv(const double* __restrict__ M, const double* __restrict__ x,
                                                   double* __restrict__ y, int n) {
     const int i = blockIdx.x;

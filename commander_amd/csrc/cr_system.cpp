@@ -220,6 +220,7 @@ void CrSystem::finalize() {
         else { compacts_[o.second].pos = pos; pos += compacts_[o.second].nparam; }
     }
     for (Compact& K : compacts_) {
+        compact_scratch_.ensure((size_t)compact_adj_scratch(K.nparam));
         K.sigma_dev.upload(K.sigma);
         K.mean_dev.upload(K.mean);
         for (CompactBand& B : K.P) {   // COO -> CSR over the touched cells (sorted) and CSC by parameter
@@ -532,7 +533,7 @@ void CrSystem::compact_adjoint(Group& G, const double* maps, double* yc) {   // 
         for (CompactBand& B : K.P) {
             if (&groups_[bands_[B.band].group] != &G) continue;
             launch_compact_adj(maps, cell_base(B.band), B.cptr.get(), B.ccell.get(), B.cval.get(), nullptr, yc + K.pos,
-                               K.nparam, true, stream_);
+                               K.nparam, true, compact_scratch_.get(), stream_);
         }
     }
 }
@@ -564,7 +565,7 @@ void CrSystem::compact_precond_init() {
                         launch_pix(0, bands_[B.band].mul.get() + (int64_t)st * np, G.tmpmap.get() + cb.off[st], nullptr,
                                    G.tmpmap.get() + cb.off[st], np, stream_);
                     launch_compact_adj(G.tmpmap.get(), cb, B.cptr.get(), B.ccell.get(), B.cval.get(), nullptr, col.get(), n,
-                                       true, stream_);
+                                       true, compact_scratch_.get(), stream_);
                 }
                 sync();
                 CMDR_HIP_CHECK(hipMemcpy(hc.data(), col.get(), sizeof(double) * n, hipMemcpyDeviceToHost));

@@ -192,6 +192,7 @@ class CrSystem {
     std::vector<Band> bands_;
     std::vector<Comp> comps_;
     std::vector<Compact> compacts_;
+    DevBuf<double> compact_scratch_;           // slice sums of k_compact_adj
     std::vector<std::pair<int, int>> order_;   // stacked-vector order: (0, diffuse index) | (1, compact index)
     std::vector<Group> groups_;
     std::vector<std::pair<int, std::vector<int>>> ring_sets_;

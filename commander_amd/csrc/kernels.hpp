@@ -76,7 +76,8 @@ void launch_axpby(const double* a, const double* b, double cb, double* out, int6
 void launch_compact_fwd(double* z, const CellBase& B, const int64_t* rows, const int64_t* ptr, const int* col,
                         const double* val, const double* a, int64_t nrows, hipStream_t s);
 void launch_compact_adj(const double* u, const CellBase& B, const int64_t* cptr, const int64_t* cell, const double* val,
-                        const double* scale, double* y, int nparam, bool accumulate, hipStream_t s);
+                        const double* scale, double* y, int nparam, bool accumulate, double* scratch, hipStream_t s);
+int compact_adj_scratch(int nparam);   // doubles of scratch launch_compact_adj needs
 void launch_dense_mv(const double* M, const double* x, double* y, int n, hipStream_t s);
 // mode 0: out = a * s ; 1: out = a / s ; 2: out = a * s + b ; 3: out = a * s + b + c / s  (b, c nullable -> 0)
 void launch_vec_scale(int mode, const double* a, const double* sc, const double* b, const double* c, double* out, int n,

@@ -330,7 +330,7 @@ void launch_compact_fwd(double* z, const CellBase& B, const int64_t* rows, const
     for (int64_t r = 0; r < nrows; ++r) compact_fwd_row(z, B, rows, ptr, col, val, a, r);
 }
 void launch_compact_adj(const double* u, const CellBase& B, const int64_t* cptr, const int64_t* cell, const double* val,
-                        const double* scale, double* y, int nparam, bool accumulate, hipStream_t) {
+                        const double* scale, double* y, int nparam, bool accumulate, double*, hipStream_t) {
     for (int p = 0; p < nparam; ++p) {
         double acc = 0.0;
         for (int64_t k = cptr[p]; k < cptr[p + 1]; ++k) acc += compact_adj_term(u, B, cell, val, k);
@@ -338,6 +338,7 @@ void launch_compact_adj(const double* u, const CellBase& B, const int64_t* cptr,
         y[p] = accumulate ? y[p] + v : v;
     }
 }
+int compact_adj_scratch(int nparam) { return nparam; }
 void launch_dense_mv(const double* M, const double* x, double* y, int n, hipStream_t) {
     for (int i = 0; i < n; ++i) {
         double acc = 0.0;
