@@ -146,7 +146,7 @@ def ncr_of(spec):
     return sum(c["nparam"] if c.get("kind") == "compact" else (c["lmax"] + 1) ** 2 * c["nmaps"] for c in spec["comps"])
 
 
-def add_compact_blocks(spec, nsrc=5, seed=77):
+def add_compact_blocks(spec, nsrc=5, seed=77, template_bands=None):
     """Append synthetic compact components to a problem spec: a monopole + dipole template block
     on every band (comm_md_comp-like: 4 amplitudes per band, dense columns) inserted after the first diffuse component,
     and ``nsrc`` point sources (sparse beam-sized footprints on every band, flat spectrum) at the end."""
@@ -163,6 +163,8 @@ def add_compact_blocks(spec, nsrc=5, seed=77):
     np_loc = pix.size
     blocks = []
     for ib, b in enumerate(spec["bands"]):
+        if template_bands is not None and ib not in template_bands:
+            continue
         nm = b["siN"].shape[1] if np.ndim(b["siN"]) > 1 else 1
         T = np.zeros((np_loc * nm, 4))
         T[:np_loc, :] = vec                          # temperature-only templates (Stokes 0 cells)

@@ -247,13 +247,14 @@ def test_compact_components_gpu(pol):
 
 
 def test_compact_components_cfg3_size():
-    """The same at the benchmark geometry (9 bands, Nside 1024, lmax 2000): 36 template amplitudes + 50 sources; the
-    operator stays symmetric and >= 1, and a short PCG reduces the preconditioned residual."""
+    """The same at the benchmark geometry (9 bands, Nside 1024, lmax 2000): monopole + dipole templates on three of the
+    bands (12 amplitudes) + 50 sources on all; the operator stays symmetric and >= 1, and a short PCG reduces the
+    preconditioned residual."""
     from commander_amd import synth
     from commander_amd.cr import build_context
-    spec = synth.add_compact_blocks(synth.make_problem("cfg3"), nsrc=50)
+    spec = synth.add_compact_blocks(synth.make_problem("cfg3"), nsrc=50, template_bands=(0, 4, 8))
     ctx = build_context(spec)
-    assert ctx.ncr == synth.ncr_of(spec) == 2001 ** 2 + 36 + 50
+    assert ctx.ncr == synth.ncr_of(spec) == 2001 ** 2 + 12 + 50
     rng = np.random.default_rng(8)
     x, y = rng.standard_normal(ctx.ncr), rng.standard_normal(ctx.ncr)
     Ax, Ay = ctx.cr_matmulA(x), ctx.cr_matmulA(y)
