@@ -184,6 +184,12 @@ class CRContext:
         check(self.L.cmdr_get_alpha_nu(self._h, int(band), _p(out)), self.L)
         return out
 
+    def set_band_qucov(self, band, iN, siN_mat):
+        """comm_N_QUcov: dense inverse covariance and its symmetric square root on the stacked (Q; U) pixels."""
+        a = np.ascontiguousarray(iN, dtype=np.float64)
+        b = np.ascontiguousarray(siN_mat, dtype=np.float64)
+        check(self.L.cmdr_band_set_qucov(self._h, int(band), _p(a), _p(b)), self.L)
+
     def add_compact(self, nparam, sigma, mean, P, active=True):
         """Compact block (templates / point sources): P = {band: scipy.sparse or dense (ncell_b, nparam)} with
         cell = pix_local + npix_local * stokes.  Call in compList order relative to add_comp."""
@@ -304,8 +310,10 @@ def build_context(spec, device=0, rings_by_nside=None, _lib=None):
     if rings_by_nside:
         for ns, r in rings_by_nside.items():
             ctx.set_rings(ns, r)
-    for b in spec["bands"]:
+    for ib, b in enumerate(spec["bands"]):
         ctx.add_band(b["nside"], b["lmax"], b["siN"], b["b_l"], b.get("mb_eff", 1.0), b.get("sg_mask"), b.get("wring"))
+        if b.get("qucov_iN") is not None:
+            ctx.set_band_qucov(ib, b["qucov_iN"], b["qucov_siN"])
     kd = 0
     for c in spec["comps"]:      # compList order == stacked-vector order; entries with kind == "compact" are compact blocks
         if c.get("kind") == "compact":

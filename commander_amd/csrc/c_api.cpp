@@ -315,6 +315,12 @@ int cmdr_get_alpha_nu(cmdr_ctx* ctx, int band, double* out_host) {
         std::copy(a.begin(), a.end(), out_host);
     });
 }
+int cmdr_band_set_qucov(cmdr_ctx* ctx, int band, const double* iN, const double* siN_mat) {
+    return guarded([&] {
+        CMDR_REQUIRE(ctx, "ctx is NULL");
+        ctx->sys->set_band_qucov(band, iN, siN_mat);
+    });
+}
 int cmdr_compact_add(cmdr_ctx* ctx, int nparam, const double* sigma, const double* mean, int active) {
     int idx = -1;
     const int rc = guarded([&] {

@@ -174,6 +174,18 @@ int CrSystem::add_comp(int lmax_amp, int nmaps, int lmax_cl, const double* sqrtS
     return (int)comps_.size() - 1;
 }
 
+void CrSystem::set_band_qucov(int band, const double* iN, const double* siN_mat) {
+    CMDR_REQUIRE(!finalized_, "set_band_qucov after finalize");
+    CMDR_REQUIRE(band >= 0 && band < (int)bands_.size() && iN && siN_mat, "bad arguments");
+    Band& B = bands_[band];
+    CMDR_REQUIRE(B.nmaps == 3, "a QU-covariance band has nmaps = 3");
+    const int64_t np = band_npix(band);
+    CMDR_REQUIRE(np == 12 * (int64_t)B.nside * B.nside, "QU-covariance bands are not ring-sharded (every rank holds all pixels)");
+    const size_t n = (size_t)(2 * np) * (size_t)(2 * np);
+    B.qucov_iN.upload(iN, n);
+    B.qucov_siN.upload(siN_mat, n);
+}
+
 int CrSystem::add_compact(int nparam, const double* sigma, const double* mean, int active) {
     CMDR_REQUIRE(!finalized_, "add_compact after finalize");
     CMDR_REQUIRE(!bands_.empty(), "add bands first");
@@ -498,7 +510,18 @@ void CrSystem::mix_adjoint(Group& G, bool rhs) {
 }
 
 // ------------------------------------------------------------------------------------------------- compact components
+void CrSystem::qucov_invN(Group& G, int band, double* maps) {   // matmulInvN_1map, comm_N_QUcov_mod.f90:320-340
+    const CellBase cb = cell_base(band);
+    const int n = (int)(2 * cb.np);
+    qucov_tmp_.ensure((size_t)n);
+    CMDR_HIP_CHECK(hipMemsetAsync(maps + cb.off[0], 0, sizeof(double) * cb.np, stream_));
+    launch_dense_mv(bands_[band].qucov_iN.get(), maps + cb.off[1], qucov_tmp_.get(), n, stream_);   // Q, U maps are adjacent
+    CMDR_HIP_CHECK(hipMemcpyAsync(maps + cb.off[1], qucov_tmp_.get(), sizeof(double) * n, hipMemcpyDeviceToDevice, stream_));
+}
+
 bool CrSystem::group_has_compact(const Group& G) const {
+    for (int b : G.bands)
+        if (bands_[b].qucov_iN.size()) return true;
     for (const Compact& K : compacts_)
         if (K.active)
             for (const CompactBand& B : K.P)
@@ -681,9 +704,15 @@ void CrSystem::matmulA(const double* x, double* y) {
             span_begin(1);
             P.rings(0, G.tmpmap.get(), np, nullptr, false, G.nbm, stream_);
             compact_forward(G, sx_.get(), G.tmpmap.get());
-            for (int bm = 0; bm < G.nbm; ++bm)
-                launch_pix(0, bands_[G.bm_band[bm]].mul.get() + (int64_t)G.bm_stokes[bm] * np, G.tmpmap.get() + (int64_t)bm * np,
-                           nullptr, G.tmpmap.get() + (int64_t)bm * np, np, stream_);
+            for (int bm = 0; bm < G.nbm; ++bm) {
+                const Band& B = bands_[G.bm_band[bm]];
+                if (B.qucov_iN.size()) {
+                    if (G.bm_stokes[bm] == 0) qucov_invN(G, G.bm_band[bm], G.tmpmap.get());
+                    continue;
+                }
+                launch_pix(0, B.mul.get() + (int64_t)G.bm_stokes[bm] * np, G.tmpmap.get() + (int64_t)bm * np, nullptr,
+                           G.tmpmap.get() + (int64_t)bm * np, np, stream_);
+            }
             compact_adjoint(G, G.tmpmap.get(), yc_.get());
             P.rings(1, G.tmpmap.get(), np, nullptr, false, G.nbm, stream_);
             span_end();
@@ -741,6 +770,22 @@ void CrSystem::compute_rhs(bool sample, const double* const* resid, const double
             const Band& B = bands_[b];
             const double* dmap = resid[b] + (int64_t)j * np;
             double* out = G.tmpmap.get() + (int64_t)bm * np;
+            if (B.qucov_iN.size()) {   // dense noise: T = 0, (Q;U) through the matrices (comm_N_QUcov_mod.f90:320-385)
+                if (j != 0) continue;
+                const CellBase cb = cell_base(b);
+                const int n2 = (int)(2 * np);
+                CMDR_HIP_CHECK(hipMemsetAsync(G.tmpmap.get() + cb.off[0], 0, sizeof(double) * np, stream_));
+                if (sample) {
+                    qucov_tmp_.ensure((size_t)n2);
+                    qucov_tmp2_.ensure((size_t)n2);
+                    launch_dense_mv(B.qucov_siN.get(), resid[b] + np, qucov_tmp_.get(), n2, stream_);
+                    launch_axpby(qucov_tmp_.get(), xi[b] + np, 1.0, qucov_tmp2_.get(), n2, stream_);
+                    launch_dense_mv(B.qucov_siN.get(), qucov_tmp2_.get(), G.tmpmap.get() + cb.off[1], n2, stream_);
+                } else {
+                    launch_dense_mv(B.qucov_iN.get(), resid[b] + np, G.tmpmap.get() + cb.off[1], n2, stream_);
+                }
+                continue;
+            }
             if (sample)  // sqrtInvN, + xi, sqrtInvN  (comm_cr_mod.f90:600-609)
                 launch_pix(1, B.siN.get() + (int64_t)j * np, dmap, xi[b] + (int64_t)j * np, out, np, stream_);
             else         // invN (:611)

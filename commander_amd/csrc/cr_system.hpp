@@ -47,6 +47,9 @@ class CrSystem {
     // compList order relative to add_comp (that order is the stacked-vector order).  Then one sparse matrix per band:
     // COO triplets (cell = pix_local + npix_local * stokes, param, value) = what evalTemplateBand / evalPtsrcBand add
     // to the band's map per unit amplitude.
+    // comm_N_QUcov (comm_N_QUcov_mod.f90): dense inverse noise covariance and its symmetric square root on the stacked
+    // (Q; U) pixels of a T,Q,U band (temperature is zeroed); the band's siN then plays siN_diag (preconditioner only).
+    void set_band_qucov(int band, const double* iN, const double* siN_mat);
     int add_compact(int nparam, const double* sigma, const double* mean, int active);
     void set_compact_band(int block, int band, int64_t nnz, const int64_t* cell, const int* param, const double* val);
     void finalize();
@@ -108,6 +111,7 @@ class CrSystem {
         std::vector<double> Nmap_h;         // rms^2 (* mask), 0 where siN = 0: comm_N_rms%N (comm_N_rms_mod.f90:288-301)
         DevBuf<double> mulP;                // (W_ring 4pi/Npix)^2 * Nmap: WY . N . YtW of the pseudo-inverse precond
         std::vector<double> alpha_nu;       // [nmaps]
+        DevBuf<double> qucov_iN, qucov_siN; // (2 npix)^2 each, row-major (symmetric); empty: white noise
     };
     struct Comp {
         CompDev d;
@@ -162,7 +166,9 @@ class CrSystem {
     void compact_forward(Group& G, const double* sx, double* maps);     // maps += P (sigma already applied: sx)
     void compact_adjoint(Group& G, const double* maps, double* yc);      // yc[block] += P^t maps
     void compact_precond_init();
-    bool group_has_compact(const Group& G) const;
+    bool group_has_compact(const Group& G) const;   // also true for dense-noise bands: the map has to exist
+    void qucov_invN(Group& G, int band, double* maps);   // maps(T) = 0, maps(Q;U) = iN maps(Q;U)
+    DevBuf<double> qucov_tmp_, qucov_tmp2_;
     void rebuild_weights();
     void rebuild_mixing();
     void mix_forward(Group& G, const double* sx);

@@ -66,6 +66,7 @@ def _sig(L):
     L.cmdr_precond_init_pseudoinv.argtypes = [c_vp]
     L.cmdr_precond_update_pseudoinv.argtypes = [c_vp]
     L.cmdr_get_alpha_nu.argtypes = [c_vp, c_int, dp]
+    L.cmdr_band_set_qucov.argtypes = [c_vp, c_int, dp, dp]
     L.cmdr_compact_add.argtypes = [c_vp, c_int, dp, dp, c_int]
     L.cmdr_compact_set_band.argtypes = [c_vp, c_int, c_int, c_i64, ctypes.POINTER(c_i64), ctypes.POINTER(c_int), dp]
     L.cmdr_comp_set_mixing_map.argtypes = [c_vp, c_int, c_int, dp, c_int]

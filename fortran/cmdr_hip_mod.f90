@@ -246,6 +246,15 @@ module cmdr_hip_mod
        integer(c_int)                 :: ierr
      end function cmdr_compact_set_band
 
+     ! comm_N_QUcov band: dense inverse covariance and its symmetric square root on the stacked (Q;U) pixels
+     function cmdr_band_set_qucov(ctx, band, iN, siN_mat) bind(c, name='cmdr_band_set_qucov') result(ierr)
+       import :: c_int, c_ptr, c_double
+       type(c_ptr),    value      :: ctx
+       integer(c_int), value      :: band
+       real(c_double), intent(in) :: iN(*), siN_mat(*)
+       integer(c_int)             :: ierr
+     end function cmdr_band_set_qucov
+
   end interface
 
 contains

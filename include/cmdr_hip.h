@@ -116,6 +116,11 @@ int cmdr_band_add(cmdr_ctx* ctx, int nside, int lmax, int nmaps, const double* s
 int cmdr_comp_add(cmdr_ctx* ctx, int lmax_amp, int nmaps, int lmax_cl, const double* sqrtS_mat,
                   const double* sqrtInvS_mat, const double* S_mat, const double* F_mean, int active);
 int cmdr_finalize(cmdr_ctx* ctx);
+/* Dense QU noise covariance of a T,Q,U band (comm_N_QUcov: low-resolution WMAP-type polarisation bands): iN and its
+ * symmetric square root siN_mat, (2 npix)^2 doubles each on the stacked (Q; U) pixels; N^-1 and N^-1/2 then zero the
+ * temperature and multiply (Q; U) by the matrices (comm_N_QUcov_mod.f90:320-385).  The siN passed to cmdr_band_add
+ * plays siN_diag (:256-272) and only feeds the preconditioner.  Before cmdr_finalize; such bands are not ring-sharded. */
+int cmdr_band_set_qucov(cmdr_ctx* ctx, int band, const double* iN, const double* siN_mat);
 /* Compact components in the solve (templates: comm_template_comp_mod.f90:210-270; point sources:
  * comm_ptsrc_comp_mod.f90:336-428): a block of nparam scalar amplitudes with Gaussian prior (mean, sigma) = P_cg / P_x,
  * i.e. S^1/2 = sigma (comm_cr_mod.f90:817-833).  Call cmdr_compact_add in compList order relative to cmdr_comp_add:

@@ -48,13 +48,28 @@ class Band:
         self.info = healpix.AlmInfo(lmax)
         self.invN_diag = None
 
+    def set_qucov(self, iN, siN_mat):
+        """comm_N_QUcov (comm_N_QUcov_mod.f90:236-290): dense inverse covariance iN and its symmetric square root on the
+        stacked (Q; U) pixels; temperature is zeroed.  ``self.siN`` then plays siN_diag (preconditioner only)."""
+        assert self.nmaps == 3
+        self.qucov_iN = np.asarray(iN, dtype=np.float64).reshape(2 * self.npix, 2 * self.npix)
+        self.qucov_siN = np.asarray(siN_mat, dtype=np.float64).reshape(2 * self.npix, 2 * self.npix)
+
+    def _dense(self, M, m):                   # matmulInvN_1map / matmulSqrtInvN_1map (:320-385)
+        v = M @ np.concatenate([m[:, 1], m[:, 2]])
+        return np.stack([np.zeros(self.npix), v[: self.npix], v[self.npix:]], axis=1)
+
     # comm_N_rms_mod.f90:264-273
     def invN(self, m):
+        if getattr(self, "qucov_iN", None) is not None:
+            return self._dense(self.qucov_iN, m)
         out = self.siN ** 2 * m
         return out * self.sg_mask if self.sg_mask is not None else out
 
     # comm_N_rms_mod.f90:304-313
     def sqrtInvN(self, m):
+        if getattr(self, "qucov_iN", None) is not None:
+            return self._dense(self.qucov_siN, m)
         out = self.siN * m
         return out * self.sg_mask if self.sg_mask is not None else out
 

@@ -16,6 +16,9 @@ def oracle_system(spec, only_pol=False):
     from oracle import cr_oracle as cro
     bands = [cro.Band(b["nside"], b["lmax"], b["siN"], b["b_l"], b.get("mb_eff", 1.0), b.get("sg_mask"), b.get("wring"))
              for b in spec["bands"]]
+    for B, b in zip(bands, spec["bands"]):
+        if b.get("qucov_iN") is not None:
+            B.set_qucov(b["qucov_iN"], b["qucov_siN"])
     comps = []
     for c in spec["comps"]:
         if c.get("kind") == "compact":

@@ -263,3 +263,9 @@ def test_compact_components_cfg3_size():
     ctx.initPrecond(); ctx.update_precond()
     _, niter, stat, r = ctx.solve_cr_eqn_by_CG(Ax, conv_crit="fixed_iter", maxiter=6)
     assert stat == 0 and niter == 6 and r[0] < 0.1 * r[1]
+
+
+def test_qucov_band_gpu():
+    """White-noise T,Q,U band at Nside 32 plus a dense-QU-covariance band at Nside 8 (comm_N_QUcov) against the oracle."""
+    import test_host_logic
+    test_host_logic._qucov_case(None, nside_hi=32, lmax_hi=64, nside_lo=8, lmax_lo=16)

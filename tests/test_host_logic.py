@@ -338,3 +338,56 @@ def _compact_case(EL_or_none, nside, lmax, pol=False, tol=1e-11):
 @pytest.mark.parametrize("pol", [False, True])
 def test_emul_compact_components_vs_oracle(EL, pol):
     _compact_case(EL, 8, 16, pol=pol)
+
+
+def _qucov_spec(nside_hi=8, lmax_hi=16, nside_lo=4, lmax_lo=8):
+    """A polarised white-noise band plus a low-resolution band with dense QU noise covariance (comm_N_QUcov: the
+    WMAP-type polarisation bands of a BeyondPlanck run); CMB + synchrotron, T,Q,U."""
+    from commander_amd import synth
+    spec = synth.make_problem("cfg2", nside=nside_hi, lmax=lmax_hi, pol=True)
+    spec["bands"] = spec["bands"][:2]
+    for c in spec["comps"]:
+        c["F_mean"] = c["F_mean"][:2, :]
+    lo = dict(spec["bands"][1])
+    npix = 12 * nside_lo * nside_lo
+    rng = np.random.default_rng(99)
+    A = rng.standard_normal((2 * npix, 2 * npix)) / np.sqrt(2 * npix)
+    cov = A @ A.T + 0.5 * np.eye(2 * npix)                       # N(Q;U), SPD, correlated
+    w, V = np.linalg.eigh(cov)
+    scale = 1.0 / (lo["sigma0"] ** 2)
+    iN = (V / w) @ V.T * scale
+    siN_mat = (V / np.sqrt(w)) @ V.T * np.sqrt(scale)
+    d = np.diag(cov) / scale
+    siN = np.stack([np.zeros(npix), 1.0 / np.sqrt(d[:npix]), 1.0 / np.sqrt(d[npix:])], axis=1)   # siN_diag, T = 0
+    lo.update(nside=nside_lo, lmax=lmax_lo, siN=siN, b_l=lo["b_l"][: lmax_lo + 1], qucov_iN=iN, qucov_siN=siN_mat)
+    spec["bands"][1] = lo
+    return spec
+
+
+def _qucov_case(lib, tol=1e-11, **kw):
+    from commander_amd import synth
+    from commander_amd.cr import build_context
+    spec = _qucov_spec(**kw)
+    S = oracle_system(spec)
+    ctx = build_context(spec, _lib=lib)
+    rng = np.random.default_rng(41)
+    x = rng.standard_normal(ctx.ncr)
+    assert rel(ctx.cr_matmulA(x), S.matmulA(x)) < tol
+    resid, xi = [], []
+    for b in spec["bands"]:
+        npix = 12 * b["nside"] ** 2
+        resid.append(rng.standard_normal((npix, 3)))
+        xi.append(rng.standard_normal((npix, 3)))
+    eta = rng.standard_normal(ctx.ncr)
+    bo = S.computeRHS(resid, "sample", xi, eta)
+    assert rel(ctx.cr_computeRHS("sample", resid, xi, eta), bo) < tol
+    assert rel(ctx.cr_computeRHS("mean", resid), S.computeRHS(resid, "mean")) < tol
+    ctx.initPrecond(); ctx.update_precond(); S.init_precond_diag(); S.update_precond_diag()
+    assert rel(ctx.cr_invM(x), S.invM(x)) < 1e-10
+    xg, ng, sg, _ = ctx.solve_cr_eqn_by_CG(bo, "fixed_iter", maxiter=6)
+    xo, no, so = S.solve(bo, "fixed_iter", maxiter=6)
+    assert rel(xg, xo) < 1e-8
+
+
+def test_emul_qucov_band_vs_oracle(EL):
+    _qucov_case(EL)
