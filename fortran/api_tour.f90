@@ -1,0 +1,123 @@
+!================================================================================
+! api_tour -- calls, from Fortran through ISO_C_BINDING, the parts of the C ABI that mini_commander does not touch:
+! two bands, two diffuse components (one with a spatially varying mixing matrix), a template block and a point-source
+! block (compact components), the error path (a preconditioner type that rejects compact components), getSigmaL and
+! the chain-file a_lm order.  Tiny sizes (Nside 8, lmax 16); every check is a size-independent property.
+! Build: make -C fortran     Run: ./fortran/api_tour   (needs a GPU)
+!================================================================================
+program api_tour
+  use iso_c_binding
+  use cmdr_hip_mod
+  implicit none
+  integer(c_int), parameter :: nside = 8, lmax = 16, nmaps = 1, nband = 2
+  integer, parameter        :: npix = 12*nside*nside, nalm = (lmax+1)**2
+  real(c_double), parameter :: pi = 3.141592653589793238462643383279502884d0
+  type(c_ptr)    :: ctx
+  integer(c_int) :: ierr, ib, ic, blk, niter, stat
+  integer(c_int64_t) :: ncr
+  real(c_double), allocatable, target :: siN(:), b_l(:), sqrtS(:), sqrtInvS(:), S(:), F(:), Fmap(:), z(:)
+  real(c_double), allocatable, target :: x(:), y(:), ax(:), ay(:), sol(:), sig(:)
+  real(c_float),  allocatable         :: chain(:)
+  real(c_double), allocatable         :: back(:)
+  integer(c_int64_t), allocatable     :: cell(:)
+  integer(c_int),     allocatable     :: par(:)
+  real(c_double),     allocatable     :: val(:)
+  real(c_double) :: res(2), sgm(2), mean(2), lhs, rhs
+  integer :: l, i, n
+  integer(8) :: seed
+
+  if (cmdr_device_count() < 1) then
+     write(*,*) 'api_tour: no GPU visible (libcmdr_hip has no CPU path)'
+     stop 2
+  end if
+  allocate(siN(npix), z(npix), b_l(0:lmax), sqrtS(0:lmax), sqrtInvS(0:lmax), S(0:lmax), F(nband), Fmap(npix))
+  do i = 1, npix
+     z(i) = 1.d0 - 2.d0*(i-0.5d0)/npix
+     siN(i) = 1.d0 / (3.d0*(1.d0 + 0.5d0*z(i)))
+  end do
+  do l = 0, lmax
+     b_l(l) = exp(-0.5d0*l*(l+1.d0)*(0.05d0)**2)
+     S(l) = 100.d0 / max(l*(l+1.d0), 1.d0); sqrtS(l) = sqrt(S(l)); sqrtInvS(l) = 1.d0/sqrtS(l)
+  end do
+
+  call cmdr_check(cmdr_ctx_create(0_c_int, ctx), 'cmdr_ctx_create')
+  do ib = 1, nband
+     call cmdr_check(cmdr_band_add(ctx, nside, lmax, nmaps, siN, b_l, 1.d0, c_null_ptr, c_null_ptr), 'cmdr_band_add')
+  end do
+  F = 1.d0                                                           ! component 0: CMB-like, constant mixing
+  call cmdr_check(cmdr_comp_add(ctx, lmax, nmaps, lmax, c_loc(sqrtS), c_loc(sqrtInvS), c_loc(S), F, 1_c_int), 'comp 0')
+  ! compact block between the two diffuse components (compList order = stacked-vector order): 2 templates on band 0
+  sgm = [20.d0, 5.d0]; mean = [1.d0, -1.d0]
+  blk = cmdr_compact_add(ctx, 2_c_int, sgm, mean, 1_c_int)
+  call cmdr_check(blk, 'cmdr_compact_add')
+  n = 2*npix
+  allocate(cell(n), par(n), val(n))
+  do i = 1, npix
+     cell(i) = i-1;        par(i) = 0;        val(i) = 1.d0           ! monopole
+     cell(npix+i) = i-1;   par(npix+i) = 1;   val(npix+i) = z(i)      ! dipole-z
+  end do
+  call cmdr_check(cmdr_compact_set_band(ctx, blk, 0_c_int, int(n, c_int64_t), cell, par, val), 'compact band 0')
+  F = [1.d0, 0.3d0]                                                  ! component 1: varying mixing on both bands
+  ic = cmdr_comp_add(ctx, lmax, nmaps, lmax, c_loc(sqrtS), c_loc(sqrtInvS), c_loc(S), F, 1_c_int)
+  call cmdr_check(ic, 'comp 1')
+  do ib = 1, nband
+     Fmap = F(ib) * (1.d0 + 0.1d0*z)
+     call cmdr_check(cmdr_comp_set_mixing_map(ctx, ic, int(ib-1, c_int), c_loc(Fmap), nmaps), 'mixing map')
+  end do
+  ! one point source seen by both bands: a 5-pixel footprint
+  blk = cmdr_compact_add(ctx, 1_c_int, [3.d0], [0.d0], 1_c_int)
+  do ib = 1, nband
+     call cmdr_check(cmdr_compact_set_band(ctx, blk, int(ib-1, c_int), 5_c_int64_t, &
+          & int([100, 101, 102, 131, 132], c_int64_t), int([0, 0, 0, 0, 0], c_int), &
+          & [0.2d0, 1.d0, 0.2d0, 0.5d0, 0.5d0]*ib), 'source footprint')
+  end do
+  call cmdr_check(cmdr_finalize(ctx), 'cmdr_finalize')
+  ncr = cmdr_ncr(ctx)
+  if (ncr /= 2*nalm + 3) stop 'api_tour: ncr mismatch'
+
+  ! A is symmetric (unit ring weights) and >= 1
+  allocate(x(ncr), y(ncr), ax(ncr), ay(ncr), sol(ncr))
+  seed = 4242_8
+  do i = 1, int(ncr)
+     x(i) = uni(seed) - 0.5d0; y(i) = uni(seed) - 0.5d0
+  end do
+  call cmdr_check(cmdr_matmulA(ctx, x, ax), 'cr_matmulA x')
+  call cmdr_check(cmdr_matmulA(ctx, y, ay), 'cr_matmulA y')
+  lhs = sum(y*ax); rhs = sum(x*ay)
+  if (abs(lhs-rhs) > 1.d-10*sqrt(sum(y*y)*sum(ax*ax))) stop 'api_tour: A not symmetric'
+  if (sum(x*ax) < sum(x*x)*(1.d0-1.d-12)) stop 'api_tour: A < 1'
+
+  ! diagonal preconditioner + compact dense blocks; solve A sol = A x  =>  S^1/2-scaled x comes back after enough iterations
+  call cmdr_check(cmdr_precond_init_diag(ctx), 'initPrecond')
+  call cmdr_check(cmdr_precond_update_diag(ctx), 'update_precond')
+  call cmdr_check(cmdr_solve(ctx, ax, sol, CMDR_CRIT_RESIDUAL, 1.d-12, 5_c_int, 400_c_int, 1_c_int, c_null_ptr, &
+       & niter, res, stat), 'solve_cr_eqn_by_CG')
+  if (stat /= 0) stop 'api_tour: CG did not converge'
+  write(*,'(a,i4,a,es10.3)') ' converged in ', niter, ' iterations, delta/delta0 = ', res(1)/res(2)
+
+  ! error path: the pseudo-inverse preconditioner rejects compact components; the message comes through cmdr_last_error
+  ierr = cmdr_precond_init_pseudoinv(ctx)
+  if (ierr >= 0) stop 'api_tour: expected an error'
+
+  ! getSigmaL and the chain-file order
+  allocate(sig(0:lmax), chain(nalm), back(nalm))
+  call cmdr_check(cmdr_sigma_l(sol(1:nalm), lmax, nmaps, sig), 'getSigmaL')
+  if (any(sig < 0.d0)) stop 'api_tour: sigma_l < 0'
+  call cmdr_check(cmdr_alm_to_chain_order(sol(1:nalm), lmax, nmaps, chain), 'chain order')
+  call cmdr_check(cmdr_alm_from_chain_order(chain, lmax, nmaps, back), 'chain order back')
+  if (maxval(abs(back - real(real(sol(1:nalm), c_float), c_double))) > 0.d0) stop 'api_tour: chain order round trip'
+  if (abs(chain(1) - real(sol(1), c_float)) > 0.0) stop 'api_tour: chain order l=0'      ! (l,m)=(0,0) is index 0 in both
+
+  call cmdr_check(cmdr_ctx_destroy(ctx), 'cmdr_ctx_destroy')
+  write(*,*) 'api_tour: OK'
+
+contains
+
+  function uni(s) result(u)
+    integer(8), intent(inout) :: s
+    real(c_double) :: u
+    s = mod(s*6364136223846793005_8 + 1442695040888963407_8, 9223372036854775807_8)
+    u = (real(abs(s), c_double) + 1.d0) / 9223372036854775809.d0
+  end function uni
+
+end program api_tour

@@ -255,6 +255,15 @@ module cmdr_hip_mod
        integer(c_int)             :: ierr
      end function cmdr_band_set_qucov
 
+     ! comm_map%getSigmaL (comm_map_mod.f90:1302-1351): alm(nalm, nmaps) -> sigma_l(0:lmax, nspec)
+     function cmdr_sigma_l(alm, lmax, nmaps, sigma_l) bind(c, name='cmdr_sigma_l') result(ierr)
+       import :: c_int, c_double
+       real(c_double), intent(in)  :: alm(*)
+       integer(c_int), value       :: lmax, nmaps
+       real(c_double), intent(out) :: sigma_l(*)
+       integer(c_int)              :: ierr
+     end function cmdr_sigma_l
+
   end interface
 
 contains
