@@ -424,10 +424,182 @@ __global__ void __launch_bounds__(256) k_leg2_adj(Leg2Args A, const WaveTask* __
     }
 }
 
+// ---- two polarisation pairs per wave: the two spin-weighted recursions (and W, X) are shared, only the 16 accumulate
+// FMAs per l-pair are per polarisation pair (28 -> 22 instructions per ring pair, l-pair and polarisation pair)
+template <int R>
+__global__ void __launch_bounds__(256) k_leg2_synth_np2(Leg2Args A, const WaveTask* __restrict__ tasks, int ntasks,
+                                                        const double* __restrict__ st, int npol, int ip0,
+                                                        double* __restrict__ ph, int64_t ph_stride, int kq) {
+    const int wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int t = blockIdx.x * 4 + wid;
+    if (t >= ntasks) return;
+    const WaveTask T = tasks[t];
+    if (T.chunk < 0) return;
+    const int m = __builtin_amdgcn_readfirstlane(T.m), chunk = __builtin_amdgcn_readfirstlane(T.chunk);
+    const int lw = __builtin_amdgcn_readfirstlane(T.lw), lAend = __builtin_amdgcn_readfirstlane(T.lAend);
+    const int lane = threadIdx.x & 63;
+    const int lmax = A.lmax;
+    const int64_t mo = d_moffp(lmax, m);
+    const double* __restrict__ al = A.alpha + (mo - m);
+    const double* __restrict__ be = A.beta + (mo - m);
+    const double* __restrict__ as = st + 4 * ((int64_t)npol * (mo - m) + ip0);
+    const int64_t ls4 = 4 * (int64_t)npol;
+    Leg2State<R> S;
+    leg2_load_state<R>(A, m, chunk, lane, S);
+    double ar[R][2][4], ai[R][2][4];
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+#pragma unroll
+        for (int p = 0; p < 2; ++p)
+#pragma unroll
+            for (int k = 0; k < 4; ++k) ar[r][p][k] = ai[r][p][k] = 0.0;
+        if (S.ls[r] == lw) { S.pc[r] = S.sd[r][0]; S.pp[r] = S.sd[r][1]; S.mc[r] = S.sd[r][2]; S.mp[r] = S.sd[r][3]; }
+    }
+    for (int l = lw; l <= lmax; l += 2) {
+        const double* __restrict__ c0 = as + ls4 * l;
+        const double* __restrict__ c1 = c0 + ls4;
+        const double al1 = al[l + 1], be1 = be[l + 1], al2 = al[l + 2], be2 = be[l + 2];
+        const bool inj = l < lAend;
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            double W = S.pc[r] + S.mc[r], X = S.pc[r] - S.mc[r];
+#pragma unroll
+            for (int p = 0; p < 2; ++p) {
+                const double e0r = c0[4 * p], e0i = c0[4 * p + 1], b0r = c0[4 * p + 2], b0i = c0[4 * p + 3];
+                ar[r][p][0] += e0r * W;  ai[r][p][0] += e0i * W;
+                ar[r][p][1] -= b0i * X;  ai[r][p][1] += b0r * X;
+                ar[r][p][2] += b0r * W;  ai[r][p][2] += b0i * W;
+                ar[r][p][3] += e0i * X;  ai[r][p][3] -= e0r * X;
+            }
+            if (inj) leg2_advance<R, true>(S, r, l, al1, be1); else leg2_advance<R, false>(S, r, l, al1, be1);
+            W = S.pc[r] + S.mc[r];
+            X = S.pc[r] - S.mc[r];
+#pragma unroll
+            for (int p = 0; p < 2; ++p) {
+                const double e1r = c1[4 * p], e1i = c1[4 * p + 1], b1r = c1[4 * p + 2], b1i = c1[4 * p + 3];
+                ar[r][p][1] += e1r * W;  ai[r][p][1] += e1i * W;
+                ar[r][p][0] -= b1i * X;  ai[r][p][0] += b1r * X;
+                ar[r][p][3] += b1r * W;  ai[r][p][3] += b1i * W;
+                ar[r][p][2] += e1i * X;  ai[r][p][2] -= e1r * X;
+            }
+            if (inj) leg2_advance<R, true>(S, r, l + 1, al2, be2); else leg2_advance<R, false>(S, r, l + 1, al2, be2);
+        }
+    }
+    const int l0 = m > 2 ? m : 2;
+    const bool swap = ((l0 + m) & 1) != 0;
+    const int base = chunk * 64 * R + lane;
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        const int pr = base + r * 64;
+#pragma unroll
+        for (int p = 0; p < 2; ++p)
+#pragma unroll
+            for (int q = 0; q < 2; ++q) {
+                const double kr = swap ? ar[r][p][2 * q + 1] : ar[r][p][2 * q], ki = swap ? ai[r][p][2 * q + 1] : ai[r][p][2 * q];
+                const double fr = swap ? ar[r][p][2 * q] : ar[r][p][2 * q + 1], fi = swap ? ai[r][p][2 * q] : ai[r][p][2 * q + 1];
+                double* o = ph + (kq + 2 * p + q) * ph_stride + ((int64_t)m * A.npair_pad + pr) * 4;
+                o[0] = kr + fr;
+                o[1] = ki + fi;
+                o[2] = kr - fr;
+                o[3] = ki - fi;
+            }
+    }
+}
+
+template <int R>
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) k_leg2_adj_np2(Leg2Args A, const WaveTask* __restrict__ tasks, int ntasks,
+                                                      const double* __restrict__ ph, int64_t ph_stride, int kq,
+                                                      double* __restrict__ part, int64_t part_pol_stride,
+                                                      int64_t part_chunk_stride) {
+    __shared__ __attribute__((aligned(16))) double lds[4][2 * kRedTile];
+    const int wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    const int t = blockIdx.x * 4 + wid;
+    if (t >= ntasks) return;
+    const WaveTask T = tasks[t];
+    if (T.chunk < 0) return;
+    const int m = __builtin_amdgcn_readfirstlane(T.m), chunk = __builtin_amdgcn_readfirstlane(T.chunk);
+    const int lw = __builtin_amdgcn_readfirstlane(T.lw), lAend = __builtin_amdgcn_readfirstlane(T.lAend);
+    const int lmax = A.lmax;
+    Leg2State<R> S;
+    Adj2G<R> G[2];
+    leg2_load_state<R>(A, m, chunk, lane, S);
+    leg2_adj_load<R>(A, ph, ph_stride, kq, m, chunk, lane, G[0]);
+    leg2_adj_load<R>(A, ph, ph_stride, kq + 2, m, chunk, lane, G[1]);
+#pragma unroll
+    for (int r = 0; r < R; ++r)
+        if (S.ls[r] == lw) { S.pc[r] = S.sd[r][0]; S.pp[r] = S.sd[r][1]; S.mc[r] = S.sd[r][2]; S.mp[r] = S.sd[r][3]; }
+    const int64_t mo = d_moffp(lmax, m);
+    const double* __restrict__ al = A.alpha + (mo - m);
+    const double* __restrict__ be = A.beta + (mo - m);
+    double* __restrict__ out = part + chunk * part_chunk_stride + 4 * (mo - m);
+    double* wl = lds[wid];
+    const int id = lane >> 2;
+    int buf = 0;
+    for (int l0g = lw; l0g <= lmax; l0g += 4) {
+        double v[2][16];
+        const bool inj = l0g < lAend;
+#pragma unroll
+        for (int j = 0; j < 4; j += 2) {
+            const int l = l0g + j;
+            double a0[2][4] = {{0, 0, 0, 0}, {0, 0, 0, 0}}, a1[2][4] = {{0, 0, 0, 0}, {0, 0, 0, 0}};
+#pragma unroll
+            for (int r = 0; r < R; ++r) {
+                double W = S.pc[r] + S.mc[r], X = S.pc[r] - S.mc[r];
+#pragma unroll
+                for (int p = 0; p < 2; ++p) {
+                    a0[p][0] += W * G[p].qk_r[r] - X * G[p].uf_i[r];
+                    a0[p][1] += W * G[p].qk_i[r] + X * G[p].uf_r[r];
+                    a0[p][2] += W * G[p].uk_r[r] + X * G[p].qf_i[r];
+                    a0[p][3] += W * G[p].uk_i[r] - X * G[p].qf_r[r];
+                }
+                if (inj) leg2_advance<R, true>(S, r, l, al[l + 1], be[l + 1]); else leg2_advance<R, false>(S, r, l, al[l + 1], be[l + 1]);
+                W = S.pc[r] + S.mc[r];
+                X = S.pc[r] - S.mc[r];
+#pragma unroll
+                for (int p = 0; p < 2; ++p) {
+                    a1[p][0] += W * G[p].qf_r[r] - X * G[p].uk_i[r];
+                    a1[p][1] += W * G[p].qf_i[r] + X * G[p].uk_r[r];
+                    a1[p][2] += W * G[p].uf_r[r] + X * G[p].qk_i[r];
+                    a1[p][3] += W * G[p].uf_i[r] - X * G[p].qk_r[r];
+                }
+                if (inj) leg2_advance<R, true>(S, r, l + 1, al[l + 2], be[l + 2]); else leg2_advance<R, false>(S, r, l + 1, al[l + 2], be[l + 2]);
+            }
+#pragma unroll
+            for (int p = 0; p < 2; ++p)
+#pragma unroll
+                for (int k = 0; k < 4; ++k) { v[p][4 * j + k] = a0[p][k]; v[p][4 * j + 4 + k] = a1[p][k]; }
+        }
+        const int l = l0g + (id >> 2);
+#pragma unroll
+        for (int p = 0; p < 2; ++p) {
+            const double sacc = wave_reduce16(v[p], wl + buf * kRedTile, lane);
+            buf ^= 1;
+            if ((lane & 3) == 0 && l <= lmax) out[p * part_pol_stride + 4 * l + (id & 3)] = sacc;
+        }
+    }
+}
+
+// CMDR_LEG2_NP_S=1 switches the two-pairs-per-wave synthesis off; CMDR_LEG2_NP_A=2 switches the adjoint form on
+// (measured slower: 166 -> 168 VGPRs with spills at the same occupancy)
+static bool leg2_pairs2(bool adjoint) {
+    static int v[2] = {-1, -1};
+    if (v[adjoint] < 0) {
+        v[adjoint] = adjoint ? 0 : 1;
+        if (const char* e = std::getenv(adjoint ? "CMDR_LEG2_NP_A" : "CMDR_LEG2_NP_S")) v[adjoint] = std::atoi(e) >= 2 ? 1 : 0;
+    }
+    return v[adjoint] == 1;
+}
+
 void launch_leg2_synth(const Leg2Args& A, const WaveTask* tasks, int ntasks, const double* st, int npol, double* ph,
                        int64_t ph_stride, int kq0, hipStream_t s) {
     if (ntasks == 0) return;
     for (int ip = 0; ip < npol; ++ip) {
+        if (A.R == 2 && ip + 1 < npol && leg2_pairs2(false)) {
+            hipLaunchKernelGGL(k_leg2_synth_np2<2>, dim3(ntasks / 4), dim3(256), 0, s, A, tasks, ntasks, st, npol, ip, ph, ph_stride, kq0 + 2 * ip);
+            ++ip;
+            continue;
+        }
         if (A.R == 1) hipLaunchKernelGGL(k_leg2_synth<1>, dim3(ntasks / 4), dim3(256), 0, s, A, tasks, ntasks, st, npol, ip, ph, ph_stride, kq0 + 2 * ip);
         else hipLaunchKernelGGL(k_leg2_synth<2>, dim3(ntasks / 4), dim3(256), 0, s, A, tasks, ntasks, st, npol, ip, ph, ph_stride, kq0 + 2 * ip);
     }
@@ -437,6 +609,11 @@ void launch_leg2_adj(const Leg2Args& A, const WaveTask* tasks, int ntasks, const
                      hipStream_t s) {
     if (ntasks == 0) return;
     for (int ip = 0; ip < npol; ++ip) {
+        if (A.R == 2 && ip + 1 < npol && leg2_pairs2(true)) {
+            hipLaunchKernelGGL(k_leg2_adj_np2<2>, dim3(ntasks / 4), dim3(256), 0, s, A, tasks, ntasks, ph, ph_stride, kq0 + 2 * ip, part + ip * part_pol_stride, part_pol_stride, part_chunk_stride);
+            ++ip;
+            continue;
+        }
         if (A.R == 1) hipLaunchKernelGGL(k_leg2_adj<1>, dim3(ntasks / 4), dim3(256), 0, s, A, tasks, ntasks, ph, ph_stride, kq0 + 2 * ip, part + ip * part_pol_stride, part_chunk_stride);
         else hipLaunchKernelGGL(k_leg2_adj<2>, dim3(ntasks / 4), dim3(256), 0, s, A, tasks, ntasks, ph, ph_stride, kq0 + 2 * ip, part + ip * part_pol_stride, part_chunk_stride);
     }

@@ -7,8 +7,9 @@ from commander_amd.cr import build_context
 
 cfg = sys.argv[1] if len(sys.argv) > 1 else "cfg3"
 precond = sys.argv[2] if len(sys.argv) > 2 else "diagonal"
-t0 = time.time(); spec = synth.make_problem(cfg)
-if len(sys.argv) > 3 and sys.argv[3] == "compact":      # + monopole/dipole templates per band and 50 point sources
+pol = "pol" in sys.argv[3:]
+t0 = time.time(); spec = synth.make_problem(cfg, pol=True) if pol else synth.make_problem(cfg)
+if "compact" in sys.argv[3:]:      # + monopole/dipole templates per band and 50 point sources
     synth.add_compact_blocks(spec, nsrc=50)
 print("spec %.1fs" % (time.time() - t0), flush=True)
 t0 = time.time(); ctx = build_context(spec); print("context %.1fs ncr=%d" % (time.time() - t0, ctx.ncr), flush=True)
