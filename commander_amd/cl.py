@@ -1,6 +1,9 @@
 """Host-side mirror of ``comm_Cl%updateS`` (commander3/src/comm_Cl_mod.f90:316-384): per-l nmaps x nmaps
 S_mat / sqrtS_mat / sqrtInvS_mat from D_l.  Setup-time CPU work in the reference as well (LAPACK dsyevd through
-``compute_hermitian_root``, commander3/src/math_tools.f90:606-662); the GPU only consumes the tables."""
+``compute_hermitian_root``, commander3/src/math_tools.f90:606-662); the GPU only consumes the tables.
+
+Used by ``synth`` to build synthetic problems.  The library's own entry point for a Fortran caller is
+``cmdr_cl_update_S`` (``commander_amd.cr.updateS``), checked against the oracle in tests/test_cl_step.py."""
 import numpy as np
 
 

@@ -215,6 +215,21 @@ class CRContext:
         F = _f(np.asarray(F, dtype=np.float64).reshape(len(F), -1))
         check(self.L.cmdr_comp_set_mixing_map(self._h, int(comp), int(band), _p(F), F.shape[1]), self.L)
 
+    def set_comp_cl(self, comp, sqrtS_mat, sqrtInvS_mat, S_mat):
+        """New S tables of a component after ``sampleCls`` -> ``updateS`` (comm_Cl_mod.f90:838-863); arrays
+        (nmaps, nmaps, lmax_cl+1).  Follow with ``update_precond`` as the Gibbs loop does."""
+        a, b, c = (_f(np.asarray(v, dtype=np.float64)) for v in (sqrtS_mat, sqrtInvS_mat, S_mat))
+        check(self.L.cmdr_comp_set_cl(self._h, int(comp), _p(a), _p(b), _p(c)), self.L)
+
+    def set_comp_f_mean(self, comp, F_mean):
+        F = _f(np.asarray(F_mean, dtype=np.float64).reshape(len(self.band_shape), -1))
+        check(self.L.cmdr_comp_set_f_mean(self._h, int(comp), _p(F)), self.L)
+
+    def set_active(self, comp, active, compact=False):
+        """``c%active_samp_group(samp_group)`` of a diffuse component (or compact block) for the next sampling group."""
+        f = self.L.cmdr_compact_set_active if compact else self.L.cmdr_comp_set_active
+        check(f(self._h, int(comp), int(bool(active))), self.L)
+
     def set_cl_diag(self, comp, cl):
         cl = _f(np.asarray(cl, dtype=np.float64).reshape(len(cl), -1))
         check(self.L.cmdr_comp_set_cl_diag(self._h, int(comp), _p(cl)), self.L)
@@ -336,6 +351,38 @@ def getSigmaL(alm, lmax, _lib=None):
     out = np.zeros((lmax + 1, nmaps * (nmaps + 1) // 2), order="F")
     check(L.cmdr_sigma_l(_p(a), int(lmax), nmaps, _p(out)), L)
     return out
+
+
+def updateS(Dl, lmin, RJ2unit, _lib=None):
+    """``comm_Cl%updateS`` (comm_Cl_mod.f90:316-384): Dl (lmax+1, nspec) -> (sqrtS_mat, sqrtInvS_mat, S_mat), each
+    (nmaps, nmaps, lmax+1), and the number of multipoles that were not positive definite."""
+    L = _lib if _lib is not None else _libmod.lib()
+    D = _f(np.asarray(Dl, dtype=np.float64).reshape(len(Dl), -1))
+    nmaps = {1: 1, 3: 2, 6: 3}[D.shape[1]]
+    rj = np.ascontiguousarray(RJ2unit, dtype=np.float64)
+    out = [np.zeros((nmaps, nmaps, D.shape[0]), order="F") for _ in range(3)]
+    nbad = check(L.cmdr_cl_update_S(D.shape[0] - 1, nmaps, int(lmin), _p(D), _p(rj), _p(out[0]), _p(out[1]), _p(out[2])), L)
+    return out[0], out[1], out[2], nbad
+
+
+def sampleCls_binned(Dl, sigma_l, S_mat, RJ2unit, bins, uniforms, _lib=None):
+    """``sample_Cls_inverse_wishart2`` for cltype 'binned' (comm_Cl_mod.f90:1008-1249, InvSamp_mod.f90:35-294), no
+    lookup branch.  bins: depth-first list of dicts(lmin, lmax, spec (1-based), sample, sigma); one uniform variate per
+    sampled bin.  Returns (new Dl, ok, n_uniform_used)."""
+    L = _lib if _lib is not None else _libmod.lib()
+    D = _f(np.array(Dl, dtype=np.float64).reshape(len(Dl), -1))
+    nmaps = {1: 1, 3: 2, 6: 3}[D.shape[1]]
+    sg = _f(np.asarray(sigma_l, dtype=np.float64).reshape(D.shape))
+    Sm = _f(np.asarray(S_mat, dtype=np.float64).reshape(nmaps, nmaps, D.shape[0]))
+    rj = np.ascontiguousarray(RJ2unit, dtype=np.float64)
+    arr = (_libmod.ClBin * max(len(bins), 1))()
+    for i, b in enumerate(bins):
+        arr[i] = _libmod.ClBin(int(b["lmin"]), int(b["lmax"]), int(b["spec"]), int(bool(b["sample"])), float(b["sigma"]))
+    u = np.ascontiguousarray(uniforms, dtype=np.float64)
+    used = ctypes.c_int(0)
+    rc = check(L.cmdr_cl_sample_binned(D.shape[0] - 1, nmaps, _p(sg), _p(Sm), _p(rj), len(bins), arr, _p(u), u.size, _p(D),
+                                       ctypes.byref(used)), L)
+    return D, rc == 0, used.value
 
 
 def alm_to_chain_order(alm, lmax, _lib=None):

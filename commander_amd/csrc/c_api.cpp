@@ -4,6 +4,7 @@
 #include <cstring>
 #include <string>
 
+#include "cl_sampler.hpp"
 #include "common.hpp"
 #include "cr_system.hpp"
 #include "sht_plan.hpp"
@@ -347,6 +348,44 @@ int cmdr_comp_set_cl_diag(cmdr_ctx* ctx, int comp, const double* cl) {
         CMDR_REQUIRE(ctx, "ctx is NULL");
         ctx->sys->set_cl_diag(comp, cl);
     });
+}
+int cmdr_comp_set_cl(cmdr_ctx* ctx, int comp, const double* sqrtS_mat, const double* sqrtInvS_mat, const double* S_mat) {
+    return guarded([&] {
+        CMDR_REQUIRE(ctx, "ctx is NULL");
+        ctx->sys->set_comp_cl(comp, sqrtS_mat, sqrtInvS_mat, S_mat);
+    });
+}
+int cmdr_comp_set_f_mean(cmdr_ctx* ctx, int comp, const double* F_mean) {
+    return guarded([&] {
+        CMDR_REQUIRE(ctx, "ctx is NULL");
+        ctx->sys->set_comp_f_mean(comp, F_mean);
+    });
+}
+int cmdr_comp_set_active(cmdr_ctx* ctx, int comp, int active) {
+    return guarded([&] {
+        CMDR_REQUIRE(ctx, "ctx is NULL");
+        ctx->sys->set_active(0, comp, active);
+    });
+}
+int cmdr_compact_set_active(cmdr_ctx* ctx, int block, int active) {
+    return guarded([&] {
+        CMDR_REQUIRE(ctx, "ctx is NULL");
+        ctx->sys->set_active(1, block, active);
+    });
+}
+int cmdr_cl_update_S(int lmax, int nmaps, int lmin, const double* Dl, const double* RJ2unit, double* sqrtS_mat,
+                     double* sqrtInvS_mat, double* S_mat) {
+    int n = 0;
+    const int rc = guarded([&] { n = cmdr::cl_update_S(lmax, nmaps, lmin, Dl, RJ2unit, sqrtS_mat, sqrtInvS_mat, S_mat); });
+    return rc < 0 ? rc : n;
+}
+int cmdr_cl_sample_binned(int lmax, int nmaps, const double* sigma_l, const double* S_mat, const double* RJ2unit, int nbin,
+                          const cmdr_cl_bin* bins, const double* uniform, int nuniform, double* Dl, int* nused) {
+    int r = 0;
+    const int rc = guarded([&] {
+        r = cmdr::cl_sample_binned(lmax, nmaps, sigma_l, S_mat, RJ2unit, nbin, bins, uniform, nuniform, Dl, nused);
+    });
+    return rc < 0 ? rc : r;
 }
 int cmdr_get_invN_diag(cmdr_ctx* ctx, int band, double* out_host) {
     return guarded([&] {

@@ -1,0 +1,13 @@
+// C_l Gibbs step, host side (see cl_sampler.cpp).
+#pragma once
+#include "../../include/cmdr_hip.h"
+
+namespace cmdr {
+// comm_Cl%updateS: returns the number of multipoles whose matrix was not positive definite (the reference leaves
+// A(1,1) = -1e30 there and carries on; so does this).
+int cl_update_S(int lmax, int nmaps, int lmin, const double* Dl, const double* RJ2unit, double* sqrtS, double* sqrtInvS,
+                double* S);
+// sample_Cls_inverse_wishart2 (no lookup): 0 = ok, 1 = the reference's ok = .false.
+int cl_sample_binned(int lmax, int nmaps, const double* sigma_l, const double* S_mat, const double* RJ2unit, int nbin,
+                     const cmdr_cl_bin* bins, const double* uniform, int nuniform, double* Dl, int* nused);
+}  // namespace cmdr

@@ -389,6 +389,55 @@ void CrSystem::set_cl_diag(int comp, const double* cl) {
     C.cl_diag.assign(cl, cl + (size_t)(C.d.lmax_cl + 1) * C.d.nmaps);
 }
 
+// New S tables of one component after the C_l Gibbs step (sampleCls -> updateS, comm_Cl_mod.f90:838-863); the
+// preconditioner is refreshed by the caller's next cmdr_precond_update_* as in the reference's Gibbs loop.
+void CrSystem::set_comp_cl(int comp, const double* sqrtS, const double* sqrtInvS, const double* S) {
+    CMDR_REQUIRE(comp >= 0 && comp < (int)comps_.size(), "bad comp");
+    Comp& C = comps_[comp];
+    CMDR_REQUIRE(C.d.lmax_cl >= 0, "component has no C_l (cltype none)");
+    CMDR_REQUIRE(sqrtS && sqrtInvS && S, "S tables are NULL");
+    const size_t n = (size_t)C.d.nmaps * C.d.nmaps * (C.d.lmax_cl + 1);
+    C.sqrtS.assign(sqrtS, sqrtS + n);
+    C.sqrtInvS.assign(sqrtInvS, sqrtInvS + n);
+    C.S.assign(S, S + n);
+    if (finalized_) {
+        sync();
+        double* d = smat_.get() + C.d.smat_off;
+        CMDR_HIP_CHECK(hipMemcpy(d, C.sqrtS.data(), sizeof(double) * n, hipMemcpyHostToDevice));
+        CMDR_HIP_CHECK(hipMemcpy(d + n, C.sqrtInvS.data(), sizeof(double) * n, hipMemcpyHostToDevice));
+        CMDR_HIP_CHECK(hipMemcpy(d + 2 * n, C.S.data(), sizeof(double) * n, hipMemcpyHostToDevice));
+    }
+}
+
+void CrSystem::set_comp_f_mean(int comp, const double* F_mean) {
+    CMDR_REQUIRE(comp >= 0 && comp < (int)comps_.size() && F_mean, "bad comp / F_mean");
+    Comp& C = comps_[comp];
+    C.F_mean.assign(F_mean, F_mean + (size_t)bands_.size() * C.d.nmaps);
+    if (finalized_) {
+        sync();
+        rebuild_weights();
+    }
+}
+
+// c%active_samp_group(samp_group) of a diffuse (kind 0) or compact (kind 1) component
+void CrSystem::set_active(int kind, int idx, int active) {
+    if (kind == 0) {
+        CMDR_REQUIRE(idx >= 0 && idx < (int)comps_.size(), "bad comp");
+        comps_[idx].d.active = active ? 1 : 0;
+    } else {
+        CMDR_REQUIRE(idx >= 0 && idx < (int)compacts_.size(), "bad compact block");
+        compacts_[idx].active = active ? 1 : 0;
+    }
+    if (finalized_) {
+        sync();
+        std::vector<CompDev> cd;
+        for (Comp& C : comps_) cd.push_back(C.d);
+        comps_dev_.upload(cd);
+        rebuild_weights();
+        rebuild_mixing();
+    }
+}
+
 // Batches of (band, component) pairs with a mixing map, per plan: scalar columns first, then (Q,U) pairs, as many
 // per sandwich() call as the plan has map slots.
 void CrSystem::rebuild_mixing() {

@@ -56,6 +56,9 @@ class CrSystem {
     // F(band,0)%p%map of a component with spatially varying mixing: npix_local x nmaps (nmaps = min of the band's and
     // the component's), or nullptr to go back to the F_mean fast path.  Callable before or after finalize.
     void set_mixing_map(int comp, int band, const double* F, int nmaps);
+    void set_comp_cl(int comp, const double* sqrtS, const double* sqrtInvS, const double* S);
+    void set_comp_f_mean(int comp, const double* F_mean);
+    void set_active(int kind, int idx, int active);
     void set_cl_diag(int comp, const double* cl);   // getCl(l, p): (lmax_cl+1) x nmaps, for the pseudo-inverse U
     void set_allreduce(AllreduceFn fn, void* user) { allreduce_ = fn; allreduce_user_ = user; }
     void set_allreduce_stream(AllreduceStreamFn fn, void* user) { allreduce_s_ = fn; allreduce_s_user_ = user; }

@@ -21,6 +21,12 @@ def build_library(force=False):
     return _SO
 
 
+class ClBin(ctypes.Structure):
+    """cmdr_cl_bin of include/cmdr_hip.h."""
+    _fields_ = [("lmin", ctypes.c_int), ("lmax", ctypes.c_int), ("spec", ctypes.c_int), ("sample", ctypes.c_int),
+                ("sigma", ctypes.c_double)]
+
+
 def _sig(L):
     c_int, c_i64, c_sz, c_vp = ctypes.c_int, ctypes.c_int64, ctypes.c_size_t, ctypes.c_void_p
     dp = ctypes.POINTER(ctypes.c_double)
@@ -71,6 +77,13 @@ def _sig(L):
     L.cmdr_compact_set_band.argtypes = [c_vp, c_int, c_int, c_i64, ctypes.POINTER(c_i64), ctypes.POINTER(c_int), dp]
     L.cmdr_comp_set_mixing_map.argtypes = [c_vp, c_int, c_int, dp, c_int]
     L.cmdr_comp_set_cl_diag.argtypes = [c_vp, c_int, dp]
+    L.cmdr_comp_set_cl.argtypes = [c_vp, c_int, dp, dp, dp]
+    L.cmdr_comp_set_f_mean.argtypes = [c_vp, c_int, dp]
+    L.cmdr_comp_set_active.argtypes = [c_vp, c_int, c_int]
+    L.cmdr_compact_set_active.argtypes = [c_vp, c_int, c_int]
+    L.cmdr_cl_update_S.argtypes = [c_int, c_int, c_int, dp, dp, dp, dp, dp]
+    L.cmdr_cl_sample_binned.argtypes = [c_int, c_int, dp, dp, dp, c_int, ctypes.POINTER(ClBin), dp, c_int, dp,
+                                        ctypes.POINTER(c_int)]
     L.cmdr_matmulA.argtypes = [c_vp, dp, dp]
     L.cmdr_invM.argtypes = [c_vp, dp, dp]
     L.cmdr_matmulA_dev.argtypes = [c_vp, c_vp, c_vp]

@@ -1,8 +1,8 @@
 !================================================================================
 ! api_tour -- calls, from Fortran through ISO_C_BINDING, the parts of the C ABI that mini_commander does not touch:
 ! two bands, two diffuse components (one with a spatially varying mixing matrix), a template block and a point-source
-! block (compact components), the error path (a preconditioner type that rejects compact components), getSigmaL and
-! the chain-file a_lm order.  Tiny sizes (Nside 8, lmax 16); every check is a size-independent property.
+! block (compact components), the error path (a preconditioner type that rejects compact components), getSigmaL, the
+! chain-file a_lm order, and the C_l step with the update entry points (sampleCls, updateS, set_cl, set_active).  Tiny sizes (Nside 8, lmax 16); every check is a size-independent property.
 ! Build: make -C fortran     Run: ./fortran/api_tour   (needs a GPU)
 !================================================================================
 program api_tour
@@ -23,6 +23,9 @@ program api_tour
   integer(c_int),     allocatable     :: par(:)
   real(c_double),     allocatable     :: val(:)
   real(c_double) :: res(2), sgm(2), mean(2), lhs, rhs
+  real(c_double), allocatable :: Dl(:), u(:)
+  type(cmdr_cl_bin), allocatable :: bins(:)
+  integer(c_int) :: nused
   integer :: l, i, n
   integer(8) :: seed
 
@@ -107,6 +110,35 @@ program api_tour
   call cmdr_check(cmdr_alm_from_chain_order(chain, lmax, nmaps, back), 'chain order back')
   if (maxval(abs(back - real(real(sol(1:nalm), c_float), c_double))) > 0.d0) stop 'api_tour: chain order round trip'
   if (abs(chain(1) - real(sol(1), c_float)) > 0.0) stop 'api_tour: chain order l=0'      ! (l,m)=(0,0) is index 0 in both
+
+  ! C_l | a_lm for component 0 and the next amplitude sample with the new prior (commander.f90:229 sample_powspec)
+  allocate(Dl(0:lmax), bins(3), u(3))
+  do l = 0, lmax
+     Dl(l) = S(l) * l*(l+1) / (2.d0*pi)
+  end do
+  Dl(0) = S(0)
+  bins(1) = cmdr_cl_bin(2, 5, 1, 1, 0.1d0*Dl(2)); bins(2) = cmdr_cl_bin(6, 11, 1, 1, 0.1d0*Dl(6))
+  bins(3) = cmdr_cl_bin(12, lmax, 1, 0, 0.d0)                        ! not sampled
+  u = [uni(seed), uni(seed), uni(seed)]
+  lhs = Dl(12)
+  ierr = cmdr_cl_sample_binned(lmax, nmaps, sig, S, [1.d0], 3_c_int, bins, u, 3_c_int, Dl, nused)
+  call cmdr_check(ierr, 'sampleCls')
+  if (ierr /= 0 .or. nused /= 2) stop 'api_tour: sampleCls failed'
+  if (Dl(12) /= lhs .or. Dl(2) <= 0.d0 .or. Dl(3) /= Dl(2) .or. Dl(6) == Dl(2)) stop 'api_tour: sampled D_l not as binned'
+  ierr = cmdr_cl_update_S(lmax, nmaps, 0_c_int, Dl, [1.d0], sqrtS, sqrtInvS, S)
+  call cmdr_check(ierr, 'updateS')
+  if (ierr /= 0) stop 'api_tour: updateS found a non-positive-definite multipole'
+  if (abs(sqrtS(2)**2 - S(2)) > 1.d-14*S(2)) stop 'api_tour: sqrtS**2 /= S'
+  call cmdr_check(cmdr_comp_set_cl(ctx, 0_c_int, sqrtS, sqrtInvS, S), 'set_cl')
+  call cmdr_check(cmdr_compact_set_active(ctx, blk, 0_c_int), 'compact inactive')      ! next sampling group
+  call cmdr_check(cmdr_precond_init_diag(ctx), 'initPrecond 2')
+  call cmdr_check(cmdr_precond_update_diag(ctx), 'update_precond 2')
+  call cmdr_check(cmdr_matmulA(ctx, x, ax), 'cr_matmulA, new prior')
+  if (ax(ncr) /= 0.d0) stop 'api_tour: inactive block not zero'
+  call cmdr_check(cmdr_solve(ctx, ax, sol, CMDR_CRIT_RESIDUAL, 1.d-12, 5_c_int, 400_c_int, 1_c_int, c_null_ptr, &
+       & niter, res, stat), 'second solve')
+  if (stat /= 0) stop 'api_tour: second CG did not converge'
+  write(*,'(a,i4,a)') ' second sample (new C_l) converged in ', niter, ' iterations'
 
   call cmdr_check(cmdr_ctx_destroy(ctx), 'cmdr_ctx_destroy')
   write(*,*) 'api_tour: OK'

@@ -14,6 +14,12 @@ module cmdr_hip_mod
   integer(c_int), parameter :: CMDR_YtW = 0, CMDR_Y = 1, CMDR_Yt = 2, CMDR_WY = 3   ! sharp.f90:8-14
   integer(c_int), parameter :: CMDR_CRIT_RESIDUAL = 0, CMDR_CRIT_FIXED_ITER = 1      ! cpar%cg_conv_crit
 
+  ! one node of comm_Cl's bins2 tree (comm_Cl_mod.f90:41-47), flattened depth-first; sample /= 0 where stat == 'S'
+  type, bind(c) :: cmdr_cl_bin
+     integer(c_int) :: lmin, lmax, spec, sample
+     real(c_double) :: sigma
+  end type cmdr_cl_bin
+
   interface
      function cmdr_last_error() bind(c, name='cmdr_last_error') result(msg)
        import :: c_ptr
@@ -169,6 +175,62 @@ module cmdr_hip_mod
        real(c_double), intent(in) :: cl(*)
        integer(c_int)             :: ierr
      end function cmdr_comp_set_cl_diag
+
+     ! ---- between Gibbs iterations (after cmdr_finalize)
+     ! sampleCls -> updateS (comm_Cl_mod.f90:838-863): new S tables of a component
+     function cmdr_comp_set_cl(ctx, comp, sqrtS_mat, sqrtInvS_mat, S_mat) bind(c, name='cmdr_comp_set_cl') result(ierr)
+       import :: c_int, c_ptr, c_double
+       type(c_ptr),    value      :: ctx
+       integer(c_int), value      :: comp
+       real(c_double), intent(in) :: sqrtS_mat(*), sqrtInvS_mat(*), S_mat(*)
+       integer(c_int)             :: ierr
+     end function cmdr_comp_set_cl
+
+     function cmdr_comp_set_f_mean(ctx, comp, F_mean) bind(c, name='cmdr_comp_set_f_mean') result(ierr)
+       import :: c_int, c_ptr, c_double
+       type(c_ptr),    value      :: ctx
+       integer(c_int), value      :: comp
+       real(c_double), intent(in) :: F_mean(*)
+       integer(c_int)             :: ierr
+     end function cmdr_comp_set_f_mean
+
+     ! c%active_samp_group(samp_group)
+     function cmdr_comp_set_active(ctx, comp, active) bind(c, name='cmdr_comp_set_active') result(ierr)
+       import :: c_int, c_ptr
+       type(c_ptr),    value :: ctx
+       integer(c_int), value :: comp, active
+       integer(c_int)        :: ierr
+     end function cmdr_comp_set_active
+
+     function cmdr_compact_set_active(ctx, block, active) bind(c, name='cmdr_compact_set_active') result(ierr)
+       import :: c_int, c_ptr
+       type(c_ptr),    value :: ctx
+       integer(c_int), value :: block, active
+       integer(c_int)        :: ierr
+     end function cmdr_compact_set_active
+
+     ! comm_Cl%updateS (comm_Cl_mod.f90:316-384); returns the number of non-positive-definite multipoles
+     function cmdr_cl_update_S(lmax, nmaps, lmin, Dl, RJ2unit, sqrtS_mat, sqrtInvS_mat, S_mat) &
+          & bind(c, name='cmdr_cl_update_S') result(ierr)
+       import :: c_int, c_double
+       integer(c_int), value       :: lmax, nmaps, lmin
+       real(c_double), intent(in)  :: Dl(*), RJ2unit(*)
+       real(c_double), intent(out) :: sqrtS_mat(*), sqrtInvS_mat(*), S_mat(*)
+       integer(c_int)              :: ierr
+     end function cmdr_cl_update_S
+
+     ! sample_Cls_inverse_wishart2 for cltype 'binned' (comm_Cl_mod.f90:1008-1249): one rand_uni(handle) per sampled
+     ! bin goes in through `uniform`; returns 0, or 1 for ok = .false.
+     function cmdr_cl_sample_binned(lmax, nmaps, sigma_l, S_mat, RJ2unit, nbin, bins, uniform, nuniform, Dl, nused) &
+          & bind(c, name='cmdr_cl_sample_binned') result(ierr)
+       import :: c_int, c_double, cmdr_cl_bin
+       integer(c_int), value          :: lmax, nmaps, nbin, nuniform
+       real(c_double), intent(in)     :: sigma_l(*), S_mat(*), RJ2unit(*), uniform(*)
+       type(cmdr_cl_bin), intent(in)  :: bins(*)
+       real(c_double), intent(inout)  :: Dl(*)
+       integer(c_int), intent(out)    :: nused
+       integer(c_int)                 :: ierr
+     end function cmdr_cl_sample_binned
 
      function cmdr_matmulA(ctx, x, y) bind(c, name='cmdr_matmulA') result(ierr)
        import :: c_int, c_ptr, c_double

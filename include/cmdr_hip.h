@@ -180,11 +180,44 @@ int cmdr_solve(cmdr_ctx* ctx, const double* b, double* x, int crit, double tol, 
 int cmdr_solve_dev(cmdr_ctx* ctx, const double* b_dev, double* x_dev, int crit, double tol, int miniter,
                    int maxiter, int check_freq, const double* x0_dev, int* niter, double* res, int* stat);
 
+/* Updates between Gibbs iterations (all after cmdr_finalize; follow with cmdr_precond_update_*):
+ *  - cmdr_comp_set_cl: new sqrtS_mat / sqrtInvS_mat / S_mat of a component after sampleCls -> updateS
+ *    (comm_Cl_mod.f90:838-863, 316-384); same shapes as at cmdr_comp_add.
+ *  - cmdr_comp_set_f_mean: new F_mean(numband, nmaps) after a spectral-index update (comm_diffuse_comp_mod.f90:1991-1999);
+ *    run cmdr_precond_init_* again afterwards, as the reference does (recompute_diffuse_precond).
+ *  - cmdr_comp_set_active / cmdr_compact_set_active: c%active_samp_group(samp_group) when the driver moves to the
+ *    next sampling group (comm_signal_mod.f90 sample_amps_by_CG). */
+int cmdr_comp_set_cl(cmdr_ctx* ctx, int comp, const double* sqrtS_mat, const double* sqrtInvS_mat, const double* S_mat);
+int cmdr_comp_set_f_mean(cmdr_ctx* ctx, int comp, const double* F_mean);
+int cmdr_comp_set_active(cmdr_ctx* ctx, int comp, int active);
+int cmdr_compact_set_active(cmdr_ctx* ctx, int block, int active);
+
 /* getSigmaL (commander3/src/comm_map_mod.f90:1302-1351): sigma_l(0:lmax, nspec), nspec = nmaps(nmaps+1)/2 in
  * Commander's (1,1),(1,2)..(nmaps,nmaps) order, from a packed a_lm(0:nalm-1, nmaps) -- the power-spectrum statistic the
  * C_l Gibbs step (sample_powspec, commander.f90:229) consumes right after the amplitude solve. */
 int cmdr_sigma_l(const double* alm, int lmax, int nmaps, double* sigma_l);
 int cmdr_sigma_l_dev(const double* alm_dev, int64_t stride, int lmax, int nmaps, double* sigma_l_dev);
+
+/* The rest of the C_l Gibbs step (commander.f90:229 sample_powspec), host side -- O(lmax) scalar work on matrices of
+ * order <= 3 that the reference runs on rank 0 only; no GPU needed.
+ *  - cmdr_cl_update_S: comm_Cl%updateS (comm_Cl_mod.f90:316-384).  Dl(0:lmax, nspec) and RJ2unit(nmaps) in,
+ *    sqrtS_mat / sqrtInvS_mat / S_mat (nmaps, nmaps, 0:lmax) out.  Returns the number of multipoles whose matrix was not
+ *    positive definite (compute_hermitian_root then leaves A(1,1) = -1e30, math_tools.f90:640-648), < 0 on error.
+ *  - cmdr_cl_sample_binned: sample_Cls_inverse_wishart2 for cltype 'binned' without the lookup branch
+ *    (comm_Cl_mod.f90:1008-1249 with sample_InvSamp, InvSamp_mod.f90:35-294).  bins = the bins2 tree flattened in the
+ *    depth-first order sample_Dl_bin visits it; sample != 0 where stat == 'S'; spec is 1-based (TT, TE, TB, EE, EB, BB).
+ *    sigma_l as cmdr_sigma_l returns it, S_mat as the last updateS left it; Dl is updated in place.  The reference draws
+ *    one rand_uni per sampled bin (InvSamp_mod.f90:258-261): pass them in `uniform` in that order (the Fortran driver
+ *    keeps its planck_rng handle); *nused returns how many were consumed.  Returns 0, 1 for the reference's
+ *    ok = .false. (a bin's sampler failed; later bins untouched), < 0 on error. */
+typedef struct cmdr_cl_bin {
+    int lmin, lmax, spec, sample;
+    double sigma;
+} cmdr_cl_bin;
+int cmdr_cl_update_S(int lmax, int nmaps, int lmin, const double* Dl, const double* RJ2unit, double* sqrtS_mat,
+                     double* sqrtInvS_mat, double* S_mat);
+int cmdr_cl_sample_binned(int lmax, int nmaps, const double* sigma_l, const double* S_mat, const double* RJ2unit, int nbin,
+                          const cmdr_cl_bin* bins, const double* uniform, int nuniform, double* Dl, int* nused);
 
 /* HIP-event timing of the dominant kernels, on the stream they are launched on.  kinds: 0 Legendre synthesis
  * launches, 1 fused ring-stage launches, 2 Legendre adjoint launches, 3 whole cr_matmulA.  ms_sum[4], count[4]. */

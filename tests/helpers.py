@@ -157,3 +157,77 @@ def golden_kat(_lib=None):
         xo, no, so = S.solve(b, "fixed_iter", maxiter=nit, history=hist)
         assert ng == no == nit and rel(xg, xo) < 1e-10
         assert abs(res[0] - hist[-1]) <= 1e-9 * abs(hist[-1])
+
+
+def gibbs_loop_checks(_lib=None, nside=16, lmax=32, tol=1e-7):
+    """Two Gibbs iterations of amplitudes | C_l and C_l | amplitudes through the product's update path
+    (getSigmaL -> sampleCls_binned -> updateS -> set_comp_cl -> update_precond -> next solve), against the oracle
+    rebuilt from scratch with the oracle's own sampled spectrum; then the sampling-group / mixing updates
+    (set_active, set_comp_f_mean) against freshly built oracle systems.  Shared by the emulation and the GPU tier."""
+    import copy
+    from commander_amd import synth
+    from commander_amd.cr import build_context, getSigmaL, sampleCls_binned, updateS
+    from oracle import cl_oracle, cr_oracle
+    spec = synth.make_problem("cfg2", nside=nside, lmax=lmax)
+    ctx = build_context(spec, _lib=_lib)
+    ctx.initPrecond()
+    rng = np.random.default_rng(2024)
+    RJ = np.ones(1)
+    edges = [(2, 3), (4, 7), (8, 15), (16, lmax)]
+    ospec = copy.deepcopy(spec)
+    na0 = (lmax + 1) ** 2
+    for it in range(2):
+        S = oracle_system(ospec)
+        S.init_precond_diag(); S.update_precond_diag()
+        ctx.update_precond()
+        resid, xi, eta = synth.draw_inputs(spec)
+        resid = [r * (1.0 + 0.1 * it) for r in resid]
+        cols = lambda lst: [np.asarray(v)[:, None] for v in lst]  # noqa: E731
+        rhs = ctx.cr_computeRHS("sample", resid, xi, eta)
+        rhso = S.computeRHS(cols(resid), "sample", cols(xi), eta)
+        # second pass: the two sides carry their own sampled spectrum (equal to ~tol), so the prior term differs at that level
+        assert rel(rhs, rhso) < (1e-11 if it == 0 else 10 * tol), (it, rel(rhs, rhso))
+        x, n, stat, res = ctx.solve_cr_eqn_by_CG(rhs, "residual", 1e-12, 5, 600, 1)
+        xo, no, so = S.solve(rhso, "residual", 1e-12, 5, 600, 1)
+        assert rel(x, xo) < (tol if it == 0 else 10 * tol), (it, rel(x, xo))
+        # C_l | a_lm for the CMB component (first block of the stacked vector)
+        Dl = np.asarray(spec["comps"][0]["Dl"], dtype=np.float64).reshape(lmax + 1, 1)
+        Dlo = np.asarray(ospec["comps"][0]["Dl"], dtype=np.float64).reshape(lmax + 1, 1)
+        bins = [dict(lmin=a, lmax=b, spec=1, sample=True, sigma=0.1 * Dl[a, 0]) for a, b in edges]
+        u = rng.uniform(size=len(bins))
+        sig = getSigmaL(x[:na0], lmax, _lib=_lib)
+        sigo = cr_oracle.getSigmaL(xo[:na0], lmax)
+        assert rel(sig, sigo) < tol
+        newDl, ok, used = sampleCls_binned(Dl, sig, spec["comps"][0]["S_mat"], RJ, bins, u, _lib=_lib)
+        newDlo = Dlo.copy()
+        oko, usedo = cl_oracle.sample_cls_binned(newDlo, sigo, ospec["comps"][0]["S_mat"], RJ, bins, u)
+        assert ok and oko and used == usedo == len(bins)
+        assert rel(newDl, newDlo) < 10 * tol, (it, rel(newDl, newDlo))
+        assert rel(newDl, Dl) > 1e-3                      # it did move
+        sq, isq, Sm, nbad = updateS(newDl, 0, RJ, _lib=_lib)
+        assert nbad == 0
+        ctx.set_comp_cl(0, sq, isq, Sm)
+        spec["comps"][0].update(Dl=newDl[:, 0], sqrtS_mat=sq, sqrtInvS_mat=isq, S_mat=Sm)
+        o = cl_oracle.update_S(newDlo, 0, RJ)
+        ospec["comps"][0].update(Dl=newDlo[:, 0], sqrtS_mat=o[0], sqrtInvS_mat=o[1], S_mat=o[2])
+    # the matvec sees the new prior at once
+    xt = rng.standard_normal(ctx.ncr)
+    S = oracle_system(ospec)
+    assert rel(ctx.cr_matmulA(xt), S.matmulA(xt)) < 10 * tol
+    # ---- next sampling group: second component switched off, then on again with new mixing
+    ospec["comps"][1]["active"] = False
+    ctx.set_active(1, False)
+    S = oracle_system(ospec)
+    y = ctx.cr_matmulA(xt)
+    assert rel(y, S.matmulA(xt)) < 10 * tol and np.all(y[na0:] == 0.0)
+    ctx.update_precond(); S.init_precond_diag(); S.update_precond_diag()
+    assert rel(ctx.cr_invM(xt), S.invM(xt)) < 10 * tol
+    ospec["comps"][1]["active"] = True
+    ospec["comps"][1]["F_mean"] = ospec["comps"][1]["F_mean"] * np.array([1.3, 1.0, 0.6])[:, None]
+    ctx.set_active(1, True)
+    ctx.set_comp_f_mean(1, ospec["comps"][1]["F_mean"])
+    S = oracle_system(ospec)
+    assert rel(ctx.cr_matmulA(xt), S.matmulA(xt)) < 10 * tol
+    # new mixing: the reference sets recompute_diffuse_precond and runs initPrecond again before the next solve
+    ctx.initPrecond(); ctx.update_precond(); S.init_precond_diag(); S.update_precond_diag()
+    assert rel(ctx.cr_invM(xt), S.invM(xt)) < 10 * tol

@@ -269,3 +269,11 @@ def test_qucov_band_gpu():
     """White-noise T,Q,U band at Nside 32 plus a dense-QU-covariance band at Nside 8 (comm_N_QUcov) against the oracle."""
     import test_host_logic
     test_host_logic._qucov_case(None, nside_hi=32, lmax_hi=64, nside_lo=8, lmax_lo=16)
+
+
+@pytest.mark.gpu
+def test_gibbs_loop_updates_gpu():
+    """Two Gibbs iterations (amplitudes | C_l, C_l | amplitudes) through getSigmaL / sampleCls_binned / updateS /
+    cmdr_comp_set_cl / update_precond, then the sampling-group and mixing updates, against the oracle."""
+    from helpers import gibbs_loop_checks
+    gibbs_loop_checks(None, nside=16, lmax=32)

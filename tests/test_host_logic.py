@@ -391,3 +391,10 @@ def _qucov_case(lib, tol=1e-11, **kw):
 
 def test_emul_qucov_band_vs_oracle(EL):
     _qucov_case(EL)
+
+
+def test_emul_gibbs_loop_updates(EL):
+    """C_l | a_lm between two amplitude solves, and the sampling-group / mixing updates, through the update entry
+    points a Gibbs chain uses (cmdr_comp_set_cl, cmdr_comp_set_active, cmdr_comp_set_f_mean)."""
+    from helpers import gibbs_loop_checks
+    gibbs_loop_checks(EL, nside=8, lmax=16)
