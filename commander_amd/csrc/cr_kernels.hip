@@ -339,6 +339,31 @@ void launch_vec_scale(int mode, const double* a, const double* sc, const double*
     hipLaunchKernelGGL(k_vec_scale, dim3((n + 255) / 256), dim3(256), 0, s, mode, a, sc, b, c, out, n);
 }
 
+// Phase-array slots of maps that share a synthesis (bcast: slot j <- slot 0) or whose adjoints are summed into one
+// column (sum: slot 0 += slots 1..n-1, fixed order); slot j starts at base + j * slot_stride.
+__global__ void __launch_bounds__(256) k_phase_share(double* __restrict__ base, int64_t slot_stride, int n, int64_t elems,
+                                                     int sum) {
+    const int64_t i = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 2;
+    if (i >= elems) return;
+    double2* p0 = reinterpret_cast<double2*>(base + i);
+    double2 v = *p0;
+    if (sum) {
+        for (int j = 1; j < n; ++j) {
+            const double2 w = *reinterpret_cast<const double2*>(base + j * slot_stride + i);
+            v.x += w.x;
+            v.y += w.y;
+        }
+        *p0 = v;
+    } else {
+        for (int j = 1; j < n; ++j) *reinterpret_cast<double2*>(base + j * slot_stride + i) = v;
+    }
+}
+void launch_phase_share(double* base, int64_t slot_stride, int n, int64_t elems, bool sum, hipStream_t s) {
+    if (n <= 1 || elems <= 0) return;
+    hipLaunchKernelGGL(k_phase_share, dim3((unsigned)((elems / 2 + 255) / 256)), dim3(256), 0, s, base, slot_stride, n, elems,
+                       sum ? 1 : 0);
+}
+
 __global__ void k_alm_chain(double* __restrict__ alm, int64_t alm_stride, float* __restrict__ c32, int lmax,
                             int to_chain) {
     const int m = blockIdx.y, l = m + blockIdx.x * 256 + threadIdx.x;

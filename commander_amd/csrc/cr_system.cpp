@@ -446,9 +446,11 @@ void CrSystem::rebuild_mixing() {
         const int64_t np = P.npix_local(), na = P.nalm();
         const std::vector<double> pw = P.pixel_weights();
         G.mix.clear();
-        std::vector<MixCol> T, Pp;
-        for (int c = 0; c < (int)comps_.size(); ++c) {
+        const int cap = P.max_maps();
+        bool any = false;
+        for (int c = 0; c < (int)comps_.size(); ++c) {   // a batch holds columns of ONE component: they share its synthesis
             Comp& C = comps_[c];
+            std::vector<MixCol> T, Pp;
             for (int ib = 0; ib < (int)G.bands.size(); ++ib) {
                 const int b = G.bands[ib];
                 if (C.F_map[b].empty()) { C.mulF[b] = DevBuf<double>(); continue; }
@@ -465,31 +467,38 @@ void CrSystem::rebuild_mixing() {
                     Pp.push_back({G.nT + 2 * ip, c, 1});
                 }
             }
-        }
-        if (T.empty()) continue;
-        const int cap = P.max_maps();
-        size_t it = 0, ip = 0;
-        while (it < T.size() || ip < Pp.size()) {
-            MixBatch B;
-            int used = 0;
-            while (it < T.size() && used < cap) { B.T.push_back(T[it++]); ++used; }
-            while (ip < Pp.size() && used + 2 <= cap) { B.P.push_back(Pp[ip++]); used += 2; }
-            CMDR_REQUIRE(used > 0, "plan has too few map slots for a polarised mixing pair");
-            std::vector<const double*> mp;
-            for (const MixCol& m : B.T) mp.push_back(comps_[m.comp].mulF[G.bm_band[m.bm]].get());
-            for (const MixCol& m : B.P) {
-                const double* f = comps_[m.comp].mulF[G.bm_band[m.bm]].get();
-                mp.push_back(f + np);
-                mp.push_back(f + 2 * np);
+            size_t it = 0, ip = 0;
+            while (it < T.size() || ip < Pp.size()) {
+                MixBatch B;
+                int used = 0;
+                while (it < T.size() && used < cap) { B.T.push_back(T[it++]); ++used; }
+                while (ip < Pp.size() && used + 2 <= cap) { B.P.push_back(Pp[ip++]); used += 2; }
+                CMDR_REQUIRE(used > 0, "plan has too few map slots for a polarised mixing pair");
+                std::vector<const double*> mp;
+                for (const MixCol& m : B.T) mp.push_back(comps_[m.comp].mulF[G.bm_band[m.bm]].get());
+                for (const MixCol& m : B.P) {
+                    const double* f = comps_[m.comp].mulF[G.bm_band[m.bm]].get();
+                    mp.push_back(f + np);
+                    mp.push_back(f + 2 * np);
+                }
+                B.mul_ptrs.upload(mp);
+                G.mix.push_back(std::move(B));
+                any = true;
             }
-            B.mul_ptrs.upload(mp);
-            G.mix.push_back(std::move(B));
         }
+        if (!any) continue;
         G.mix_in.ensure((size_t)cap * na);
         G.mix_out.ensure((size_t)cap * na);
         G.E.ensure((size_t)G.nbm * na);
         G.U.ensure((size_t)G.nbm * na);
     }
+}
+
+// CMDR_MIX_SHARE=0: every (band, component) pair runs its own synthesis and adjoint (development A/B switch)
+static bool mix_share() {
+    static int v = -1;
+    if (v < 0) { v = 1; if (const char* e = std::getenv("CMDR_MIX_SHARE")) v = std::atoi(e) != 0; }
+    return v == 1;
 }
 
 // E[bm] = b_l * sum_{c with a mixing map} YtW F_bc Y (S^1/2 x)_c      (evalDiffuseBand, :2082-2089)
@@ -506,9 +515,11 @@ void CrSystem::mix_forward(Group& G, const double* sx) {
                             false, stream_);
             ++k;
         };
-        for (const MixCol& m : B.T) col_in(m, 0);
-        for (const MixCol& m : B.P) { col_in(m, 1); col_in(m, 2); }
-        P.sandwich(G.mix_in.get(), G.mix_out.get(), B.mul_ptrs.get(), nT, nP, stream_);
+        // every column of a batch starts from the same component a_lm: with sharing it is staged (and synthesised) once
+        const bool share = mix_share();
+        for (const MixCol& m : B.T) { col_in(m, 0); if (share) break; }
+        for (const MixCol& m : B.P) { col_in(m, 1); col_in(m, 2); if (share) break; }
+        P.sandwich(G.mix_in.get(), G.mix_out.get(), B.mul_ptrs.get(), nT, nP, stream_, share, false);
         reduce_rings(G.mix_out.get(), (int64_t)(nT + 2 * nP) * na);
         k = 0;
         auto col_out = [&](int bm) {
@@ -545,7 +556,9 @@ void CrSystem::mix_adjoint(Group& G, bool rhs) {
         };
         for (const MixCol& m : B.T) col_in(m.bm, m.comp);
         for (const MixCol& m : B.P) { col_in(m.bm, m.comp); col_in(m.bm + 1, m.comp); }
-        P.sandwich(G.mix_in.get(), G.mix_out.get(), B.mul_ptrs.get(), nT, nP, stream_);
+        // ... and every output is added to the same component block: with sharing the phases are summed and one adjoint runs
+        const bool share = mix_share();
+        P.sandwich(G.mix_in.get(), G.mix_out.get(), B.mul_ptrs.get(), nT, nP, stream_, false, share);
         k = 0;
         auto col_out = [&](const MixCol& m, int stokes) {
             const CompDev& C = comps_[m.comp].d;
@@ -553,8 +566,8 @@ void CrSystem::mix_adjoint(Group& G, bool rhs) {
                             nullptr, true, stream_);
             ++k;
         };
-        for (const MixCol& m : B.T) col_out(m, 0);
-        for (const MixCol& m : B.P) { col_out(m, 1); col_out(m, 2); }
+        for (const MixCol& m : B.T) { col_out(m, 0); if (share) break; }
+        for (const MixCol& m : B.P) { col_out(m, 1); col_out(m, 2); if (share) break; }
     }
 }
 

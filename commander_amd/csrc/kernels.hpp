@@ -82,6 +82,7 @@ void launch_dense_mv(const double* M, const double* x, double* y, int n, hipStre
 // mode 0: out = a * s ; 1: out = a / s ; 2: out = a * s + b ; 3: out = a * s + b + c / s  (b, c nullable -> 0)
 void launch_vec_scale(int mode, const double* a, const double* sc, const double* b, const double* c, double* out, int n,
                       hipStream_t s);
+void launch_phase_share(double* base, int64_t slot_stride, int n, int64_t elems, bool sum, hipStream_t s);
 void launch_alm_chain(double* alm, int64_t alm_stride, float* c32, int lmax, int nmaps, bool to_chain, hipStream_t s);
 void launch_sigma_l(const double* alm, int64_t stride, int lmax, int nmaps, double* out, hipStream_t s);
 

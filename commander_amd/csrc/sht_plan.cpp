@@ -227,29 +227,61 @@ void ShtPlan::map2alm_spin2(const double* d_Q, const double* d_U, double* d_E, d
                         T_.lmax, 1, s);
 }
 
+// share_in : every scalar column has the same input (d_in holds it once) and every (Q,U) pair the same (E,B) input
+//            (once, after the scalar column): one synthesis instead of one per column.
+// sum_out  : the scalar outputs are wanted summed (d_out holds one column), likewise the (E,B) outputs: one adjoint
+//            (Yt is linear).
+// Scalar columns share in pixel space -- the one synthesised map feeds nT analysis FFTs with their own multipliers, or
+// the nT multiplied maps are summed before one analysis FFT -- so the ring stage does n + 1 transforms instead of 2 n.
+// (Q,U) pairs share in phase space (slots copied before / summed after the fused ring stage).
 void ShtPlan::sandwich(const double* d_in, double* d_out, const double* const* d_mul, int nT, int npol,
-                       hipStream_t s) {
+                       hipStream_t s, bool share_in, bool sum_out) {
     CMDR_REQUIRE(nT + 2 * npol <= max_maps_, "sandwich: more columns than the plan was sized for");
     CMDR_REQUIRE(npol == 0 || pol_, "plan was created without polarisation");
-    const int64_t na = nalm();
+    CMDR_REQUIRE(!(share_in && sum_out), "sandwich: share_in and sum_out are exclusive");
+    const int64_t na = nalm(), pe = leg_.ph_elems(), np = npix_local();
+    const int nTin = share_in ? std::min(nT, 1) : nT, nPin = share_in ? std::min(npol, 1) : npol;
+    const int nTout = sum_out ? std::min(nT, 1) : nT, nPout = sum_out ? std::min(npol, 1) : npol;
+    const bool pixT = nT > 1 && (share_in || sum_out);   // scalar columns through pixel space
     if (nT) {
-        launch_alm_to_stream(d_in, na, ast_.get(), leg_.cnorm.get(), T_.lmax, nT, s);
-        synth_from_stream(nT, s);
+        launch_alm_to_stream(d_in, na, ast_.get(), leg_.cnorm.get(), T_.lmax, nTin, s);
+        synth_from_stream(nTin, s);
     }
     if (npol) {
-        launch_alm2_to_stream(d_in + nT * na, d_in + (nT + 1) * na, 2 * na, st2_.get(), npol, leg2_.cnorm.get(), T_.lmax, s);
-        synth2_from_stream(npol, nT, s);
+        launch_alm2_to_stream(d_in + nTin * na, d_in + (nTin + 1) * na, 2 * na, st2_.get(), nPin, leg2_.cnorm.get(), T_.lmax, s);
+        synth2_from_stream(nPin, nT, s);
+        if (nPin < npol) {
+            launch_phase_share(ph_.get() + (int64_t)nT * pe, 2 * pe, npol, pe, false, s);         // Q slots
+            launch_phase_share(ph_.get() + (int64_t)(nT + 1) * pe, 2 * pe, npol, pe, false, s);   // U slots
+        }
     }
-    rings(2, nullptr, 0, d_mul, false, nT + 2 * npol, s);
+    if (!pixT) {
+        rings(2, nullptr, 0, d_mul, false, nT + 2 * npol, s);
+    } else {
+        share_map_.ensure((size_t)np * (share_in ? 1 : nT));
+        if (share_in) {
+            rings(0, share_map_.get(), np, nullptr, false, 1, s);
+            rings(1, share_map_.get(), 0, d_mul, false, nT, s);
+        } else {
+            rings(0, share_map_.get(), np, d_mul, false, nT, s);
+            launch_phase_share(share_map_.get(), np, nT, np, true, s);
+            rings(1, share_map_.get(), 0, nullptr, false, 1, s);
+        }
+        if (npol) rings_fused_range(nT, 2 * npol, d_mul, s);
+    }
     if (nT) {
-        adjoint_to_partials(nT, false, s);
+        adjoint_to_partials(nTout, false, s);
         launch_part_to_alm(part_.get(), part_map_stride(), leg_.tri_elems(), leg_.nchunk, d_out, na, leg_.cnorm.get(),
-                           T_.lmax, nT, s);
+                           T_.lmax, nTout, s);
     }
     if (npol) {
-        adjoint2_to_partials(npol, nT, s);
-        launch_part2_to_alm(part2_.get(), part2_pol_stride(), leg2_.tri4(), leg2_.nchunk, d_out + nT * na,
-                            d_out + (nT + 1) * na, 2 * na, leg2_.cnorm.get(), T_.lmax, npol, s);
+        if (nPout < npol) {
+            launch_phase_share(ph_.get() + (int64_t)nT * pe, 2 * pe, npol, pe, true, s);
+            launch_phase_share(ph_.get() + (int64_t)(nT + 1) * pe, 2 * pe, npol, pe, true, s);
+        }
+        adjoint2_to_partials(nPout, nT, s);
+        launch_part2_to_alm(part2_.get(), part2_pol_stride(), leg2_.tri4(), leg2_.nchunk, d_out + nTout * na,
+                            d_out + (nTout + 1) * na, 2 * na, leg2_.cnorm.get(), T_.lmax, nPout, s);
     }
 }
 

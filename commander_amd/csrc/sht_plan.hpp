@@ -66,7 +66,8 @@ class ShtPlan {
     // (Q,U) maps take mul_{nT+2i}, mul_{nT+2i+1}.  d_in / d_out: nT + 2 npol packed a_lm columns (stride nalm());
     // d_mul: device array of nT + 2 npol device map pointers.  Ring weights (YtW / WY) are folded into mul by the
     // caller (pixel_weights()).  Needs nT + 2 npol <= max_maps.
-    void sandwich(const double* d_in, double* d_out, const double* const* d_mul, int nT, int npol, hipStream_t s);
+    void sandwich(const double* d_in, double* d_out, const double* const* d_mul, int nT, int npol, hipStream_t s, bool share_in = false,
+                  bool sum_out = false);
     // W_ring * 4 pi / Npix for every pixel of the local map (host)
     std::vector<double> pixel_weights() const;
 
@@ -98,6 +99,7 @@ class ShtPlan {
     std::vector<int> ncls_;
     DevBuf<double> tw_, chirp_, ring_scratch_;   // ring_scratch_: one line of n/2 complex per split ring pair and map
     DevBuf<double> ast_, ph_, part_;
+    DevBuf<double> share_map_;   // pixel maps of sandwich()'s shared scalar columns (allocated on first use)
 };
 
 }  // namespace cmdr

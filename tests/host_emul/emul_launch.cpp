@@ -355,6 +355,13 @@ void launch_vec_scale(int mode, const double* a, const double* sc, const double*
         out[i] = v;
     }
 }
+void launch_phase_share(double* base, int64_t slot_stride, int n, int64_t elems, bool sum, hipStream_t) {
+    for (int64_t i = 0; i < elems; ++i)
+        for (int j = 1; j < n; ++j) {
+            if (sum) base[i] += base[j * slot_stride + i];
+            else base[j * slot_stride + i] = base[i];
+        }
+}
 void launch_alm_chain(double* alm, int64_t alm_stride, float* c32, int lmax, int nmaps, bool to_chain, hipStream_t) {
     const int64_t na = (int64_t)(lmax + 1) * (lmax + 1);
     for (int k = 0; k < nmaps; ++k)

@@ -1,6 +1,6 @@
 """Development timing of the CR path on the GPU: matvec, RHS, 40-iteration solve at a synth config."""
 import sys, time
-sys.path.insert(0, ".")
+import os; sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
 import numpy as np
 from commander_amd import synth
 from commander_amd.cr import build_context

@@ -1,7 +1,7 @@
 """Development timing of ONE rank's share of a ring-sharded matvec (no collective): python tools/cr_time_rank.py cfg3 8
 times what rank 0 of 8 would compute per iteration, to tune the small-shard kernel parameters on a 1-GPU box."""
 import sys, time, ctypes
-sys.path.insert(0, ".")
+import os; sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
 import numpy as np
 from commander_amd import synth, healpix
 from commander_amd.cr import build_context

@@ -1,7 +1,7 @@
 """Quick SHT timing on the GPU (development aid): pairs/s at a given geometry."""
 import ctypes, sys, time
 import numpy as np
-sys.path.insert(0, ".")
+import os; sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
 import importlib
 _m = importlib.import_module("commander_amd.lib"); lib, check = _m.lib, _m.check
 from commander_amd import ShtPlan
