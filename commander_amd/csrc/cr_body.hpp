@@ -87,40 +87,52 @@ CMDR_HD void band_prep_elem(const CompDev* __restrict__ comps, int ncomp, const 
 
 // Component entry of y_c: (+)= kappa'_m * sum_{bm in group} w[bm][c][l] cnorm[t] sum_chunks part[bm][chunk][t]
 //   (projectDiffuseBand, comm_diffuse_comp_mod.f90:2112-2167, and the truncation comm_cr_mod.f90:931-933).
-CMDR_HD void band_post_elem(const CompDev& C, int c, int ncomp, const double* __restrict__ part,
+CMDR_HD void band_post_elem(const CompDev* __restrict__ comps, int ncomp, const double* __restrict__ part,
                             int64_t part_map_stride, int64_t part_chunk_stride, int nchunk, int nbm,
                             const int* __restrict__ bm_stokes, const double* __restrict__ w /* [nbm][ncomp][lmax_g+1] */,
                             const double* __restrict__ cnorm, int lmax_g, double* __restrict__ yc, int accumulate,
                             int m, int l) {
-    const int64_t i0 = d_packed_index(C.lmax, l, m);
-    for (int a = 0; a < C.nmaps; ++a) {
-        double re = 0.0, im = 0.0;
-        if (l <= lmax_g && C.active) {
-            const int64_t t = d_moffp(lmax_g, m) + (l - m);
-            for (int b = 0; b < nbm; ++b) {
-                if (bm_stokes[b] != a) continue;
-                const double wc = w[((int64_t)b * ncomp + c) * (lmax_g + 1) + l];
-                if (wc == 0.0) continue;
-                const double* p = part + b * part_map_stride + 2 * t;
-                double sr = 0.0, si = 0.0;
-                for (int ch = 0; ch < nchunk; ++ch) {
-                    sr += p[ch * part_chunk_stride];
-                    si += p[ch * part_chunk_stride + 1];
-                }
-                re += wc * sr;
-                im += wc * si;
+    // one thread = one (l, m): the chunk partials of a band map are read once and feed every component
+    constexpr int kMaxComp = 8;
+    double re[kMaxComp], im[kMaxComp];
+    for (int c = 0; c < kMaxComp; ++c) re[c] = im[c] = 0.0;
+    if (l <= lmax_g) {
+        const int64_t t = d_moffp(lmax_g, m) + (l - m);
+        for (int b = 0; b < nbm; ++b) {
+            if (bm_stokes[b] != 0) continue;
+            double wc[kMaxComp];
+            bool any = false;
+            for (int c = 0; c < ncomp; ++c) {
+                wc[c] = comps[c].active ? w[((int64_t)b * ncomp + c) * (lmax_g + 1) + l] : 0.0;
+                any = any || wc[c] != 0.0;
             }
-            const double f = cnorm[t] * (m == 0 ? 1.0 : 1.41421356237309504880);
-            re *= f;
-            im *= f;
+            if (!any) continue;
+            const double* p = part + b * part_map_stride + 2 * t;
+            double sr = 0.0, si = 0.0;
+            for (int ch = 0; ch < nchunk; ++ch) {
+                sr += p[ch * part_chunk_stride];
+                si += p[ch * part_chunk_stride + 1];
+            }
+            for (int c = 0; c < ncomp; ++c)
+                if (wc[c] != 0.0) { re[c] += wc[c] * sr; im[c] += wc[c] * si; }
         }
-        const int64_t i = C.pos + (int64_t)a * C.nalm + i0;
-        if (accumulate) {
-            yc[i] += re;
-            if (m > 0) yc[i + 1] += im;
-        } else {
-            yc[i] = re;
-            if (m > 0) yc[i + 1] = im;
+        const double f = cnorm[t] * (m == 0 ? 1.0 : 1.41421356237309504880);
+        for (int c = 0; c < ncomp; ++c) { re[c] *= f; im[c] *= f; }
+    }
+    for (int c = 0; c < ncomp; ++c) {
+        const CompDev C = comps[c];
+        if (m > C.lmax || l > C.lmax) continue;
+        const int64_t i0 = d_packed_index(C.lmax, l, m);
+        for (int a = 0; a < C.nmaps; ++a) {
+            const double vr = a == 0 ? re[c] : 0.0, vi = a == 0 ? im[c] : 0.0;   // (Q,U) columns come from band_post2
+            const int64_t i = C.pos + (int64_t)a * C.nalm + i0;
+            if (accumulate) {
+                yc[i] += vr;
+                if (m > 0) yc[i + 1] += vi;
+            } else {
+                yc[i] = vr;
+                if (m > 0) yc[i + 1] = vi;
+            }
         }
     }
 }

@@ -249,14 +249,12 @@ void launch_pinv_prior(const CompDev* comps, int ncomp, int, const double* Q, in
     for (int m = 0; m <= lmax_pre; ++m)
         for (int l = m; l <= lmax_pre; ++l) pinv_prior_elem(comps, ncomp, Q, lmax_pre, nmaps_pre, x, z, out, m, l);
 }
-void launch_band_post(const CompDev* comps, int ncomp, int, const double* part, int64_t pms, int64_t pcs,
+void launch_band_post(const CompDev* comps, int ncomp, int lmax_max, const double* part, int64_t pms, int64_t pcs,
                       int nchunk, int nbm, const int* bm_stokes, const double* w, const double* cnorm, int lmax_g,
                       double* yc, bool accumulate, hipStream_t) {
-    for (int c = 0; c < ncomp; ++c)
-        for (int m = 0; m <= comps[c].lmax; ++m)
-            for (int l = m; l <= comps[c].lmax; ++l)
-                band_post_elem(comps[c], c, ncomp, part, pms, pcs, nchunk, nbm, bm_stokes, w, cnorm, lmax_g, yc,
-                               accumulate ? 1 : 0, m, l);
+    for (int m = 0; m <= lmax_max; ++m)
+        for (int l = m; l <= lmax_max; ++l)
+            band_post_elem(comps, ncomp, part, pms, pcs, nchunk, nbm, bm_stokes, w, cnorm, lmax_g, yc, accumulate ? 1 : 0, m, l);
 }
 void launch_band_prep2(const CompDev* comps, int ncomp, const double* sx, const double* w, int nT, double* st, int npol,
                        const double* cnorm2, int lmax_g, hipStream_t, const double* extra) {
