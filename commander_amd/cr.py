@@ -334,8 +334,11 @@ def build_context(spec, device=0, rings_by_nside=None, _lib=None):
         if c.get("kind") == "compact":
             ctx.add_compact(c["nparam"], c["sigma"], c["mean"], c["P"], c.get("active", True))
             continue
-        ctx.add_comp(c["lmax"], c["nmaps"], c["F_mean"], c.get("sqrtS_mat"), c.get("sqrtInvS_mat"), c.get("S_mat"),
-                     c.get("active", True))
+        tabs = (c.get("sqrtS_mat"), c.get("sqrtInvS_mat"), c.get("S_mat"))
+        if tabs[0] is not None and (c.get("lmax_prior", -1) >= 0 or c.get("l_apod", 0) != 0):
+            # COMP_PRIOR_AMP_LMAX: get_Cl_apod folded into the tables (comm_Cl_mod.f90:572-666)
+            tabs = apply_Cl_apod(*tabs, c.get("l_apod", 0), c.get("lmax_prior", -1), _lib=_lib)
+        ctx.add_comp(c["lmax"], c["nmaps"], c["F_mean"], tabs[0], tabs[1], tabs[2], c.get("active", True))
         for ib, F in (c.get("F_map") or {}).items():
             ctx.set_mixing_map(kd, ib, F)
         kd += 1
@@ -363,6 +366,15 @@ def updateS(Dl, lmin, RJ2unit, _lib=None):
     out = [np.zeros((nmaps, nmaps, D.shape[0]), order="F") for _ in range(3)]
     nbad = check(L.cmdr_cl_update_S(D.shape[0] - 1, nmaps, int(lmin), _p(D), _p(rj), _p(out[0]), _p(out[1]), _p(out[2])), L)
     return out[0], out[1], out[2], nbad
+
+
+def apply_Cl_apod(sqrtS_mat, sqrtInvS_mat, S_mat, l_apod, lmax_prior, _lib=None):
+    """Fold ``get_Cl_apod`` (comm_Cl_mod.f90:676-704) into copies of the updateS tables: what ``matmulSqrtS`` /
+    ``matmulS`` / ``matmulSqrtInvS`` apply per l.  Returns the three scaled tables for ``add_comp`` / ``set_comp_cl``."""
+    L = _lib if _lib is not None else _libmod.lib()
+    a, b, c = (np.array(v, dtype=np.float64, order="F") for v in (sqrtS_mat, sqrtInvS_mat, S_mat))
+    check(L.cmdr_cl_apply_apod(a.shape[2] - 1, a.shape[0], int(l_apod), int(lmax_prior), _p(a), _p(b), _p(c)), L)
+    return a, b, c
 
 
 def sampleCls_binned(Dl, sigma_l, S_mat, RJ2unit, bins, uniforms, _lib=None):

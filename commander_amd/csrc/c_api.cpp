@@ -379,6 +379,13 @@ int cmdr_cl_update_S(int lmax, int nmaps, int lmin, const double* Dl, const doub
     const int rc = guarded([&] { n = cmdr::cl_update_S(lmax, nmaps, lmin, Dl, RJ2unit, sqrtS_mat, sqrtInvS_mat, S_mat); });
     return rc < 0 ? rc : n;
 }
+double cmdr_cl_apod(int l, int l_apod, int lmax, int lmax_prior, int positive) {
+    return cmdr::cl_apod(l, l_apod, lmax, lmax_prior, positive != 0);
+}
+int cmdr_cl_apply_apod(int lmax, int nmaps, int l_apod, int lmax_prior, double* sqrtS_mat, double* sqrtInvS_mat,
+                       double* S_mat) {
+    return guarded([&] { cmdr::cl_apply_apod(lmax, nmaps, l_apod, lmax_prior, sqrtS_mat, sqrtInvS_mat, S_mat); });
+}
 int cmdr_cl_sample_binned(int lmax, int nmaps, const double* sigma_l, const double* S_mat, const double* RJ2unit, int nbin,
                           const cmdr_cl_bin* bins, const double* uniform, int nuniform, double* Dl, int* nused) {
     int r = 0;

@@ -250,6 +250,42 @@ int inv_samp(double eta, const double x_in[3], LnL&& lnL, const double prior[2],
 
 }  // namespace
 
+// get_Cl_apod (comm_Cl_mod.f90:676-704)
+double cl_apod(int l, int l_apod, int lmax, int lmax_prior, bool positive) {
+    const double alpha = std::log(1e3);
+    double f;
+    if (l_apod > 0) {
+        if (l <= l_apod) f = 1.0;
+        else if (l > lmax) f = 0.0;
+        else { const double r = (double)(l - l_apod) / (double)(lmax - l_apod + 1); f = std::exp(-alpha * r * r); }
+    } else {
+        const int la = std::abs(l_apod);
+        if (l >= la) f = 1.0;
+        else if (l == 0 || l > lmax) f = 0.0;
+        else { const double r = (double)(la - l) / (double)(la - 1); f = std::exp(-alpha * r * r); }
+    }
+    if (lmax_prior >= 0 && l < lmax_prior) {
+        const double c = 0.5 * (std::cos(M_PI * (double)(std::max(l, 1) - lmax_prior) / (double)lmax_prior) + 1.0);
+        f *= c * c;
+    }
+    if (!positive && f != 0.0) f = 1.0 / f;
+    return f;
+}
+
+// The apodisation enters matmulSqrtS / matmulS / matmulSqrtInvS / getCl as a per-l scalar (comm_Cl_mod.f90:550-674,
+// 1440-1456): fold it into the tables the solver context receives.
+void cl_apply_apod(int lmax, int nmaps, int l_apod, int lmax_prior, double* sqrtS, double* sqrtInvS, double* S) {
+    CMDR_REQUIRE(lmax >= 0 && nmaps >= 1 && nmaps <= 3 && sqrtS && sqrtInvS && S, "bad arguments");
+    for (int l = 0; l <= lmax; ++l) {
+        const double f = cl_apod(l, l_apod, lmax, lmax_prior, true), g = cl_apod(l, l_apod, lmax, lmax_prior, false);
+        for (int k = 0; k < nmaps * nmaps; ++k) {
+            sqrtS[(size_t)nmaps * nmaps * l + k] *= f;
+            S[(size_t)nmaps * nmaps * l + k] *= f * f;
+            sqrtInvS[(size_t)nmaps * nmaps * l + k] *= g;
+        }
+    }
+}
+
 int cl_update_S(int lmax, int nmaps, int lmin, const double* Dl, const double* RJ2unit, double* sqrtS, double* sqrtInvS,
                 double* S) {
     CMDR_REQUIRE(lmax >= 0 && nmaps >= 1 && nmaps <= 3 && Dl && RJ2unit && sqrtS && sqrtInvS && S, "bad arguments");

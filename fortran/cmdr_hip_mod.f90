@@ -219,6 +219,15 @@ module cmdr_hip_mod
        integer(c_int)              :: ierr
      end function cmdr_cl_update_S
 
+     ! get_Cl_apod folded into the tables handed to cmdr_comp_add / cmdr_comp_set_cl (comm_Cl_mod.f90:572-704)
+     function cmdr_cl_apply_apod(lmax, nmaps, l_apod, lmax_prior, sqrtS_mat, sqrtInvS_mat, S_mat) &
+          & bind(c, name='cmdr_cl_apply_apod') result(ierr)
+       import :: c_int, c_double
+       integer(c_int), value         :: lmax, nmaps, l_apod, lmax_prior
+       real(c_double), intent(inout) :: sqrtS_mat(*), sqrtInvS_mat(*), S_mat(*)
+       integer(c_int)                :: ierr
+     end function cmdr_cl_apply_apod
+
      ! sample_Cls_inverse_wishart2 for cltype 'binned' (comm_Cl_mod.f90:1008-1249): one rand_uni(handle) per sampled
      ! bin goes in through `uniform`; returns 0, or 1 for ok = .false.
      function cmdr_cl_sample_binned(lmax, nmaps, sigma_l, S_mat, RJ2unit, nbin, bins, uniform, nuniform, Dl, nused) &

@@ -218,6 +218,14 @@ int cmdr_cl_update_S(int lmax, int nmaps, int lmin, const double* Dl, const doub
                      double* sqrtInvS_mat, double* S_mat);
 int cmdr_cl_sample_binned(int lmax, int nmaps, const double* sigma_l, const double* S_mat, const double* RJ2unit, int nbin,
                           const cmdr_cl_bin* bins, const double* uniform, int nuniform, double* Dl, int* nused);
+/* get_Cl_apod (comm_Cl_mod.f90:676-704): the per-l factor matmulSqrtS / matmulS / matmulSqrtInvS / getCl apply on top of
+ * the updateS tables (:572-666, :1454) -- not 1 for l < COMP_PRIOR_AMP_LMAX (cs_lmax_amp_prior, :134).  The solver context
+ * takes tables with the factor folded in: cmdr_cl_apply_apod scales sqrtS_mat by f, S_mat by f^2 and sqrtInvS_mat by 1/f
+ * (0 where f = 0) in place; call it on a COPY of the updateS output before cmdr_comp_add / cmdr_comp_set_cl
+ * (cmdr_cl_sample_binned wants the raw S_mat, as the reference's lnL_invWishart does). */
+double cmdr_cl_apod(int l, int l_apod, int lmax, int lmax_prior, int positive);
+int cmdr_cl_apply_apod(int lmax, int nmaps, int l_apod, int lmax_prior, double* sqrtS_mat, double* sqrtInvS_mat,
+                       double* S_mat);
 
 /* HIP-event timing of the dominant kernels, on the stream they are launched on.  kinds: 0 Legendre synthesis
  * launches, 1 fused ring-stage launches, 2 Legendre adjoint launches, 3 whole cr_matmulA.  ms_sum[4], count[4]. */

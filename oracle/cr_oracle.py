@@ -111,12 +111,40 @@ def hermitian_root(A, pw):
     return (V * W ** pw) @ V.T
 
 
+def get_Cl_apod(l, l_apod, lmax, lmax_prior, positive):
+    """comm_Cl_mod.f90:676-704."""
+    alpha = np.log(1e3)
+    if l_apod > 0:
+        if l <= l_apod:
+            f = 1.0
+        elif l > lmax:
+            f = 0.0
+        else:
+            f = np.exp(-alpha * (l - l_apod) ** 2 / float(lmax - l_apod + 1) ** 2)
+    else:
+        if l >= abs(l_apod):
+            f = 1.0
+        elif l == 0 or l > lmax:
+            f = 0.0
+        else:
+            f = np.exp(-alpha * (abs(l_apod) - l) ** 2 / float(abs(l_apod) - 1) ** 2)
+    if lmax_prior >= 0 and l < lmax_prior:
+        f = f * (0.5 * (np.cos(np.pi * float(max(l, 1) - lmax_prior) / float(lmax_prior)) + 1.0)) ** 2
+    if not positive and f != 0.0:
+        f = 1.0 / f
+    return float(f)
+
+
 class Cl:
     """``comm_Cl``: S_mat / sqrtS_mat / sqrtInvS_mat from D_l (comm_Cl_mod.f90:316-384)."""
 
-    def __init__(self, lmax, nmaps, Dl, lmin=0, RJ2unit=None, cltype="power_law"):
+    def __init__(self, lmax, nmaps, Dl, lmin=0, RJ2unit=None, cltype="power_law", l_apod=0, lmax_prior=-1):
         self.lmax, self.nmaps, self.type = lmax, nmaps, cltype
         self.lmin = lmin
+        # get_Cl_apod per l (comm_Cl_mod.f90:676-704): l_apod is never assigned in the reference (=> 0 here);
+        # lmax_prior = COMP_PRIOR_AMP_LMAX (:134) switches on a cosine roll-off below it
+        self.f_apod = np.array([get_Cl_apod(l, l_apod, lmax, lmax_prior, True) for l in range(lmax + 1)])
+        self.g_apod = np.array([get_Cl_apod(l, l_apod, lmax, lmax_prior, False) for l in range(lmax + 1)])
         nspec = nmaps * (nmaps + 1) // 2
         Dl = np.asarray(Dl, dtype=np.float64).reshape(lmax + 1, nspec)
         self.Dl = Dl
@@ -160,32 +188,34 @@ class Cl:
             self.S_mat[:, :, l] = sq @ sq
             self.sqrtInvS_mat[:, :, l] = isq
 
-    def _apply(self, mats, alm, info, diag=False):
-        # comm_Cl_mod.f90:588-637 / 639-674; l_apod is never assigned in the reference => f_apod = 1
+    def _apply(self, mats, alm, info, diag=False, inverse=False):
+        # matmulSqrtS / matmulSqrtInvS, comm_Cl_mod.f90:588-674: f_apod (or its reciprocal) times the per-l matrix
         if self.type == "none":
             return alm.copy()
         out = np.zeros_like(alm)
         ok = info.l <= self.lmax
         lc = np.minimum(info.l, self.lmax)
+        fa = (self.g_apod if inverse else self.f_apod)[lc][:, None]
         if diag:
             d = np.sqrt(np.stack([self.S_mat[j, j, :] for j in range(self.nmaps)], axis=1))  # (lmax+1, nmaps)
-            out = np.where(ok[:, None], d[lc, : alm.shape[1]] * alm, 0.0)
+            out = np.where(ok[:, None], fa * d[lc, : alm.shape[1]] * alm, 0.0)
         else:
             Ml = np.moveaxis(mats, 2, 0)[lc]  # (nalm, nmaps, nmaps)
-            out = np.where(ok[:, None], np.einsum("nij,nj->ni", Ml, alm), 0.0)
+            out = np.where(ok[:, None], fa * np.einsum("nij,nj->ni", Ml, alm), 0.0)
         return out
 
     def getCl(self, l, p):
-        """comm_Cl_mod.f90:1440-1456 (p: 0-based Stokes index; f_apod = 1)."""
+        """comm_Cl_mod.f90:1440-1456 (p: 0-based Stokes index)."""
         n = self.nmaps
         j = p * n - p * (p - 1) // 2          # diagonal spectrum index of Stokes p (0-based)
-        return self.Dl[l, j] if l == 0 else self.Dl[l, j] / (l * (l + 1) / (2.0 * np.pi))
+        v = self.Dl[l, j] if l == 0 else self.Dl[l, j] / (l * (l + 1) / (2.0 * np.pi))
+        return v * self.f_apod[l] ** 2
 
     def sqrtS(self, alm, info, diag=False):
         return self._apply(self.sqrtS_mat, alm, info, diag)
 
     def sqrtInvS(self, alm, info):
-        return self._apply(self.sqrtInvS_mat, alm, info)
+        return self._apply(self.sqrtInvS_mat, alm, info, inverse=True)
 
 
 class DiffuseComp:
@@ -526,7 +556,7 @@ class CRSystem:
             ok = info_pre.l <= c.Cl.lmax
             d = np.zeros((info_pre.nalm, nmaps_pre))
             for j in range(min(nmaps_pre, c.nmaps)):
-                d[:, j] = np.where(ok, np.sqrt(c.Cl.S_mat[j, j, lc]), 0.0)   # sqrtS(diag=.true.) :1371,1409
+                d[:, j] = np.where(ok, c.Cl.f_apod[lc] * np.sqrt(c.Cl.S_mat[j, j, lc]), 0.0)   # sqrtS(diag=.true.) :1371,1409
             M[:, :, :, k1] *= d[:, :, None]
             M[:, :, k1, :] *= d[:, :, None]
         if self.only_pol:

@@ -27,7 +27,7 @@ def oracle_system(spec, only_pol=False):
         if c.get("sqrtS_mat") is None:
             cl = cro.Cl(c["lmax"], c["nmaps"], np.zeros((c["lmax"] + 1, c["nmaps"] * (c["nmaps"] + 1) // 2)), cltype="none")
         else:
-            cl = cro.Cl(c["lmax"], c["nmaps"], c["Dl"])
+            cl = cro.Cl(c["lmax"], c["nmaps"], c["Dl"], l_apod=c.get("l_apod", 0), lmax_prior=c.get("lmax_prior", -1))
             # the product receives the tables from commander_amd.cl.update_S; make sure both sides hold the same
             assert np.allclose(cl.sqrtS_mat, c["sqrtS_mat"], rtol=1e-13, atol=0)
         comps.append(cro.DiffuseComp(c["lmax"], c["nmaps"], cl, c["F_mean"], active=c.get("active", True),
@@ -97,6 +97,23 @@ def edge_case_checks(_lib=None, tol=1e-11):
         xg, ng, sg, _ = ctx.solve_cr_eqn_by_CG(b, "fixed_iter", maxiter=nit)
         xo, no, so = S.solve(b, "fixed_iter", maxiter=nit)
         assert rel(xg, xo) < 1e-9, (nside, lmax, clm)
+    # ---- COMP_PRIOR_AMP_LMAX: the cosine roll-off of get_Cl_apod below lmax_prior on one component (T and T,Q,U)
+    for pol in (False, True):
+        spec = synth.make_problem("cfg2", nside=8, lmax=16, pol=pol)
+        spec["comps"][1]["lmax_prior"] = 10
+        S = oracle_system(spec)
+        assert S.comps[1].Cl.f_apod[3] < 0.5 and S.comps[1].Cl.f_apod[10] == 1.0
+        ctx = build_context(spec, _lib=_lib)
+        x = rng.standard_normal(ctx.ncr)
+        assert rel(ctx.cr_matmulA(x), S.matmulA(x)) < tol
+        resid, xi, eta = synth.draw_inputs(spec)
+        b = S.computeRHS(resid, "sample", xi, eta)
+        assert rel(ctx.cr_computeRHS("sample", resid, xi, eta), b) < tol
+        ctx.initPrecond(); ctx.update_precond(); S.init_precond_diag(); S.update_precond_diag()
+        assert rel(ctx.cr_invM(x), S.invM(x)) < tol
+        xg, ng, sg, _ = ctx.solve_cr_eqn_by_CG(b, "fixed_iter", maxiter=8)
+        xo, no, so = S.solve(b, "fixed_iter", maxiter=8)
+        assert rel(xg, xo) < 1e-9
 
 
 def golden_checks(_lib=None, tol=1e-12):

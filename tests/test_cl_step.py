@@ -65,6 +65,25 @@ def test_updateS_not_positive_definite_is_reported():
         assert nbad == 1 and a[0, 0, 5] == -1e30        # compute_hermitian_root's marker (math_tools.f90:640-648)
 
 
+def test_get_Cl_apod_and_table_folding():
+    from oracle import cr_oracle
+    from commander_amd.cr import apply_Cl_apod
+    for name, L in _libs():
+        for l_apod in (0, 7, -7):
+            for lmax_prior in (-1, 0, 12):
+                for pos in (True, False):
+                    for l in range(0, 25):
+                        got = L.cmdr_cl_apod(l, l_apod, 20, lmax_prior, int(pos))
+                        want = cr_oracle.get_Cl_apod(l, l_apod, 20, lmax_prior, pos)
+                        assert abs(got - want) <= 1e-15 * max(1.0, abs(want)), (name, l, l_apod, lmax_prior, pos)
+        rng = np.random.default_rng(1)
+        a, b, c = (rng.standard_normal((3, 3, 21)) for _ in range(3))
+        fa, fb, fc = apply_Cl_apod(a, b, c, 0, 12, _lib=L)
+        f = np.array([cr_oracle.get_Cl_apod(l, 0, 20, 12, True) for l in range(21)])
+        assert np.allclose(fa, a * f, rtol=1e-15) and np.allclose(fc, c * f * f, rtol=1e-15)
+        assert np.allclose(fb, b / f, rtol=1e-15) and f[1] < 0.01 and f[12] == 1.0
+
+
 def _sigma_from_draw(Dl, lmin, RJ, rng):
     """sigma_l of an a_lm drawn from S: what getSigmaL hands the sampler."""
     from oracle import cl_oracle
