@@ -56,6 +56,12 @@ int cmdr_dev_alloc(size_t nbytes, void** out) {
 int cmdr_dev_free(void* p) {
     return guarded([&] { CMDR_HIP_CHECK(hipFree(p)); });
 }
+int cmdr_dev_mem_info(size_t* free_bytes, size_t* total_bytes) {
+    return guarded([&] {
+        CMDR_REQUIRE(free_bytes && total_bytes, "NULL argument");
+        CMDR_HIP_CHECK(hipMemGetInfo(free_bytes, total_bytes));
+    });
+}
 int cmdr_memcpy_h2d(void* dst, const void* src, size_t n) {
     return guarded([&] { CMDR_HIP_CHECK(hipMemcpy(dst, src, n, hipMemcpyHostToDevice)); });
 }

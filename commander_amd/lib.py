@@ -37,6 +37,7 @@ def _sig(L):
     L.cmdr_set_device.argtypes = [c_int]
     L.cmdr_dev_alloc.argtypes = [c_sz, ctypes.POINTER(c_vp)]
     L.cmdr_dev_free.argtypes = [c_vp]
+    L.cmdr_dev_mem_info.argtypes = [ctypes.POINTER(c_sz), ctypes.POINTER(c_sz)]
     L.cmdr_memcpy_h2d.argtypes = [c_vp, c_vp, c_sz]
     L.cmdr_memcpy_d2h.argtypes = [c_vp, c_vp, c_sz]
     L.cmdr_sht_plan_create.argtypes = [c_int, c_int, c_int, ip, dp, c_int, ctypes.POINTER(c_vp)]
@@ -129,6 +130,13 @@ def check(rc, L=None):
     if rc < 0:
         raise CmdrError((L or lib()).cmdr_last_error().decode())
     return rc
+
+
+def device_mem_info():
+    """(free, total) bytes of the current device."""
+    f, t = ctypes.c_size_t(0), ctypes.c_size_t(0)
+    check(lib().cmdr_dev_mem_info(ctypes.byref(f), ctypes.byref(t)))
+    return f.value, t.value
 
 
 def device_count():

@@ -39,6 +39,8 @@ int cmdr_device_synchronize(void);
 /* ---- device memory helpers (so a host language without HIP bindings can keep data resident) ---- */
 int cmdr_dev_alloc(size_t nbytes, void** out);
 int cmdr_dev_free(void* p);
+/* hipMemGetInfo of the current device: free and total bytes (sizing bands / plans against the 288 GB of one MI355X). */
+int cmdr_dev_mem_info(size_t* free_bytes, size_t* total_bytes);
 int cmdr_memcpy_h2d(void* dst_dev, const void* src_host, size_t nbytes);
 int cmdr_memcpy_d2h(void* dst_host, const void* src_dev, size_t nbytes);
 

@@ -277,3 +277,26 @@ def test_gibbs_loop_updates_gpu():
     cmdr_comp_set_cl / update_precond, then the sampling-group and mixing updates, against the oracle."""
     from helpers import gibbs_loop_checks
     gibbs_loop_checks(None, nside=16, lmax=32)
+
+
+@pytest.mark.gpu
+def test_context_lifecycle_releases_device_memory_gpu():
+    """A chain creates and destroys solver contexts (new sampling groups, new band sets): device memory must come back.
+    20 create / solve / destroy cycles at Nside 64 with compact blocks and a mixing map; free memory afterwards within
+    16 MiB of the level after the first cycle (allocator granularity), i.e. nothing accumulates per cycle."""
+    from commander_amd import synth
+    from commander_amd.cr import build_context
+    from commander_amd.lib import device_mem_info
+    spec = synth.make_problem("cfg2", nside=64, lmax=128, pol=True)
+    synth.add_compact_blocks(spec, nsrc=3)
+    levels = []
+    for it in range(20):
+        ctx = build_context(spec)
+        ctx.initPrecond(); ctx.update_precond()
+        resid, xi, eta = synth.draw_inputs(spec)
+        b = ctx.cr_computeRHS("sample", resid, xi, eta)
+        x, n, stat, res = ctx.solve_cr_eqn_by_CG(b, "fixed_iter", maxiter=3)
+        assert np.all(np.isfinite(x))
+        ctx.close()
+        levels.append(device_mem_info()[0])
+    assert abs(levels[-1] - levels[1]) < 16 << 20, [(v - levels[1]) >> 20 for v in levels]
