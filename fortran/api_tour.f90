@@ -25,7 +25,9 @@ program api_tour
   real(c_double) :: res(2), sgm(2), mean(2), lhs, rhs
   real(c_double), allocatable :: Dl(:), u(:)
   type(cmdr_cl_bin), allocatable :: bins(:)
-  integer(c_int) :: nused
+  integer(c_int) :: nused, niter2
+  integer(c_size_t) :: mem_free, mem_total, nb
+  type(c_ptr) :: dx, dy, dz
   integer :: l, i, n
   integer(8) :: seed
 
@@ -43,6 +45,7 @@ program api_tour
      S(l) = 100.d0 / max(l*(l+1.d0), 1.d0); sqrtS(l) = sqrt(S(l)); sqrtInvS(l) = 1.d0/sqrtS(l)
   end do
 
+  call cmdr_check(cmdr_set_device(0_c_int), 'cmdr_set_device')        ! one rank per GPU: the node-local rank goes here
   call cmdr_check(cmdr_ctx_create(0_c_int, ctx), 'cmdr_ctx_create')
   do ib = 1, nband
      call cmdr_check(cmdr_band_add(ctx, nside, lmax, nmaps, siN, b_l, 1.d0, c_null_ptr, c_null_ptr), 'cmdr_band_add')
@@ -97,6 +100,25 @@ program api_tour
        & niter, res, stat), 'solve_cr_eqn_by_CG')
   if (stat /= 0) stop 'api_tour: CG did not converge'
   write(*,'(a,i4,a,es10.3)') ' converged in ', niter, ' iterations, delta/delta0 = ', res(1)/res(2)
+
+  ! the same through device-resident vectors: x and A x stay in HBM between calls (what a chain does inside one solve)
+  call cmdr_check(cmdr_dev_mem_info(mem_free, mem_total), 'mem_info')
+  if (mem_free <= 0 .or. mem_free > mem_total) stop 'api_tour: mem_info'
+  nb = int(ncr, c_size_t) * 8_c_size_t
+  call cmdr_check(cmdr_dev_alloc(nb, dx), 'dev_alloc x'); call cmdr_check(cmdr_dev_alloc(nb, dy), 'dev_alloc y')
+  call cmdr_check(cmdr_dev_alloc(nb, dz), 'dev_alloc z')
+  call cmdr_check(cmdr_memcpy_h2d(dx, c_loc(x), nb), 'h2d')
+  call cmdr_check(cmdr_matmulA_dev(ctx, dx, dy), 'cr_matmulA_dev')
+  call cmdr_check(cmdr_memcpy_d2h(c_loc(ay), dy, nb), 'd2h')
+  if (maxval(abs(ay - ax)) > 0.d0) stop 'api_tour: device-pointer matvec differs from the host-pointer one'
+  call cmdr_check(cmdr_solve_dev(ctx, dy, dz, CMDR_CRIT_RESIDUAL, 1.d-12, 5_c_int, 400_c_int, 1_c_int, c_null_ptr, &
+       & niter2, res, stat), 'solve_dev')
+  call cmdr_check(cmdr_memcpy_d2h(c_loc(ay), dz, nb), 'd2h solution')
+  if (stat /= 0 .or. niter2 /= niter) stop 'api_tour: solve_dev'
+  if (maxval(abs(ay - sol)) > 1.d-12*maxval(abs(sol))) stop 'api_tour: solve_dev differs from solve'
+  call cmdr_check(cmdr_device_synchronize(), 'sync')
+  call cmdr_check(cmdr_dev_free(dx), 'free'); call cmdr_check(cmdr_dev_free(dy), 'free'); call cmdr_check(cmdr_dev_free(dz), 'free')
+  if (cmdr_band_npix(ctx, 0_c_int) /= npix) stop 'api_tour: band_npix'
 
   ! error path: the pseudo-inverse preconditioner rejects compact components; the message comes through cmdr_last_error
   ierr = cmdr_precond_init_pseudoinv(ctx)

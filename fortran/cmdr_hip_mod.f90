@@ -335,6 +335,199 @@ module cmdr_hip_mod
        integer(c_int)              :: ierr
      end function cmdr_sigma_l
 
+     ! ---- device selection and device-resident vectors (one MPI rank per GPU: cmdr_set_device(local rank) first)
+     function cmdr_set_device(device) bind(c, name='cmdr_set_device') result(ierr)
+       import :: c_int
+       integer(c_int), value :: device
+       integer(c_int)        :: ierr
+     end function cmdr_set_device
+
+     function cmdr_device_synchronize() bind(c, name='cmdr_device_synchronize') result(ierr)
+       import :: c_int
+       integer(c_int) :: ierr
+     end function cmdr_device_synchronize
+
+     function cmdr_dev_alloc(nbytes, ptr) bind(c, name='cmdr_dev_alloc') result(ierr)
+       import :: c_int, c_size_t, c_ptr
+       integer(c_size_t), value :: nbytes
+       type(c_ptr), intent(out) :: ptr
+       integer(c_int)           :: ierr
+     end function cmdr_dev_alloc
+
+     function cmdr_dev_free(ptr) bind(c, name='cmdr_dev_free') result(ierr)
+       import :: c_int, c_ptr
+       type(c_ptr), value :: ptr
+       integer(c_int)     :: ierr
+     end function cmdr_dev_free
+
+     function cmdr_dev_mem_info(free_bytes, total_bytes) bind(c, name='cmdr_dev_mem_info') result(ierr)
+       import :: c_int, c_size_t
+       integer(c_size_t), intent(out) :: free_bytes, total_bytes
+       integer(c_int)                 :: ierr
+     end function cmdr_dev_mem_info
+
+     function cmdr_memcpy_h2d(dst_dev, src_host, nbytes) bind(c, name='cmdr_memcpy_h2d') result(ierr)
+       import :: c_int, c_size_t, c_ptr
+       type(c_ptr), value       :: dst_dev, src_host      ! src_host = c_loc(array)
+       integer(c_size_t), value :: nbytes
+       integer(c_int)           :: ierr
+     end function cmdr_memcpy_h2d
+
+     function cmdr_memcpy_d2h(dst_host, src_dev, nbytes) bind(c, name='cmdr_memcpy_d2h') result(ierr)
+       import :: c_int, c_size_t, c_ptr
+       type(c_ptr), value       :: dst_host, src_dev
+       integer(c_size_t), value :: nbytes
+       integer(c_int)           :: ierr
+     end function cmdr_memcpy_d2h
+
+     ! device-pointer forms of the CR entry points: x, b stay in HBM between calls (type(c_ptr) from cmdr_dev_alloc)
+     function cmdr_matmulA_dev(ctx, x_dev, y_dev) bind(c, name='cmdr_matmulA_dev') result(ierr)
+       import :: c_int, c_ptr
+       type(c_ptr), value :: ctx, x_dev, y_dev
+       integer(c_int)     :: ierr
+     end function cmdr_matmulA_dev
+
+     function cmdr_invM_dev(ctx, x_dev, y_dev) bind(c, name='cmdr_invM_dev') result(ierr)
+       import :: c_int, c_ptr
+       type(c_ptr), value :: ctx, x_dev, y_dev
+       integer(c_int)     :: ierr
+     end function cmdr_invM_dev
+
+     function cmdr_compute_rhs_dev(ctx, sample, resid_dev, xi_dev, eta_dev, mu_dev, rhs_dev) &
+          & bind(c, name='cmdr_compute_rhs_dev') result(ierr)
+       import :: c_int, c_ptr
+       type(c_ptr),    value      :: ctx
+       integer(c_int), value      :: sample
+       type(c_ptr),    intent(in) :: resid_dev(*), xi_dev(*)     ! one device pointer per band
+       type(c_ptr),    value      :: eta_dev, mu_dev, rhs_dev    ! eta / mu may be c_null_ptr
+       integer(c_int)             :: ierr
+     end function cmdr_compute_rhs_dev
+
+     function cmdr_solve_dev(ctx, b_dev, x_dev, crit, tol, miniter, maxiter, check_freq, x0_dev, niter, res, stat) &
+          & bind(c, name='cmdr_solve_dev') result(ierr)
+       import :: c_int, c_ptr, c_double
+       type(c_ptr),    value       :: ctx, b_dev, x_dev, x0_dev
+       integer(c_int), value       :: crit, miniter, maxiter, check_freq
+       real(c_double), value       :: tol
+       integer(c_int), intent(out) :: niter, stat
+       real(c_double), intent(out) :: res(2)
+       integer(c_int)              :: ierr
+     end function cmdr_solve_dev
+
+     function cmdr_sigma_l_dev(alm_dev, stride, lmax, nmaps, sigma_l_dev) bind(c, name='cmdr_sigma_l_dev') result(ierr)
+       import :: c_int, c_int64_t, c_ptr
+       type(c_ptr),        value :: alm_dev, sigma_l_dev
+       integer(c_int64_t), value :: stride
+       integer(c_int),     value :: lmax, nmaps
+       integer(c_int)            :: ierr
+     end function cmdr_sigma_l_dev
+
+     ! ---- accessors
+     function cmdr_ctx_set_only_pol(ctx, only_pol) bind(c, name='cmdr_ctx_set_only_pol') result(ierr)
+       import :: c_int, c_ptr
+       type(c_ptr),    value :: ctx
+       integer(c_int), value :: only_pol           ! cpar%only_pol (comm_cr_mod.f90:600-601, 686-689)
+       integer(c_int)        :: ierr
+     end function cmdr_ctx_set_only_pol
+
+     function cmdr_band_npix(ctx, band) bind(c, name='cmdr_band_npix') result(n)
+       import :: c_int, c_int64_t, c_ptr
+       type(c_ptr),    value :: ctx
+       integer(c_int), value :: band
+       integer(c_int64_t)    :: n
+     end function cmdr_band_npix
+
+     function cmdr_get_invN_diag(ctx, band, out_host) bind(c, name='cmdr_get_invN_diag') result(ierr)
+       import :: c_int, c_ptr, c_double
+       type(c_ptr),    value       :: ctx
+       integer(c_int), value       :: band
+       real(c_double), intent(out) :: out_host(*)  ! data(band)%N%invN_diag%alm (nalm, nmaps)
+       integer(c_int)              :: ierr
+     end function cmdr_get_invN_diag
+
+     function cmdr_get_alpha_nu(ctx, band, out_host) bind(c, name='cmdr_get_alpha_nu') result(ierr)
+       import :: c_int, c_ptr, c_double
+       type(c_ptr),    value       :: ctx
+       integer(c_int), value       :: band
+       real(c_double), intent(out) :: out_host(*)  ! data(band)%N%alpha_nu(1:nmaps)
+       integer(c_int)              :: ierr
+     end function cmdr_get_alpha_nu
+
+     function cmdr_problem_info(ctx, info) bind(c, name='cmdr_problem_info') result(ierr)
+       import :: c_int, c_int64_t, c_ptr
+       type(c_ptr),        value       :: ctx
+       integer(c_int64_t), intent(out) :: info(3)
+       integer(c_int)                  :: ierr
+     end function cmdr_problem_info
+
+     function cmdr_profile_enable(ctx, on) bind(c, name='cmdr_profile_enable') result(ierr)
+       import :: c_int, c_ptr
+       type(c_ptr),    value :: ctx
+       integer(c_int), value :: on
+       integer(c_int)        :: ierr
+     end function cmdr_profile_enable
+
+     function cmdr_profile_read(ctx, ms_sum, count) bind(c, name='cmdr_profile_read') result(ierr)
+       import :: c_int, c_ptr, c_double, c_long_long
+       type(c_ptr), value            :: ctx
+       real(c_double),       intent(out) :: ms_sum(4)   ! synthesis, ring stage, adjoint, whole matvec
+       integer(c_long_long), intent(out) :: count(4)
+       integer(c_int)                :: ierr
+     end function cmdr_profile_read
+
+     function cmdr_cl_apod(l, l_apod, lmax, lmax_prior, positive) bind(c, name='cmdr_cl_apod') result(f)
+       import :: c_int, c_double
+       integer(c_int), value :: l, l_apod, lmax, lmax_prior, positive
+       real(c_double)        :: f
+     end function cmdr_cl_apod
+
+     ! ---- SHT level, the rest: polarised plans and the spin-2 call of exec_sharp_Y on columns 2:3
+     function cmdr_sht_plan_create_pol(nside, lmax, nrings, rings, wring, max_maps, plan) &
+          & bind(c, name='cmdr_sht_plan_create_pol') result(ierr)
+       import :: c_int, c_ptr
+       integer(c_int), value        :: nside, lmax, nrings, max_maps
+       type(c_ptr),    value        :: rings, wring
+       type(c_ptr),    intent(out)  :: plan
+       integer(c_int)               :: ierr
+     end function cmdr_sht_plan_create_pol
+
+     function cmdr_sht_nalm(plan) bind(c, name='cmdr_sht_nalm') result(n)
+       import :: c_int64_t, c_ptr
+       type(c_ptr), value :: plan
+       integer(c_int64_t) :: n
+     end function cmdr_sht_nalm
+
+     function cmdr_sht_npix(plan) bind(c, name='cmdr_sht_npix') result(n)
+       import :: c_int64_t, c_ptr
+       type(c_ptr), value :: plan
+       integer(c_int64_t) :: n
+     end function cmdr_sht_npix
+
+     function cmdr_sht_execute_dev(plan, job, nmaps, alm_dev, alm_stride, map_dev, map_stride) &
+          & bind(c, name='cmdr_sht_execute_dev') result(ierr)
+       import :: c_int, c_int64_t, c_ptr
+       type(c_ptr),        value :: plan, alm_dev, map_dev
+       integer(c_int),     value :: job, nmaps
+       integer(c_int64_t), value :: alm_stride, map_stride
+       integer(c_int)            :: ierr
+     end function cmdr_sht_execute_dev
+
+     function cmdr_sht_execute_spin2(plan, job, almE, almB, mapQ, mapU) bind(c, name='cmdr_sht_execute_spin2') result(ierr)
+       import :: c_int, c_ptr, c_double
+       type(c_ptr),    value         :: plan
+       integer(c_int), value         :: job
+       real(c_double), intent(inout) :: almE(*), almB(*), mapQ(*), mapU(*)
+       integer(c_int)                :: ierr
+     end function cmdr_sht_execute_spin2
+
+     function cmdr_sht_execute_spin2_dev(plan, job, almE_dev, almB_dev, mapQ_dev, mapU_dev) &
+          & bind(c, name='cmdr_sht_execute_spin2_dev') result(ierr)
+       import :: c_int, c_ptr
+       type(c_ptr),    value :: plan, almE_dev, almB_dev, mapQ_dev, mapU_dev
+       integer(c_int), value :: job
+       integer(c_int)        :: ierr
+     end function cmdr_sht_execute_spin2_dev
+
   end interface
 
 contains

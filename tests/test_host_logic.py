@@ -398,3 +398,16 @@ def test_emul_gibbs_loop_updates(EL):
     points a Gibbs chain uses (cmdr_comp_set_cl, cmdr_comp_set_active, cmdr_comp_set_f_mean)."""
     from helpers import gibbs_loop_checks
     gibbs_loop_checks(EL, nside=8, lmax=16)
+
+
+def test_fortran_module_binds_every_abi_symbol():
+    """fortran/cmdr_hip_mod.f90 is the reference-side binding: every function include/cmdr_hip.h
+    declares must have an ISO_C_BINDING interface there."""
+    import os, re
+    root = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..")
+    hdr = open(os.path.join(root, "include", "cmdr_hip.h")).read()
+    mod = open(os.path.join(root, "fortran", "cmdr_hip_mod.f90")).read()
+    names = sorted(set(re.findall(r"\b(cmdr_[a-zA-Z0-9_]+)\s*\(", hdr)))
+    assert len(names) > 60
+    missing = [n for n in names if "name='%s'" % n not in mod]
+    assert not missing, missing
