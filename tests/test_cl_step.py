@@ -206,3 +206,25 @@ def test_sampler_matches_analytic_inverse_gamma(l):
             c = got[l, 0] / fac
             # the sampler truncates at five sigma and integrates a spline on 10^4 points: ~1e-3 in the quantile
             assert abs(law.cdf(c) - q) < 2e-3, (name, l, q, c, law.ppf(q))
+
+
+def test_sampler_distribution_kolmogorov_smirnov():
+    """400 draws of one multipole (l = 30) from seeded uniforms: the empirical law of the product's samples against the
+    analytic inverse-gamma posterior (Kolmogorov-Smirnov).  Since the sampler maps each uniform through its numerical
+    CDF, the KS distance measures the CDF error directly (plus the finite-sample term of the uniforms themselves)."""
+    from scipy.stats import invgamma, kstest
+    import commander_amd.lib as L
+    from commander_amd.cr import sampleCls_binned
+    l, sigma_C = 30, 1.7
+    fac = l * (l + 1) / (2 * np.pi)
+    Dl = np.full((l + 1, 1), 1.5 * fac)
+    S = np.zeros((1, 1, l + 1)); S[0, 0, :] = 1.5
+    sig = np.zeros((l + 1, 1)); sig[l, 0] = sigma_C
+    law = invgamma(a=(2 * l + 1) / 2.0 - 1.0, scale=(2 * l + 1) * sigma_C / 2.0)
+    bins = [dict(lmin=l, lmax=l, spec=1, sample=True, sigma=0.2 * fac)]
+    u = np.random.default_rng(99).uniform(size=400)
+    lib = L.lib()
+    xs = np.array([sampleCls_binned(Dl, sig, S, np.ones(1), bins, [q], _lib=lib)[0][l, 0] / fac for q in u])
+    # the sampler's own CDF error: law.cdf(sample) must reproduce the uniform that produced it
+    assert np.abs(law.cdf(xs) - u).max() < 3e-3
+    assert kstest(xs, law.cdf).pvalue > 0.01
