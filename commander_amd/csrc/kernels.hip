@@ -405,7 +405,7 @@ __global__ void __launch_bounds__(256) k_leg2_adj(Leg2Args A, const WaveTask* __
     leg2_adj_load<R>(A, ph, ph_stride, kq, m, chunk, lane, G);
 #pragma unroll
     for (int r = 0; r < R; ++r)
-        if (S.ls[r] == lw) { S.pc[r] = S.sd[r][0]; S.pp[r] = S.sd[r][1]; S.mc[r] = S.sd[r][2]; S.mp[r] = S.sd[r][3]; }
+        if (S.ls[r] == lw) { S.pc[r] = S.sd(r, 0); S.pp[r] = S.sd(r, 1); S.mc[r] = S.sd(r, 2); S.mp[r] = S.sd(r, 3); }
     const int64_t mo = d_moffp(lmax, m);
     const double* __restrict__ al = A.alpha + (mo - m);
     const double* __restrict__ be = A.beta + (mo - m);
@@ -453,7 +453,7 @@ __global__ void __launch_bounds__(256) k_leg2_synth_np2(Leg2Args A, const WaveTa
         for (int p = 0; p < 2; ++p)
 #pragma unroll
             for (int k = 0; k < 4; ++k) ar[r][p][k] = ai[r][p][k] = 0.0;
-        if (S.ls[r] == lw) { S.pc[r] = S.sd[r][0]; S.pp[r] = S.sd[r][1]; S.mc[r] = S.sd[r][2]; S.mp[r] = S.sd[r][3]; }
+        if (S.ls[r] == lw) { S.pc[r] = S.sd(r, 0); S.pp[r] = S.sd(r, 1); S.mc[r] = S.sd(r, 2); S.mp[r] = S.sd(r, 3); }
     }
     for (int l = lw; l <= lmax; l += 2) {
         const double* __restrict__ c0 = as + ls4 * l;
@@ -507,7 +507,7 @@ __global__ void __launch_bounds__(256) k_leg2_synth_np2(Leg2Args A, const WaveTa
 }
 
 template <int R>
-__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) k_leg2_adj_np2(Leg2Args A, const WaveTask* __restrict__ tasks, int ntasks,
+__global__ void __launch_bounds__(256) k_leg2_adj_np2(Leg2Args A, const WaveTask* __restrict__ tasks, int ntasks,
                                                       const double* __restrict__ ph, int64_t ph_stride, int kq,
                                                       double* __restrict__ part, int64_t part_pol_stride,
                                                       int64_t part_chunk_stride) {
@@ -528,7 +528,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))
     leg2_adj_load<R>(A, ph, ph_stride, kq + 2, m, chunk, lane, G[1]);
 #pragma unroll
     for (int r = 0; r < R; ++r)
-        if (S.ls[r] == lw) { S.pc[r] = S.sd[r][0]; S.pp[r] = S.sd[r][1]; S.mc[r] = S.sd[r][2]; S.mp[r] = S.sd[r][3]; }
+        if (S.ls[r] == lw) { S.pc[r] = S.sd(r, 0); S.pp[r] = S.sd(r, 1); S.mc[r] = S.sd(r, 2); S.mp[r] = S.sd(r, 3); }
     const int64_t mo = d_moffp(lmax, m);
     const double* __restrict__ al = A.alpha + (mo - m);
     const double* __restrict__ be = A.beta + (mo - m);
@@ -580,12 +580,11 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))
     }
 }
 
-// CMDR_LEG2_NP_S=1 switches the two-pairs-per-wave synthesis off; CMDR_LEG2_NP_A=2 switches the adjoint form on
-// (measured slower: 166 -> 168 VGPRs with spills at the same occupancy)
+// CMDR_LEG2_NP_S=1 / CMDR_LEG2_NP_A=1 switch the two-pairs-per-wave synthesis / adjoint off
 static bool leg2_pairs2(bool adjoint) {
     static int v[2] = {-1, -1};
     if (v[adjoint] < 0) {
-        v[adjoint] = adjoint ? 0 : 1;
+        v[adjoint] = 1;
         if (const char* e = std::getenv(adjoint ? "CMDR_LEG2_NP_A" : "CMDR_LEG2_NP_S")) v[adjoint] = std::atoi(e) >= 2 ? 1 : 0;
     }
     return v[adjoint] == 1;

@@ -266,8 +266,9 @@ struct Leg2Args {
 template <int R>
 struct Leg2State {
     double x[R], pc[R], pp[R], mc[R], mp[R];   // mu+ (current, previous), mu- (current, previous)
-    double sd[R][4];
-    int ls[R];
+    const double* sdp;                         // seeds of ring pair r at sdp + 256 r: fetched when the pair starts
+    int ls[R];                                 // (once per ring pair and m), not carried in registers
+    CMDR_HD double sd(int r, int k) const { return sdp[r * 256 + k]; }
 };
 
 template <int R>
@@ -279,8 +280,7 @@ CMDR_HD void leg2_load_state(const Leg2Args& A, int m, int chunk, int lane, Leg2
         const int64_t idx = (int64_t)m * A.npair_pad + p;
         S.x[r] = A.x[p];
         S.ls[r] = A.ls[idx];
-#pragma unroll
-        for (int k = 0; k < 4; ++k) S.sd[r][k] = A.seed[idx * 4 + k];
+        if (r == 0) S.sdp = A.seed + idx * 4;
         S.pc[r] = S.pp[r] = S.mc[r] = S.mp[r] = 0.0;
     }
 }
@@ -295,7 +295,7 @@ CMDR_HD void leg2_advance(Leg2State<R>& S, int r, int l, double al, double be) {
     n = tm * S.mc[r] - S.mp[r];
     S.mp[r] = S.mc[r];
     S.mc[r] = n;
-    if (INJECT) if (S.ls[r] == l + 1) { S.pc[r] = S.sd[r][0]; S.pp[r] = S.sd[r][1]; S.mc[r] = S.sd[r][2]; S.mp[r] = S.sd[r][3]; }
+    if (INJECT) if (S.ls[r] == l + 1) { S.pc[r] = S.sd(r, 0); S.pp[r] = S.sd(r, 1); S.mc[r] = S.sd(r, 2); S.mp[r] = S.sd(r, 3); }
 }
 
 // st : (E,B) stream of this polarisation pair set: st[((t * npol) + ip) * 4 + {E'r, E'i, B'r, B'i}]
@@ -320,7 +320,7 @@ CMDR_HD void leg2_synth_lane(const Leg2Args& A, const double* __restrict__ st, i
         for (int k = 0; k < 4; ++k) ar[r][k] = ai[r][k] = 0.0;
 #pragma unroll
     for (int r = 0; r < R; ++r)
-        if (S.ls[r] == lw) { S.pc[r] = S.sd[r][0]; S.pp[r] = S.sd[r][1]; S.mc[r] = S.sd[r][2]; S.mp[r] = S.sd[r][3]; }
+        if (S.ls[r] == lw) { S.pc[r] = S.sd(r, 0); S.pp[r] = S.sd(r, 1); S.mc[r] = S.sd(r, 2); S.mp[r] = S.sd(r, 3); }
     for (int l = lw; l <= lmax; l += 2) {
         const double* __restrict__ c0 = as + ls4 * l;
         const double* __restrict__ c1 = c0 + ls4;

@@ -135,8 +135,8 @@ static void adj2_R(const Leg2Args& A, const WaveTask* tasks, int ntasks, const d
             leg2_adj_load<R>(A, ph, ph_stride, kq, t.m, t.chunk, lane, G[lane]);
             for (int r = 0; r < R; ++r)
                 if (S[lane].ls[r] == t.lw) {
-                    S[lane].pc[r] = S[lane].sd[r][0]; S[lane].pp[r] = S[lane].sd[r][1];
-                    S[lane].mc[r] = S[lane].sd[r][2]; S[lane].mp[r] = S[lane].sd[r][3];
+                    S[lane].pc[r] = S[lane].sd(r, 0); S[lane].pp[r] = S[lane].sd(r, 1);
+                    S[lane].mc[r] = S[lane].sd(r, 2); S[lane].mp[r] = S[lane].sd(r, 3);
                 }
         }
         const int64_t mo = d_moffp(lmax, t.m);
