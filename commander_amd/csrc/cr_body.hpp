@@ -19,36 +19,38 @@ struct CompDev {        // one diffuse component inside the stacked vector (comm
 // out = f(M_l) applied per l to the nmaps-vector of a component (comm_Cl_mod.f90:588-674), optionally + add.
 //   kind 0: sqrtS_mat, 1: sqrtInvS_mat.  l > lmax_cl -> 0.  cltype 'none' (lmax_cl < 0) -> identity.
 //   inactive components: out = (add ? add : 0)  [cr_matmulA never touches their slots: comm_cr_mod.f90:800-803]
+CMDR_HD void sqrtS_slot(const CompDev& C, const double* __restrict__ smat, int kind, const double* __restrict__ in,
+                        const double* __restrict__ add, double* __restrict__ out, int l, int64_t i,
+                        bool pass_inactive) {   // i = packed index of one real slot of multipole l
+    const int nm = C.nmaps;
+    double v[3] = {0.0, 0.0, 0.0}, r[3] = {0.0, 0.0, 0.0};
+    for (int a = 0; a < nm; ++a) v[a] = in[C.pos + a * C.nalm + i];
+    if (!C.active) {
+        for (int a = 0; a < nm; ++a) r[a] = pass_inactive ? v[a] : 0.0;
+    } else if (C.lmax_cl < 0) {
+        for (int a = 0; a < nm; ++a) r[a] = v[a];
+    } else if (l <= C.lmax_cl) {
+        const double* M = smat + C.smat_off + (int64_t)kind * nm * nm * (C.lmax_cl + 1) + (int64_t)nm * nm * l;
+        for (int a = 0; a < nm; ++a) {
+            double s = 0.0;
+            for (int b = 0; b < nm; ++b) s += M[a + nm * b] * v[b];
+            r[a] = s;
+        }
+    }
+    for (int a = 0; a < nm; ++a) {
+        double o = r[a];
+        // the unit prior / eta / mu terms exist only for active components with a prior
+        // (comm_cr_mod.f90:698, :967: "if (trim(c%cltype) /= 'none')")
+        if (add) o += (C.active && C.lmax_cl >= 0) ? add[C.pos + a * C.nalm + i] : 0.0;
+        out[C.pos + a * C.nalm + i] = o;
+    }
+}
 CMDR_HD void sqrtS_elem(const CompDev& C, const double* __restrict__ smat, int kind, const double* __restrict__ in,
                         const double* __restrict__ add, double* __restrict__ out, int m, int l,
                         bool pass_inactive) {
     const int64_t i0 = d_packed_index(C.lmax, l, m);
-    const int nslot = m == 0 ? 1 : 2;
-    const int nm = C.nmaps;
-    for (int sl = 0; sl < nslot; ++sl) {
-        const int64_t i = i0 + sl;
-        double v[3] = {0.0, 0.0, 0.0}, r[3] = {0.0, 0.0, 0.0};
-        for (int a = 0; a < nm; ++a) v[a] = in[C.pos + a * C.nalm + i];
-        if (!C.active) {
-            for (int a = 0; a < nm; ++a) r[a] = pass_inactive ? v[a] : 0.0;
-        } else if (C.lmax_cl < 0) {
-            for (int a = 0; a < nm; ++a) r[a] = v[a];
-        } else if (l <= C.lmax_cl) {
-            const double* M = smat + C.smat_off + (int64_t)kind * nm * nm * (C.lmax_cl + 1) + (int64_t)nm * nm * l;
-            for (int a = 0; a < nm; ++a) {
-                double s = 0.0;
-                for (int b = 0; b < nm; ++b) s += M[a + nm * b] * v[b];
-                r[a] = s;
-            }
-        }
-        for (int a = 0; a < nm; ++a) {
-            double o = r[a];
-            // the unit prior / eta / mu terms exist only for active components with a prior
-            // (comm_cr_mod.f90:698, :967: "if (trim(c%cltype) /= 'none')")
-            if (add) o += (C.active && C.lmax_cl >= 0) ? add[C.pos + a * C.nalm + i] : 0.0;
-            out[C.pos + a * C.nalm + i] = o;
-        }
-    }
+    sqrtS_slot(C, smat, kind, in, add, out, l, i0, pass_inactive);
+    if (m > 0) sqrtS_slot(C, smat, kind, in, add, out, l, i0 + 1, pass_inactive);
 }
 
 // Band stream entry: a~_bm(l,m) = cnorm * kappa_m * sum_c w[bm][c][l] * sx_{c, stokes(bm)}(l,m)

@@ -11,17 +11,22 @@
 namespace cmdr {
 
 // ----------------------------------------------------------------------------- (l, m)-grid kernels
+// thread = one real slot of the packed a_lm row of m (the (+m, -m) pairs are interleaved): consecutive lanes touch
+// consecutive doubles of every Stokes column
 __global__ void k_sqrtS(const CompDev* __restrict__ comps, const double* __restrict__ smat, int kind,
                         const double* __restrict__ in, const double* __restrict__ add, double* __restrict__ out,
                         int pass_inactive) {
     const CompDev C = comps[blockIdx.z];
-    const int m = blockIdx.y, l = m + blockIdx.x * 256 + threadIdx.x;
-    if (m > C.lmax || l > C.lmax) return;
-    sqrtS_elem(C, smat, kind, in, add, out, m, l, pass_inactive != 0);
+    const int m = blockIdx.y, e = blockIdx.x * 256 + threadIdx.x;
+    if (m > C.lmax) return;
+    const int l = m == 0 ? e : m + (e >> 1);
+    if (l > C.lmax) return;
+    const int64_t i = d_packed_index(C.lmax, l, m) + (m == 0 ? 0 : (e & 1));
+    sqrtS_slot(C, smat, kind, in, add, out, l, i, pass_inactive != 0);
 }
 void launch_sqrtS(const CompDev* comps, int ncomp, int lmax_max, const double* smat, int kind, const double* in,
                   const double* add, double* out, bool pass_inactive, hipStream_t s) {
-    dim3 grid((lmax_max + 1 + 255) / 256, lmax_max + 1, ncomp);
+    dim3 grid((2 * (lmax_max + 1) + 255) / 256, lmax_max + 1, ncomp);
     hipLaunchKernelGGL(k_sqrtS, grid, dim3(256), 0, s, comps, smat, kind, in, add, out, pass_inactive ? 1 : 0);
 }
 
