@@ -368,6 +368,22 @@ def updateS(Dl, lmin, RJ2unit, _lib=None):
     return out[0], out[1], out[2], nbad
 
 
+def sampleCls_lookup(Dl, Dl_lookup, lmin_lookup, active, sigma_l, S_mat, RJ2unit, uniform, _lib=None):
+    """``sample_Dl_lookup`` (comm_Cl_mod.f90:1063-1145): Dl_lookup (nl, 6, nmodel), active: 6 flags.
+    Returns (new Dl, ok, chosen model index)."""
+    L = _lib if _lib is not None else _libmod.lib()
+    D = _f(np.array(Dl, dtype=np.float64).reshape(len(Dl), 6))
+    T = _f(np.asarray(Dl_lookup, dtype=np.float64))
+    sg = _f(np.asarray(sigma_l, dtype=np.float64).reshape(D.shape))
+    Sm = _f(np.asarray(S_mat, dtype=np.float64).reshape(3, 3, D.shape[0]))
+    rj = np.ascontiguousarray(RJ2unit, dtype=np.float64)
+    act = (ctypes.c_int * 6)(*[int(bool(a)) for a in active])
+    ch = ctypes.c_int(-1)
+    rc = check(L.cmdr_cl_sample_lookup(D.shape[0] - 1, int(lmin_lookup), int(lmin_lookup) + T.shape[0] - 1, T.shape[2], _p(T), act,
+                                       _p(sg), _p(Sm), _p(rj), float(uniform), _p(D), ctypes.byref(ch)), L)
+    return D, rc == 0, ch.value
+
+
 def apply_Cl_apod(sqrtS_mat, sqrtInvS_mat, S_mat, l_apod, lmax_prior, _lib=None):
     """Fold ``get_Cl_apod`` (comm_Cl_mod.f90:676-704) into copies of the updateS tables: what ``matmulSqrtS`` /
     ``matmulS`` / ``matmulSqrtInvS`` apply per l.  Returns the three scaled tables for ``add_comp`` / ``set_comp_cl``."""

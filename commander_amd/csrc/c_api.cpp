@@ -385,6 +385,16 @@ int cmdr_cl_update_S(int lmax, int nmaps, int lmin, const double* Dl, const doub
     const int rc = guarded([&] { n = cmdr::cl_update_S(lmax, nmaps, lmin, Dl, RJ2unit, sqrtS_mat, sqrtInvS_mat, S_mat); });
     return rc < 0 ? rc : n;
 }
+int cmdr_cl_sample_lookup(int lmax, int lmin_lookup, int lmax_lookup, int nmodel, const double* Dl_lookup,
+                          const int* active, const double* sigma_l, const double* S_mat, const double* RJ2unit,
+                          double uniform, double* Dl, int* chosen) {
+    int r = 0;
+    const int rc = guarded([&] {
+        r = cmdr::cl_sample_lookup(lmax, lmin_lookup, lmax_lookup, nmodel, Dl_lookup, active, sigma_l, S_mat, RJ2unit,
+                                   uniform, Dl, chosen);
+    });
+    return rc < 0 ? rc : r;
+}
 double cmdr_cl_apod(int l, int l_apod, int lmax, int lmax_prior, int positive) {
     return cmdr::cl_apod(l, l_apod, lmax, lmax_prior, positive != 0);
 }

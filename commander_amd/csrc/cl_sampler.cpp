@@ -420,4 +420,66 @@ int cl_sample_binned(int lmax, int nmaps, const double* sigma_l, const double* S
     return 0;
 }
 
+// sample_Dl_lookup (comm_Cl_mod.f90:1063-1145): pick one of nmodel tabulated spectra for lmin_lookup..lmax_lookup by its
+// inverse-Wishart likelihood; polarised components only (the reference declares S(3,3)).
+int cl_sample_lookup(int lmax, int lmin_lookup, int lmax_lookup, int nmodel, const double* Dl_lookup, const int* active,
+                     const double* sigma_l, const double* S_mat, const double* RJ2unit, double uniform, double* Dl,
+                     int* chosen) {
+    CMDR_REQUIRE(lmax >= 0 && lmin_lookup >= 0 && lmax_lookup >= lmin_lookup && lmax_lookup <= lmax && nmodel >= 1 &&
+                 Dl_lookup && active && sigma_l && S_mat && RJ2unit && Dl, "bad arguments");
+    const int nmaps = 3, nspec = 6;
+    const int64_t ld = lmax + 1, nl = lmax_lookup - lmin_lookup + 1;
+    int pi_[6], pj_[6], k = 0;
+    for (int i = 0; i < nmaps; ++i)
+        for (int j = i; j < nmaps; ++j, ++k) { pi_[k] = i; pj_[k] = j; }
+    std::vector<double> lnL(nmodel, 0.0);
+    for (int im = 0; im < nmodel; ++im) {
+        for (int l = lmin_lookup; l <= lmax_lookup; ++l) {
+            Mat3 Sm;
+            Sm.n = nmaps;
+            const double* sm = S_mat + (size_t)9 * l;
+            for (int j = 0; j < 3; ++j)
+                for (int i = 0; i < 3; ++i) Sm.a[i][j] = sm[i + 3 * j];
+            for (int q = 0; q < nspec; ++q)
+                if (active[q]) {
+                    const double v = Dl_lookup[(l - lmin_lookup) + nl * (q + (int64_t)nspec * im)] /
+                                     ((double)l * (l + 1) / 2.0 / M_PI * RJ2unit[pi_[q]] * RJ2unit[pj_[q]]);
+                    Sm.a[pi_[q]][pj_[q]] = Sm.a[pj_[q]][pi_[q]] = v;
+                }
+            for (int i = 0; i < 3; ++i)
+                if (Sm.a[i][i] == 0.0) Sm.a[i][i] = 1.0;
+            double ln_det;
+            if (!inv_chol(Sm, ln_det)) {
+                lnL[im] = -1e30;               // assigned, not accumulated: later multipoles keep adding (:1094-1103)
+            } else {
+                double sig[3][3];
+                for (int q = 0; q < nspec; ++q) sig[pi_[q]][pj_[q]] = sig[pj_[q]][pi_[q]] = sigma_l[l + ld * q];
+                for (int i = 0; i < 3; ++i)
+                    if (sig[i][i] == 0.0) sig[i][i] = 1.0;
+                double tr = 0.0;
+                for (int i = 0; i < 3; ++i)
+                    for (int j = 0; j < 3; ++j) tr += sig[i][j] * Sm.a[j][i];
+                lnL[im] -= 0.5 * ((double)(2 * l + 1) * ln_det + (double)(2 * l + 1) * tr);
+            }
+        }
+    }
+    bool all_bad = true;
+    for (double v : lnL) all_bad = all_bad && v == -1e30;
+    if (all_bad) return 1;
+    const double mx = *std::max_element(lnL.begin(), lnL.end());
+    double sum = 0.0;
+    std::vector<double> P(nmodel);
+    for (int i = 0; i < nmodel; ++i) { P[i] = lnL[i] > -1e30 ? std::exp(lnL[i] - mx) : 0.0; sum += P[i]; }
+    for (double& v : P) v /= sum;
+    double w = 0.0;
+    int pick = 0;
+    while (w < uniform && pick < nmodel) { w += P[pick]; ++pick; }   // 1-based model index, as the reference's i
+    if (pick == 0) pick = 1;                                         // uniform == 0: the reference would read lnL(0)
+    for (int l = lmin_lookup; l <= lmax_lookup; ++l)
+        for (int q = 0; q < nspec; ++q)
+            if (active[q]) Dl[l + ld * q] = Dl_lookup[(l - lmin_lookup) + nl * (q + (int64_t)nspec * (pick - 1))];
+    if (chosen) *chosen = pick - 1;
+    return 0;
+}
+
 }  // namespace cmdr

@@ -85,6 +85,8 @@ def _sig(L):
     L.cmdr_cl_update_S.argtypes = [c_int, c_int, c_int, dp, dp, dp, dp, dp]
     L.cmdr_cl_sample_binned.argtypes = [c_int, c_int, dp, dp, dp, c_int, ctypes.POINTER(ClBin), dp, c_int, dp,
                                         ctypes.POINTER(c_int)]
+    L.cmdr_cl_sample_lookup.argtypes = [c_int, c_int, c_int, c_int, dp, ctypes.POINTER(c_int), dp, dp, dp, ctypes.c_double, dp,
+                                        ctypes.POINTER(c_int)]
     L.cmdr_cl_apod.argtypes = [c_int, c_int, c_int, c_int, c_int]
     L.cmdr_cl_apod.restype = ctypes.c_double
     L.cmdr_cl_apply_apod.argtypes = [c_int, c_int, c_int, c_int, dp, dp, dp]

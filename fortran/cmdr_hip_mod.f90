@@ -219,6 +219,19 @@ module cmdr_hip_mod
        integer(c_int)              :: ierr
      end function cmdr_cl_update_S
 
+     ! sample_Dl_lookup (comm_Cl_mod.f90:1063-1145): one rand_uni(handle) in `uniform`; chosen = 0-based model index
+     function cmdr_cl_sample_lookup(lmax, lmin_lookup, lmax_lookup, nmodel, Dl_lookup, active, sigma_l, S_mat, RJ2unit, &
+          & uniform, Dl, chosen) bind(c, name='cmdr_cl_sample_lookup') result(ierr)
+       import :: c_int, c_double
+       integer(c_int), value         :: lmax, lmin_lookup, lmax_lookup, nmodel
+       real(c_double), intent(in)    :: Dl_lookup(*), sigma_l(*), S_mat(*), RJ2unit(*)
+       integer(c_int), intent(in)    :: active(6)
+       real(c_double), value         :: uniform
+       real(c_double), intent(inout) :: Dl(*)
+       integer(c_int), intent(out)   :: chosen
+       integer(c_int)                :: ierr
+     end function cmdr_cl_sample_lookup
+
      ! get_Cl_apod folded into the tables handed to cmdr_comp_add / cmdr_comp_set_cl (comm_Cl_mod.f90:572-704)
      function cmdr_cl_apply_apod(lmax, nmaps, l_apod, lmax_prior, sqrtS_mat, sqrtInvS_mat, S_mat) &
           & bind(c, name='cmdr_cl_apply_apod') result(ierr)

@@ -220,6 +220,14 @@ int cmdr_cl_update_S(int lmax, int nmaps, int lmin, const double* Dl, const doub
                      double* sqrtInvS_mat, double* S_mat);
 int cmdr_cl_sample_binned(int lmax, int nmaps, const double* sigma_l, const double* S_mat, const double* RJ2unit, int nbin,
                           const cmdr_cl_bin* bins, const double* uniform, int nuniform, double* Dl, int* nused);
+/* sample_Dl_lookup, the table branch of the binned sampler (comm_Cl_mod.f90:1063-1145; runs before the bins when
+ * lmin_lookup >= 0): nmodel tabulated spectra Dl_lookup(lmin_lookup:lmax_lookup, 6, nmodel), active(6) = which of
+ * TT,TE,TB,EE,EB,BB they replace; one of them is drawn with probability proportional to its inverse-Wishart likelihood
+ * given sigma_l, using ONE uniform variate, and copied into Dl.  Polarised components (nmaps = 3) only, like the
+ * reference.  *chosen = 0-based model index.  Returns 0, 1 (every model failed: ok = .false.), < 0 on error. */
+int cmdr_cl_sample_lookup(int lmax, int lmin_lookup, int lmax_lookup, int nmodel, const double* Dl_lookup,
+                          const int* active, const double* sigma_l, const double* S_mat, const double* RJ2unit,
+                          double uniform, double* Dl, int* chosen);
 /* get_Cl_apod (comm_Cl_mod.f90:676-704): the per-l factor matmulSqrtS / matmulS / matmulSqrtInvS / getCl apply on top of
  * the updateS tables (:572-666, :1454) -- not 1 for l < COMP_PRIOR_AMP_LMAX (cs_lmax_amp_prior, :134).  The solver context
  * takes tables with the factor folded in: cmdr_cl_apply_apod scales sqrtS_mat by f, S_mat by f^2 and sqrtInvS_mat by 1/f

@@ -9,8 +9,8 @@ this file follows the reference text line by line with numpy / LAPACK (numpy.lin
 Follows
   * comm_Cl%updateS                    commander3/src/comm_Cl_mod.f90:316-384
   * compute_hermitian_root             commander3/src/math_tools.f90:606-662
-  * sample_Cls_inverse_wishart2        commander3/src/comm_Cl_mod.f90:1008-1249 (sample_Dl_bin, lnL_invWishart;
-                                       the `lookup` branch is not restated)
+  * sample_Cls_inverse_wishart2        commander3/src/comm_Cl_mod.f90:1008-1249 (sample_Dl_lookup, sample_Dl_bin,
+                                       lnL_invWishart)
   * sample_InvSamp                     commander3/src/InvSamp_mod.f90:35-294
   * spline_plain / splint_plain        commander3/src/spline_1D_mod.f90:109-172, locate_dp: locate_mod.f90:69-102
   * invert_matrix(cholesky, ln_det)    commander3/src/math_tools.f90:76-152
@@ -312,3 +312,41 @@ def sample_cls_binned(Dl, sigma_l_vec, S_mat, RJ2unit, bins, uniforms):
             return False, used
         Dl[lo:hi + 1, spec - 1] = s
     return True, used
+
+
+def sample_cls_lookup(Dl, Dl_lookup, lmin_lookup, active, sigma_l_vec, S_mat, RJ2unit, eta):
+    """sample_Dl_lookup (comm_Cl_mod.f90:1063-1145).  Dl_lookup[(nl), 6, nmodel]; active: 6 flags; Dl updated in place.
+    Returns (ok, chosen 0-based model index)."""
+    nl, nspec, n = Dl_lookup.shape
+    pairs = spec_pairs(3)
+    sig = sigma_l_matrix(np.asarray(sigma_l_vec), 3)
+    RJ = np.asarray(RJ2unit, dtype=np.float64)
+    lnL = np.zeros(n)
+    for i in range(n):
+        for l in range(lmin_lookup, lmin_lookup + nl):
+            S = S_mat[:, :, l].copy()
+            for m, (j, k) in enumerate(pairs):
+                if active[m]:
+                    S[j, k] = S[k, j] = Dl_lookup[l - lmin_lookup, m, i] / (l * (l + 1) / 2.0 / np.pi * RJ[j] * RJ[k])
+            for j in range(3):
+                if S[j, j] == 0.0:
+                    S[j, j] = 1.0
+            Si, status, ln_det = _inv_chol(S)
+            if status != 0:
+                lnL[i] = -1e30
+            else:
+                lnL[i] = lnL[i] - 0.5 * ((2 * l + 1) * ln_det + (2 * l + 1) * np.sum(sig[:, :, l] * Si.T))
+    if np.all(lnL == -1e30):
+        return False, -1
+    P = np.where(lnL > -1e30, np.exp(lnL - lnL.max()), 0.0)
+    P = P / P.sum()
+    w, i = 0.0, 0
+    while w < eta:
+        w += P[i]
+        i += 1
+    i = max(i, 1)
+    for l in range(lmin_lookup, lmin_lookup + nl):
+        for m in range(6):
+            if active[m]:
+                Dl[l, m] = Dl_lookup[l - lmin_lookup, m, i - 1]
+    return True, i - 1
