@@ -170,6 +170,7 @@ int CrSystem::add_comp(int lmax_amp, int nmaps, int lmax_cl, const double* sqrtS
     C.F_map.resize(bands_.size());
     C.F_map_nm.assign(bands_.size(), 0);
     C.mulF.resize(bands_.size());
+    C.mulF_dirty.assign(bands_.size(), 1);
     order_.push_back({0, (int)comps_.size() - 1});
     return (int)comps_.size() - 1;
 }
@@ -374,6 +375,7 @@ void CrSystem::set_mixing_map(int comp, int band, const double* F, int nmaps) {
         const int64_t np = band_npix(band);
         C.F_map[band].assign(F, F + np * nm);
         C.F_map_nm[band] = nm;
+        C.mulF_dirty[band] = 1;
     }
     if (finalized_) {
         sync();
@@ -455,10 +457,13 @@ void CrSystem::rebuild_mixing() {
                 const int b = G.bands[ib];
                 if (C.F_map[b].empty()) { C.mulF[b] = DevBuf<double>(); continue; }
                 const int nm = C.F_map_nm[b];
-                std::vector<double> mf((size_t)np * nm);
-                for (int j = 0; j < nm; ++j)
-                    for (int64_t i = 0; i < np; ++i) mf[(size_t)j * np + i] = C.F_map[b][(size_t)j * np + i] * pw[i];
-                C.mulF[b].upload(mf);
+                if (C.mulF_dirty[b] || C.mulF[b].size() != (size_t)np * nm) {   // a change of sampling group keeps the maps
+                    std::vector<double> mf((size_t)np * nm);
+                    for (int j = 0; j < nm; ++j)
+                        for (int64_t i = 0; i < np; ++i) mf[(size_t)j * np + i] = C.F_map[b][(size_t)j * np + i] * pw[i];
+                    C.mulF[b].upload(mf);
+                    C.mulF_dirty[b] = 0;
+                }
                 if (!C.d.active) continue;                      // comm_cr_mod.f90:851-854
                 T.push_back({ib, c, 0});
                 if (nm == 3) {

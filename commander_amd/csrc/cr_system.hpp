@@ -123,6 +123,7 @@ class CrSystem {
         std::vector<std::vector<double>> F_map;  // [nband]: empty, or npix_local x nm host copy of F(band,0)%p%map
         std::vector<int> F_map_nm;
         std::vector<DevBuf<double>> mulF;        // [nband]: F * W_ring 4pi/Npix (device), built by rebuild_mixing
+        std::vector<char> mulF_dirty;            // [nband]: the host map changed since mulF was uploaded
         std::vector<double> cl_diag;             // optional getCl table
     };
     struct CompactBand {                         // P_b of one block on one band, both orientations

@@ -411,3 +411,26 @@ def test_fortran_module_binds_every_abi_symbol():
     assert len(names) > 60
     missing = [n for n in names if "name='%s'" % n not in mod]
     assert not missing, missing
+
+
+def test_emul_mixing_map_update_and_sampling_group_switch(EL):
+    """A chain updates mixing maps (spectral-index sampling) and switches sampling groups between solves: a new map
+    must reach the device, a mere change of the active flags must not disturb the maps that are there."""
+    from commander_amd.cr import build_context
+    spec = _varying_spec(8, 16)
+    ctx = build_context(spec, _lib=EL)
+    rng = np.random.default_rng(22)
+    x = rng.standard_normal(ctx.ncr)
+    assert rel(ctx.cr_matmulA(x), oracle_system(spec).matmulA(x)) < 1e-12
+    # new map on band 1 after finalize
+    spec["comps"][1]["F_map"][1] = spec["comps"][1]["F_map"][1] * (1.0 + 0.3 * rng.random(spec["comps"][1]["F_map"][1].shape))
+    ctx.set_mixing_map(1, 1, spec["comps"][1]["F_map"][1])
+    y1 = ctx.cr_matmulA(x)
+    assert rel(y1, oracle_system(spec).matmulA(x)) < 1e-12
+    # sampling group without / with the varying component: flags only
+    ctx.set_active(1, False)
+    spec["comps"][1]["active"] = False
+    assert rel(ctx.cr_matmulA(x), oracle_system(spec).matmulA(x)) < 1e-12
+    ctx.set_active(1, True)
+    spec["comps"][1]["active"] = True
+    assert np.array_equal(ctx.cr_matmulA(x), y1)
