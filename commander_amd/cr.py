@@ -278,6 +278,22 @@ class CRContext:
                                       None if mm is None else _p(mm), _p(rhs)), self.L)
         return rhs
 
+    def compute_residual(self, amp, data):
+        """``compute_residual(band, cg_samp_group)`` for every band (comm_chisq_mod.f90:196-267): data minus the signal
+        of the components OUTSIDE the sampling group (active flag not set), from their amplitudes ``amp`` (ncr, stacked,
+        physical units).  Returns the list of residual maps."""
+        arr = _dp * self.nband
+        keep, din, dout = [], [], []
+        for b, m in enumerate(data):
+            a = _f(np.asarray(m, dtype=np.float64).reshape(self.band_shape[b]))
+            o = np.zeros(self.band_shape[b], order="F")
+            keep += [a, o]
+            din.append(_p(a)); dout.append(_p(o))
+        av = np.ascontiguousarray(amp, dtype=np.float64)
+        assert av.shape == (self.ncr,)
+        check(self.L.cmdr_compute_residual(self._h, _p(av), arr(*din), arr(*dout)), self.L)
+        return keep[1::2]
+
     def solve_cr_eqn_by_CG(self, b, conv_crit="fixed_iter", tol=1e-8, miniter=5, maxiter=40, check_freq=1, x0=None):
         """Returns (x, niter, stat, (delta_new, delta0)); x already multiplied by sqrt(S)."""
         b = np.ascontiguousarray(b, dtype=np.float64)

@@ -504,6 +504,39 @@ int cmdr_compute_rhs(cmdr_ctx* ctx, int sample, const double* const* resid, cons
     });
 }
 
+int cmdr_compute_residual_dev(cmdr_ctx* ctx, const double* amp, const double* const* data, double* const* resid) {
+    return guarded([&] {
+        CMDR_REQUIRE(ctx && amp && data && resid, "bad arguments");
+        ctx->sys->compute_residual(amp, data, resid);
+        CMDR_HIP_CHECK(hipGetLastError());
+        ctx->sys->sync();
+    });
+}
+int cmdr_compute_residual(cmdr_ctx* ctx, const double* amp, const double* const* data, double* const* resid) {
+    return guarded([&] {
+        CMDR_REQUIRE(ctx && amp && data && resid, "bad arguments");
+        const int nb = ctx->sys->nband();
+        const size_t n = (size_t)ctx->sys->ncr();
+        ctx->hmaps.resize(2 * (size_t)nb);
+        std::vector<const double*> dd(nb);
+        std::vector<double*> dr(nb);
+        std::vector<size_t> tot(nb);
+        for (int b = 0; b < nb; ++b) {
+            tot[b] = (size_t)ctx->sys->band_npix(b) * (size_t)ctx->sys->band_nmaps(b);
+            ctx->hmaps[2 * b].ensure(tot[b]);
+            ctx->hmaps[2 * b + 1].ensure(tot[b]);
+            CMDR_HIP_CHECK(hipMemcpy(ctx->hmaps[2 * b].get(), data[b], tot[b] * sizeof(double), hipMemcpyHostToDevice));
+            dd[b] = ctx->hmaps[2 * b].get();
+            dr[b] = ctx->hmaps[2 * b + 1].get();
+        }
+        ctx->hx.ensure(n);
+        CMDR_HIP_CHECK(hipMemcpy(ctx->hx.get(), amp, n * sizeof(double), hipMemcpyHostToDevice));
+        if (cmdr_compute_residual_dev(ctx, ctx->hx.get(), dd.data(), dr.data()) != 0) throw cmdr::Error(g_err);
+        for (int b = 0; b < nb; ++b)
+            CMDR_HIP_CHECK(hipMemcpy(resid[b], dr[b], tot[b] * sizeof(double), hipMemcpyDeviceToHost));
+    });
+}
+
 int cmdr_solve_dev(cmdr_ctx* ctx, const double* b, double* x, int crit, double tol, int miniter, int maxiter,
                    int check_freq, const double* x0, int* niter, double* res, int* stat) {
     return guarded([&] {

@@ -822,6 +822,49 @@ void CrSystem::matmulA(const double* x, double* y) {
     span_end();
 }
 
+// compute_residual(band, cg_samp_group) (comm_chisq_mod.f90:196-267): resid_b = data_b - Y sum_{c not in the group}
+// getBand_c(alm) - sum_{compact c not in the group} getBand_c, from the components' own amplitudes in stacked layout
+// (cr_amp2x order, physical units: no S^-1/2).  The forward half of the matvec with the active flags inverted.
+void CrSystem::flip_active() {
+    for (Comp& C : comps_) C.d.active = C.d.active ? 0 : 1;
+    for (Compact& K : compacts_) K.active = K.active ? 0 : 1;
+    std::vector<CompDev> cd;
+    for (Comp& C : comps_) cd.push_back(C.d);
+    comps_dev_.upload(cd);
+    rebuild_weights();
+    rebuild_mixing();
+}
+
+void CrSystem::compute_residual(const double* amp, const double* const* data, double* const* resid) {
+    CMDR_REQUIRE(finalized_, "finalize first");
+    const int ncomp = (int)comps_.size();
+    sync();
+    flip_active();
+    for (Group& G : groups_) {
+        ShtPlan& P = *G.plan;
+        const int64_t np = P.npix_local();
+        const double* extra = nullptr;
+        if (!G.mix.empty()) { mix_forward(G, amp); extra = G.E.get(); }
+        launch_band_prep(comps_dev_.get(), ncomp, amp, G.w.get(), G.bm_stokes_dev.get(), P.stream(), P.leg().cnorm.get(),
+                         G.lmax, G.nT, stream_, extra);
+        if (G.npol)
+            launch_band_prep2(comps_dev_.get(), ncomp, amp, G.w.get(), G.nT, P.stream2(), G.npol, P.leg2().cnorm.get(),
+                              G.lmax, stream_, extra);
+        G.tmpmap.ensure((size_t)G.nbm * np);
+        P.synth_from_stream(G.nT, stream_);
+        if (G.npol) P.synth2_from_stream(G.npol, G.nT, stream_);
+        P.rings(0, G.tmpmap.get(), np, nullptr, false, G.nbm, stream_);        // res%Y()
+        compact_forward(G, amp, G.tmpmap.get());                               // + ptsrc%map
+        for (int bm = 0; bm < G.nbm; ++bm) {
+            const int b = G.bm_band[bm], j = G.bm_stokes[bm];
+            launch_axpby(data[b] + (int64_t)j * np, G.tmpmap.get() + (int64_t)bm * np, -1.0, resid[b] + (int64_t)j * np, np,
+                         stream_);
+        }
+    }
+    sync();
+    flip_active();
+}
+
 // ------------------------------------------------------------------------------------------------- RHS
 void CrSystem::compute_rhs(bool sample, const double* const* resid, const double* const* xi, const double* eta,
                            const double* mu, double* rhs) {

@@ -59,6 +59,7 @@ class CrSystem {
     void set_comp_cl(int comp, const double* sqrtS, const double* sqrtInvS, const double* S);
     void set_comp_f_mean(int comp, const double* F_mean);
     void set_active(int kind, int idx, int active);
+    void compute_residual(const double* amp, const double* const* data, double* const* resid);   // device pointers
     void set_cl_diag(int comp, const double* cl);   // getCl(l, p): (lmax_cl+1) x nmaps, for the pseudo-inverse U
     void set_allreduce(AllreduceFn fn, void* user) { allreduce_ = fn; allreduce_user_ = user; }
     void set_allreduce_stream(AllreduceStreamFn fn, void* user) { allreduce_s_ = fn; allreduce_s_user_ = user; }
@@ -174,6 +175,7 @@ class CrSystem {
     void qucov_invN(Group& G, int band, double* maps);   // maps(T) = 0, maps(Q;U) = iN maps(Q;U)
     DevBuf<double> qucov_tmp_, qucov_tmp2_;
     void rebuild_weights();
+    void flip_active();
     void rebuild_mixing();
     void mix_forward(Group& G, const double* sx);
     void mix_adjoint(Group& G, bool rhs);

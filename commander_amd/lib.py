@@ -96,6 +96,8 @@ def _sig(L):
     L.cmdr_invM_dev.argtypes = [c_vp, c_vp, c_vp]
     L.cmdr_compute_rhs.argtypes = [c_vp, c_int, pdp, pdp, dp, dp, dp]
     L.cmdr_compute_rhs_dev.argtypes = [c_vp, c_int, pvp, pvp, c_vp, c_vp, c_vp]
+    L.cmdr_compute_residual.argtypes = [c_vp, dp, pdp, pdp]
+    L.cmdr_compute_residual_dev.argtypes = [c_vp, c_vp, pvp, pvp]
     pint = ctypes.POINTER(c_int)
     L.cmdr_sigma_l.argtypes = [dp, c_int, c_int, dp]
     L.cmdr_sigma_l_dev.argtypes = [c_vp, c_i64, c_int, c_int, c_vp]

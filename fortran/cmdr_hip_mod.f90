@@ -254,6 +254,22 @@ module cmdr_hip_mod
        integer(c_int)                 :: ierr
      end function cmdr_cl_sample_binned
 
+     ! compute_residual (comm_chisq_mod.f90:196-267) for every band; data / resid: arrays of c_loc(map) per band
+     function cmdr_compute_residual(ctx, amp, data, resid) bind(c, name='cmdr_compute_residual') result(ierr)
+       import :: c_int, c_ptr, c_double
+       type(c_ptr),    value      :: ctx
+       real(c_double), intent(in) :: amp(*)
+       type(c_ptr),    intent(in) :: data(*), resid(*)
+       integer(c_int)             :: ierr
+     end function cmdr_compute_residual
+
+     function cmdr_compute_residual_dev(ctx, amp_dev, data_dev, resid_dev) bind(c, name='cmdr_compute_residual_dev') result(ierr)
+       import :: c_int, c_ptr
+       type(c_ptr), value      :: ctx, amp_dev
+       type(c_ptr), intent(in) :: data_dev(*), resid_dev(*)
+       integer(c_int)          :: ierr
+     end function cmdr_compute_residual_dev
+
      function cmdr_matmulA(ctx, x, y) bind(c, name='cmdr_matmulA') result(ierr)
        import :: c_int, c_ptr, c_double
        type(c_ptr),    value       :: ctx

@@ -172,6 +172,14 @@ int cmdr_compute_rhs(cmdr_ctx* ctx, int sample, const double* const* resid, cons
                      const double* eta, const double* mu, double* rhs);
 int cmdr_compute_rhs_dev(cmdr_ctx* ctx, int sample, const double* const* resid_dev, const double* const* xi_dev,
                          const double* eta_dev, const double* mu_dev, double* rhs_dev);
+/* compute_residual(band, cg_samp_group) for every band (comm_chisq_mod.f90:196-267, called at comm_cr_mod.f90:568):
+ *   resid[i] = data[i] - signal of the components whose active flag is NOT set (those outside the sampling group),
+ * i.e. Y of the summed c%getBand(alm_out) of the diffuse ones plus the pixel-space getBand of templates / point sources.
+ * amp = the components' own amplitudes c%x in the stacked layout of cr_amp2x, physical units (before S^-1/2);
+ * data[i], resid[i]: [npix_local x nmaps] like the maps of cmdr_compute_rhs. */
+int cmdr_compute_residual(cmdr_ctx* ctx, const double* amp, const double* const* data, double* const* resid);
+int cmdr_compute_residual_dev(cmdr_ctx* ctx, const double* amp_dev, const double* const* data_dev,
+                              double* const* resid_dev);
 /* solve_cr_eqn_by_CG (comm_cr_mod.f90:48-406).  crit: 0 'residual', 1 'fixed_iter' (cpar%cg_conv_crit);
  * tol = cg_tol, miniter = cg_miniter, maxiter = cg_samp_group_maxiter, check_freq = cg_check_conv_freq;
  * x0 = NULL <=> cg_init_zero, else the current amplitudes (cr_amp2x).  On return x is already multiplied by

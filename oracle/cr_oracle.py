@@ -359,6 +359,33 @@ class CRSystem:
             m = m * c.F_mean[ib, :nmaps]
         return healpix.alm_equal(m, b.info, c.info, nmaps_dst=c.nmaps)
 
+    # ------------------------------------------------------------------ compute_residual
+    def compute_residual(self, data, amp):
+        """commander3/src/comm_chisq_mod.f90:196-267 with cg_samp_group given: for every band, the data map minus the
+        signal of the components that are NOT active in the sampling group.  amp: stacked amplitudes (c%x, physical
+        units); data[i]: (npix, nmaps).  Returns the list of residual maps."""
+        out = []
+        for ib, b in enumerate(self.bands):
+            res_alm = np.zeros((b.info.nalm, b.nmaps))
+            ptsrc = np.zeros(b.npix * b.nmaps)
+            nonzero = False
+            for k, c in enumerate(self.comps):
+                if c.active:                                             # :228-230 skip the group's own components
+                    continue
+                if isinstance(c, CompactBlock):                          # :246-257 pixel-space getBand
+                    if ib in c.P:
+                        pos, n, _ = self.ind_comp[k]
+                        ptsrc += c.P[ib] @ amp[pos:pos + n]
+                    continue
+                alm = self.extract(k, amp)
+                pm = healpix.alm_equal(alm, c.info, b.info, nmaps_dst=b.nmaps)   # getBand: self%x%alm_equal(m)
+                res_alm += self.getBand_alm(c, ib, pm)                   # :238-241
+                nonzero = True
+            mp = self._Y(b, res_alm, b.lmax) if nonzero else np.zeros((b.npix, b.nmaps))   # :260
+            d = np.asarray(data[ib], dtype=np.float64).reshape(b.npix, b.nmaps)
+            out.append(d - mp - ptsrc.reshape(b.nmaps, b.npix).T)        # :263
+        return out
+
     # ------------------------------------------------------------------ cr_matmulA
     def matmulA(self, x):
         """commander3/src/comm_cr_mod.f90:771-1024."""

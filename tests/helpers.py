@@ -248,3 +248,40 @@ def gibbs_loop_checks(_lib=None, nside=16, lmax=32, tol=1e-7):
     # new mixing: the reference sets recompute_diffuse_precond and runs initPrecond again before the next solve
     ctx.initPrecond(); ctx.update_precond(); S.init_precond_diag(); S.update_precond_diag()
     assert rel(ctx.cr_invM(xt), S.invM(xt)) < 10 * tol
+
+
+def residual_checks(_lib=None, nside=8, lmax=16, tol=1e-11):
+    """compute_residual(cg_samp_group) through the product against the oracle: components outside the sampling group
+    (constant mixing, spatially varying mixing, a template + point-source block) are subtracted from the data; the
+    group's own components are not; afterwards the solver context is back in its state (same matvec)."""
+    from commander_amd import synth, healpix
+    from commander_amd.cr import build_context
+    rng = np.random.default_rng(31)
+    for pol in (False, True):
+        spec = synth.make_problem("cfg2", nside=nside, lmax=lmax, pol=pol, comp_lmax=[lmax, lmax - 4])
+        nm = 3 if pol else 1
+        z = healpix.pix_z(nside)
+        spec["comps"][1]["F_map"] = {ib: np.repeat(((b["nu"] / 30.0) ** (-3.1 + 0.1 * z))[:, None], nm, axis=1)
+                                     for ib, b in enumerate(spec["bands"])}
+        synth.add_compact_blocks(spec, nsrc=3)
+        # sampling group = CMB only: synchrotron (varying mixing) and the compact blocks are "the rest of the sky model"
+        for c in spec["comps"][1:]:
+            c["active"] = False
+        S = oracle_system(spec)
+        ctx = build_context(spec, _lib=_lib)
+        amp = rng.standard_normal(ctx.ncr)
+        data = [rng.standard_normal(b["siN"].shape if pol else (len(b["siN"]), 1)) for b in spec["bands"]]
+        x = rng.standard_normal(ctx.ncr)
+        y0 = ctx.cr_matmulA(x)
+        got = ctx.compute_residual(amp, data)
+        want = S.compute_residual(data, amp)
+        for g, w, d in zip(got, want, data):
+            assert rel(g, w) < tol, (pol, rel(g, w))
+            assert rel(g, d.reshape(g.shape)) > 1e-3           # something was subtracted
+        assert np.array_equal(ctx.cr_matmulA(x), y0)            # flags, weights and mixing batches restored
+        # nothing outside the group -> the data come back unchanged
+        for c in spec["comps"]:
+            c["active"] = True
+        ctx2 = build_context(spec, _lib=_lib)
+        for g, d in zip(ctx2.compute_residual(amp, data), data):
+            assert np.array_equal(g, d.reshape(g.shape))

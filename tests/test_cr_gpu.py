@@ -300,3 +300,11 @@ def test_context_lifecycle_releases_device_memory_gpu():
         ctx.close()
         levels.append(device_mem_info()[0])
     assert abs(levels[-1] - levels[1]) < 16 << 20, [(v - levels[1]) >> 20 for v in levels]
+
+
+@pytest.mark.gpu
+def test_compute_residual_gpu():
+    """compute_residual(cg_samp_group) on the GPU (Nside 16, lmax 32; T and T,Q,U; constant and varying mixing, compact
+    blocks outside the group) against the oracle."""
+    from helpers import residual_checks
+    residual_checks(None, nside=16, lmax=32)

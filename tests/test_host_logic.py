@@ -434,3 +434,8 @@ def test_emul_mixing_map_update_and_sampling_group_switch(EL):
     ctx.set_active(1, True)
     spec["comps"][1]["active"] = True
     assert np.array_equal(ctx.cr_matmulA(x), y1)
+
+
+def test_emul_compute_residual_vs_oracle(EL):
+    from helpers import residual_checks
+    residual_checks(EL)
