@@ -17,7 +17,7 @@ _vp = ctypes.c_void_p
 ALLREDUCE_CB = ctypes.CFUNCTYPE(None, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64)
 ALLREDUCE_STREAM_CB = ctypes.CFUNCTYPE(None, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64, ctypes.c_void_p)
 
-CRIT = {"residual": 0, "fixed_iter": 1}  # cpar%cg_conv_crit (comm_cr_mod.f90:220-229); 'chisq' is not on this path
+CRIT = {"residual": 0, "fixed_iter": 1, "chisq": 2}  # cpar%cg_conv_crit (comm_cr_mod.f90:220-229)
 
 
 def _f(a):

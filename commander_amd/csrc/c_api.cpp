@@ -541,7 +541,7 @@ int cmdr_solve_dev(cmdr_ctx* ctx, const double* b, double* x, int crit, double t
                    int check_freq, const double* x0, int* niter, double* res, int* stat) {
     return guarded([&] {
         CMDR_REQUIRE(ctx && b && x, "bad arguments");
-        CMDR_REQUIRE(crit == 0 || crit == 1, "crit must be 0 (residual) or 1 (fixed_iter)");
+        CMDR_REQUIRE(crit >= 0 && crit <= 2, "crit must be 0 (residual), 1 (fixed_iter) or 2 (chisq)");
         const cmdr::SolveResult R = ctx->sys->solve(b, x, crit, tol, miniter, maxiter, check_freq, x0);
         if (niter) *niter = R.niter;
         if (stat) *stat = R.stat;

@@ -835,26 +835,33 @@ void CrSystem::flip_active() {
     rebuild_mixing();
 }
 
+// band signal maps of the components whose active flag is set, into G.tmpmap [nbm][npix_local]:
+// Y sum_c getBand_c(alm) + pixel-space getBand of the compact ones; sx = amplitudes as they enter getBand
+void CrSystem::forward_maps(Group& G, const double* sx) {
+    const int ncomp = (int)comps_.size();
+    ShtPlan& P = *G.plan;
+    const int64_t np = P.npix_local();
+    const double* extra = nullptr;
+    if (!G.mix.empty()) { mix_forward(G, sx); extra = G.E.get(); }
+    launch_band_prep(comps_dev_.get(), ncomp, sx, G.w.get(), G.bm_stokes_dev.get(), P.stream(), P.leg().cnorm.get(),
+                     G.lmax, G.nT, stream_, extra);
+    if (G.npol)
+        launch_band_prep2(comps_dev_.get(), ncomp, sx, G.w.get(), G.nT, P.stream2(), G.npol, P.leg2().cnorm.get(), G.lmax,
+                          stream_, extra);
+    G.tmpmap.ensure((size_t)G.nbm * np);
+    P.synth_from_stream(G.nT, stream_);
+    if (G.npol) P.synth2_from_stream(G.npol, G.nT, stream_);
+    P.rings(0, G.tmpmap.get(), np, nullptr, false, G.nbm, stream_);
+    compact_forward(G, sx, G.tmpmap.get());
+}
+
 void CrSystem::compute_residual(const double* amp, const double* const* data, double* const* resid) {
     CMDR_REQUIRE(finalized_, "finalize first");
-    const int ncomp = (int)comps_.size();
     sync();
     flip_active();
     for (Group& G : groups_) {
-        ShtPlan& P = *G.plan;
-        const int64_t np = P.npix_local();
-        const double* extra = nullptr;
-        if (!G.mix.empty()) { mix_forward(G, amp); extra = G.E.get(); }
-        launch_band_prep(comps_dev_.get(), ncomp, amp, G.w.get(), G.bm_stokes_dev.get(), P.stream(), P.leg().cnorm.get(),
-                         G.lmax, G.nT, stream_, extra);
-        if (G.npol)
-            launch_band_prep2(comps_dev_.get(), ncomp, amp, G.w.get(), G.nT, P.stream2(), G.npol, P.leg2().cnorm.get(),
-                              G.lmax, stream_, extra);
-        G.tmpmap.ensure((size_t)G.nbm * np);
-        P.synth_from_stream(G.nT, stream_);
-        if (G.npol) P.synth2_from_stream(G.npol, G.nT, stream_);
-        P.rings(0, G.tmpmap.get(), np, nullptr, false, G.nbm, stream_);        // res%Y()
-        compact_forward(G, amp, G.tmpmap.get());                               // + ptsrc%map
+        const int64_t np = G.plan->npix_local();
+        forward_maps(G, amp);                                                  // res%Y() + ptsrc%map
         for (int bm = 0; bm < G.nbm; ++bm) {
             const int b = G.bm_band[bm], j = G.bm_stokes[bm];
             launch_axpby(data[b] + (int64_t)j * np, G.tmpmap.get() + (int64_t)bm * np, -1.0, resid[b] + (int64_t)j * np, np,
@@ -865,11 +872,53 @@ void CrSystem::compute_residual(const double* amp, const double* const* data, do
     flip_active();
 }
 
+// cr_compute_chisq (comm_cr_mod.f90:408-465) -> compute_chisq(chisq_fullsky) (comm_chisq_mod.f90:32-118): with the
+// group's amplitudes set to S^1/2 x, chisq = sum_bands sum_pix (sqrtInvN (d - all signal))^2 = || siN (resid - signal
+// of the group) ||^2, resid = the maps the last cmdr_compute_rhs received.  sqrtInvN here carries no samp-group mask.
+double CrSystem::chisq_of(const double* x) {
+    CMDR_REQUIRE(!last_resid_.empty(), "the chisq criterion needs the residual maps: call cmdr_compute_rhs first");
+    CMDR_REQUIRE(groups_.size() <= 8, "too many plans for the chisq criterion");
+    const int ncomp = (int)comps_.size();
+    launch_sqrtS(comps_dev_.get(), ncomp, lmax_max_, smat_.get(), 0, x, nullptr, sx_.get(), false, stream_);
+    for (Compact& K : compacts_)
+        if (K.active) launch_vec_scale(0, x + K.pos, K.sigma_dev.get(), nullptr, nullptr, sx_.get() + K.pos, K.nparam, stream_);
+    double* scal = scal_.get();
+    int g = 0;
+    for (Group& G : groups_) {
+        const int64_t np = G.plan->npix_local();
+        forward_maps(G, sx_.get());
+        for (int bm = 0; bm < G.nbm; ++bm) {
+            const int b = G.bm_band[bm], j = G.bm_stokes[bm];
+            const Band& B = bands_[b];
+            CMDR_REQUIRE(!B.qucov_iN.size(), "the chisq criterion is not available with QU-covariance bands");
+            double* t = G.tmpmap.get() + (int64_t)bm * np;
+            const double* sraw = (B.siN_raw.size() ? B.siN_raw.get() : B.siN.get()) + (int64_t)j * np;
+            launch_axpby(last_resid_[b] + (int64_t)j * np, t, -1.0, t, np, stream_);
+            launch_pix(0, sraw, t, nullptr, t, np, stream_);
+        }
+        launch_dot(G.tmpmap.get(), G.tmpmap.get(), (int64_t)G.nbm * np, dot_partial_.get(), scal, 4 + g, false, stream_);
+        ++g;
+    }
+    sync();
+    double h[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    CMDR_HIP_CHECK(hipMemcpy(h, scal + 4, sizeof(double) * g, hipMemcpyDeviceToHost));
+    double tot = 0.0;
+    for (int k = 0; k < g; ++k) tot += h[k];
+    if (allreduce_ || allreduce_s_) {       // every (band, pixel) lives on exactly one rank in all sharding layouts
+        CMDR_HIP_CHECK(hipMemcpy(scal + 4, &tot, sizeof(double), hipMemcpyHostToDevice));
+        reduce(scal + 4, 1);
+        sync();
+        CMDR_HIP_CHECK(hipMemcpy(&tot, scal + 4, sizeof(double), hipMemcpyDeviceToHost));
+    }
+    return tot;
+}
+
 // ------------------------------------------------------------------------------------------------- RHS
 void CrSystem::compute_rhs(bool sample, const double* const* resid, const double* const* xi, const double* eta,
                            const double* mu, double* rhs) {
     CMDR_REQUIRE(finalized_, "finalize first");
     const int ncomp = (int)comps_.size();
+    last_resid_.assign(resid, resid + bands_.size());   // the 'chisq' convergence criterion evaluates against these
     for (Compact& K : compacts_) CMDR_HIP_CHECK(hipMemsetAsync(yc_.get() + K.pos, 0, sizeof(double) * K.nparam, stream_));
     for (Group& G : groups_) {
         ShtPlan& P = *G.plan;
@@ -1343,7 +1392,7 @@ SolveResult CrSystem::solve(const double* b, double* x, int crit, double tol, in
                             int check_freq, const double* x0) {
     CMDR_REQUIRE(finalized_ && precond_ready_, "system / preconditioner not ready");
     CMDR_REQUIRE(check_freq >= 1, "check_freq must be >= 1");
-    const bool fixed_iter = (crit == 1);
+    const bool fixed_iter = (crit == 1), by_chisq = (crit == 2);
     const int ncomp = (int)comps_.size();
     const int64_t n = ncr_;
     double* scal = scal_.get();      // [0] delta_new [1] delta_old [2] d.q [3] delta0
@@ -1371,12 +1420,18 @@ SolveResult CrSystem::solve(const double* b, double* x, int crit, double tol, in
     };
     fetch();
     R.delta0 = h[3];
-    const double lim = tol * h[3];                                                      // :220-222
+    const double lim = by_chisq ? tol : tol * h[3];                                     // :220-226
+    double chisq = by_chisq ? chisq_of(x) : 0.0;
     int i = 1;
     for (; i <= maxiter; ++i) {                                                         // :230
         if (i % check_freq == 0 && !fixed_iter) {                                       // :236-247
             fetch();
-            const double val = h[0];
+            double val = h[0];
+            if (by_chisq) {
+                const double prev = chisq;
+                chisq = chisq_of(x);
+                val = std::fabs((prev - chisq) / chisq);
+            }
             if (val < lim && (i >= miniter || h[0] <= 1e-30 * h[3])) break;
         }
         matmulA(d_.get(), q_.get());                                                    // :253

@@ -176,6 +176,9 @@ class CrSystem {
     DevBuf<double> qucov_tmp_, qucov_tmp2_;
     void rebuild_weights();
     void flip_active();
+    void forward_maps(Group& G, const double* sx);
+    double chisq_of(const double* x);
+    std::vector<const double*> last_resid_;
     void rebuild_mixing();
     void mix_forward(Group& G, const double* sx);
     void mix_adjoint(Group& G, bool rhs);

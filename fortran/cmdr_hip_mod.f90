@@ -12,7 +12,7 @@ module cmdr_hip_mod
   implicit none
 
   integer(c_int), parameter :: CMDR_YtW = 0, CMDR_Y = 1, CMDR_Yt = 2, CMDR_WY = 3   ! sharp.f90:8-14
-  integer(c_int), parameter :: CMDR_CRIT_RESIDUAL = 0, CMDR_CRIT_FIXED_ITER = 1      ! cpar%cg_conv_crit
+  integer(c_int), parameter :: CMDR_CRIT_RESIDUAL = 0, CMDR_CRIT_FIXED_ITER = 1, CMDR_CRIT_CHISQ = 2   ! cpar%cg_conv_crit
 
   ! one node of comm_Cl's bins2 tree (comm_Cl_mod.f90:41-47), flattened depth-first; sample /= 0 where stat == 'S'
   type, bind(c) :: cmdr_cl_bin

@@ -737,8 +737,40 @@ class CRSystem:
         return res
 
     # ------------------------------------------------------------------ solve_cr_eqn_by_CG
+    def compute_chisq(self, x, resid):
+        """cr_compute_chisq (comm_cr_mod.f90:408-465) + compute_chisq(chisq_fullsky) (comm_chisq_mod.f90:32-118): the
+        sampling group's amplitudes are set to S^1/2 x, the residual of every band against the whole sky model goes
+        through sqrtInvN (no samp-group mask) and is squared and summed.  resid[i]: compute_residual(i, samp_group)."""
+        sx = x.copy()
+        for k, c in enumerate(self.comps):
+            if not c.active:
+                continue
+            if isinstance(c, CompactBlock):
+                pos, n, _ = self.ind_comp[k]
+                sx[pos:pos + n] *= c.sigma
+            elif c.cltype != "none":
+                self.insert(k, False, c.Cl.sqrtS(self.extract(k, sx), c.info), sx)
+        tot = 0.0
+        for ib, b in enumerate(self.bands):
+            alm = np.zeros((b.info.nalm, b.nmaps))
+            pmap = np.zeros(b.npix * b.nmaps)
+            for k, c in enumerate(self.comps):
+                if not c.active:
+                    continue
+                if isinstance(c, CompactBlock):
+                    if ib in c.P:
+                        pos, n, _ = self.ind_comp[k]
+                        pmap += c.P[ib] @ sx[pos:pos + n]
+                    continue
+                pm = healpix.alm_equal(self.extract(k, sx), c.info, b.info, nmaps_dst=b.nmaps)
+                alm += self.getBand_alm(c, ib, pm)
+            res = np.asarray(resid[ib], dtype=np.float64).reshape(b.npix, b.nmaps) - self._Y(b, alm, b.lmax) \
+                - pmap.reshape(b.nmaps, b.npix).T
+            tot += float(np.sum((b.siN * res) ** 2))
+        return tot
+
     def solve(self, b, conv_crit="fixed_iter", tol=1e-8, miniter=5, maxiter=40, check_freq=1, x0=None,
-              history=None):
+              history=None, resid=None):
         """commander3/src/comm_cr_mod.f90:48-406.  Returns (x, niter, stat); x already multiplied by sqrt(S)."""
         if x0 is None:
             x = np.zeros(self.ncr)                                   # :133-134 cg_init_zero
@@ -757,12 +789,19 @@ class CRSystem:
         delta0 = float(b @ self.invM(b))                             # :208
         lim = tol * delta0                                           # :220-222
         val = 1e2 * lim
+        if conv_crit == "chisq":                                     # :223-226
+            lim, val = tol, 1.0
+            chisq = self.compute_chisq(x, resid)
         i = 1
         stat = 0
         niter = 0
         while i <= maxiter:                                          # :230
             if i % check_freq == 0:                                  # :236-247
                 val = delta_new
+                if conv_crit == "chisq":                             # :239-242
+                    chisq_prev = chisq
+                    chisq = self.compute_chisq(x, resid)
+                    val = abs((chisq_prev - chisq) / chisq)
                 if val < lim and (i >= miniter or delta_new <= 1e-30 * delta0) and conv_crit != "fixed_iter":
                     break
             q = self.matmulA(d)                                      # :253

@@ -285,3 +285,34 @@ def residual_checks(_lib=None, nside=8, lmax=16, tol=1e-11):
         ctx2 = build_context(spec, _lib=_lib)
         for g, d in zip(ctx2.compute_residual(amp, data), data):
             assert np.array_equal(g, d.reshape(g.shape))
+
+
+def chisq_criterion_checks(_lib=None, nside=8, lmax=16):
+    """The 'chisq' convergence criterion (cr_compute_chisq, comm_cr_mod.f90:223-242, 408-465): same stopping iteration
+    and solution as the oracle, T and T,Q,U, with a samp-group mask (chisq is evaluated without it), a component outside
+    the sampling group folded into the residual, and a compact block inside it."""
+    from commander_amd import synth
+    from commander_amd.cr import build_context
+    rng = np.random.default_rng(41)
+    for pol in (False, True):
+        spec = synth.make_problem("cfg2", nside=nside, lmax=lmax, pol=pol)
+        synth.add_compact_blocks(spec, nsrc=2)
+        for b in spec["bands"]:
+            b["sg_mask"] = (rng.random(b["siN"].shape) > 0.2).astype(np.float64)
+        S = oracle_system(spec)
+        ctx = build_context(spec, _lib=_lib)
+        ctx.initPrecond(); ctx.update_precond(); S.init_precond_diag(); S.update_precond_diag()
+        resid, xi, eta = synth.draw_inputs(spec)
+        shp = [np.asarray(b["siN"]).reshape(len(b["siN"]), -1).shape for b in spec["bands"]]
+        rcols = [np.asarray(r, dtype=np.float64).reshape(s) for r, s in zip(resid, shp)]
+        xcols = [np.asarray(r, dtype=np.float64).reshape(s) for r, s in zip(xi, shp)]
+        rhs = ctx.cr_computeRHS("sample", resid, xi, eta)
+        rhso = S.computeRHS(rcols, "sample", xcols, eta)
+        assert rel(rhs, rhso) < 1e-11
+        # limits well above the level where rounding differences between two fp64 CG trajectories decide the test
+        for tol_c, freq in ((1e-2, 1), (1e-4, 2)):
+            xg, ng, sg, _ = ctx.solve_cr_eqn_by_CG(rhs, "chisq", tol_c, 2, 200, freq)
+            xo, no, so = S.solve(rhso, "chisq", tol_c, 2, 200, freq, resid=rcols)
+            assert ng == no and sg == so and 2 <= ng < 200, (pol, tol_c, ng, no)
+            # CG trajectories of two fp64 implementations drift apart at rounding level; the stopping iteration is the check
+            assert rel(xg, xo) < 1e-5, (pol, tol_c, rel(xg, xo))

@@ -308,3 +308,9 @@ def test_compute_residual_gpu():
     blocks outside the group) against the oracle."""
     from helpers import residual_checks
     residual_checks(None, nside=16, lmax=32)
+
+
+@pytest.mark.gpu
+def test_chisq_convergence_criterion_gpu():
+    from helpers import chisq_criterion_checks
+    chisq_criterion_checks(None, nside=16, lmax=32)

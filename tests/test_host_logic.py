@@ -439,3 +439,8 @@ def test_emul_mixing_map_update_and_sampling_group_switch(EL):
 def test_emul_compute_residual_vs_oracle(EL):
     from helpers import residual_checks
     residual_checks(EL)
+
+
+def test_emul_chisq_convergence_criterion(EL):
+    from helpers import chisq_criterion_checks
+    chisq_criterion_checks(EL)
