@@ -58,7 +58,9 @@ def _worker(rank, world, port, out_dir, mode):
     b = ctx.cr_computeRHS("sample", resid, xi, eta)
     sol, n, stat, res = ctx.solve_cr_eqn_by_CG(b, "fixed_iter", 1e-8, 5, 12, 1)
     d0 = ctx.alpha_nu(0) if mode == "varying" else ctx.invN_diag(0)
-    np.savez(os.path.join(out_dir, "rank%d.npz" % rank), y=y, b=b, sol=sol, d0=d0)
+    # the 'chisq' criterion sums squared residuals over the ranks' pixels: same stopping iteration as one rank
+    solc, nc, statc, _ = ctx.solve_cr_eqn_by_CG(b, "chisq", 1e-3, 2, 60, 1)
+    np.savez(os.path.join(out_dir, "rank%d.npz" % rank), y=y, b=b, sol=sol, d0=d0, solc=solc, nc=nc)
     dist.barrier()
     dist.destroy_process_group()
 
@@ -85,8 +87,10 @@ def test_two_rank_ring_sharding_matches_single_rank(tmp_path, mode):
     resid, xi, eta = synth.draw_inputs(spec)
     b = ctx.cr_computeRHS("sample", resid, xi, eta)
     sol, n, stat, res = ctx.solve_cr_eqn_by_CG(b, "fixed_iter", 1e-8, 5, 12, 1)
+    solc, nc, statc, _ = ctx.solve_cr_eqn_by_CG(b, "chisq", 1e-3, 2, 60, 1)
     for r in range(2):
         g = np.load(os.path.join(str(tmp_path), "rank%d.npz" % r))
+        assert int(g["nc"]) == nc and 2 <= nc < 60 and rel(g["solc"], solc) < 1e-8
         assert rel(g["y"], y) < 1e-12
         assert rel(g["b"], b) < 1e-12
         assert rel(g["d0"], ctx.alpha_nu(0) if mode == "varying" else ctx.invN_diag(0)) < 1e-12
