@@ -173,29 +173,47 @@ CMDR_HD void band_prep2_elem(const CompDev* __restrict__ comps, int ncomp, const
 }
 
 // Transpose of band_prep2_elem: component c, Stokes E and B, accumulated into yc (always +=)
-CMDR_HD void band_post2_elem(const CompDev& C, int c, int ncomp, const double* __restrict__ part2,
+CMDR_HD void band_post2_elem(const CompDev* __restrict__ comps, int ncomp, const double* __restrict__ part2,
                              int64_t part_pol_stride, int64_t part_chunk_stride, int nchunk, int npol,
                              const double* __restrict__ w /* [nbm][ncomp][lmax_g+1] */, int nT,
                              const double* __restrict__ cnorm2, int lmax_g, double* __restrict__ yc, int m, int l) {
-    if (C.nmaps < 3 || !C.active || l > lmax_g || l < 2) return;
+    // one thread = one (l, m): the chunk partials of a polarisation pair are read once and feed every component
+    if (l > lmax_g || l < 2) return;
+    constexpr int kMaxComp = 8;
     const int64_t t = d_moffp(lmax_g, m) + (l - m);
-    double s[4] = {0.0, 0.0, 0.0, 0.0};
+    double s[kMaxComp][4];
+    bool use[kMaxComp];
+    bool any = false;
+    for (int c = 0; c < ncomp; ++c) {
+        const CompDev& C = comps[c];
+        use[c] = C.nmaps == 3 && C.active && m <= C.lmax && l <= C.lmax;
+        any = any || use[c];
+        for (int k = 0; k < 4; ++k) s[c][k] = 0.0;
+    }
+    if (!any) return;
     for (int ip = 0; ip < npol; ++ip) {
-        const double we = w[((int64_t)(nT + 2 * ip) * ncomp + c) * (lmax_g + 1) + l];
-        const double wb = w[((int64_t)(nT + 2 * ip + 1) * ncomp + c) * (lmax_g + 1) + l];
         const double* p = part2 + ip * part_pol_stride + 4 * t;
         double a[4] = {0.0, 0.0, 0.0, 0.0};
         for (int ch = 0; ch < nchunk; ++ch)
             for (int k = 0; k < 4; ++k) a[k] += p[ch * part_chunk_stride + k];
-        s[0] += we * a[0]; s[1] += we * a[1]; s[2] += wb * a[2]; s[3] += wb * a[3];
+        for (int c = 0; c < ncomp; ++c) {
+            if (!use[c]) continue;
+            const double we = w[((int64_t)(nT + 2 * ip) * ncomp + c) * (lmax_g + 1) + l];
+            const double wb = w[((int64_t)(nT + 2 * ip + 1) * ncomp + c) * (lmax_g + 1) + l];
+            s[c][0] += we * a[0]; s[c][1] += we * a[1]; s[c][2] += wb * a[2]; s[c][3] += wb * a[3];
+        }
     }
     const double f = -0.5 * cnorm2[t] * (m == 0 ? 1.0 : 1.41421356237309504880);
-    const int64_t i = d_packed_index(C.lmax, l, m);
-    double* e = yc + C.pos + 1 * C.nalm + i;
-    double* b = yc + C.pos + 2 * C.nalm + i;
-    e[0] += s[0] * f;
-    b[0] += s[2] * f;
-    if (m > 0) { e[1] += s[1] * f; b[1] += s[3] * f; }
+    for (int c = 0; c < ncomp; ++c) {
+        if (!use[c]) continue;
+        const CompDev& C = comps[c];
+        const int64_t i = d_packed_index(C.lmax, l, m);
+        double* e = yc + C.pos + 1 * C.nalm + i;
+        double* b = yc + C.pos + 2 * C.nalm + i;
+        e[0] += s[c][0] * f;
+        b[0] += s[c][2] * f;
+        if (m > 0) { e[1] += s[c][1] * f; b[1] += s[c][3] * f; }
+    }
 }
 
 // alm_equal with an optional per-l factor (comm_map_mod.f90:1148-1165 + comm_B_bl_mod.f90:108-127):

@@ -269,10 +269,9 @@ void launch_band_prep2(const CompDev* comps, int ncomp, const double* sx, const 
 }
 void launch_band_post2(const CompDev* comps, int ncomp, int, const double* part2, int64_t pps, int64_t pcs, int nchunk,
                        int npol, const double* w, int nT, const double* cnorm2, int lmax_g, double* yc, hipStream_t) {
-    for (int c = 0; c < ncomp; ++c)
-        for (int m = 0; m <= comps[c].lmax; ++m)
-            for (int l = m; l <= comps[c].lmax; ++l)
-                band_post2_elem(comps[c], c, ncomp, part2, pps, pcs, nchunk, npol, w, nT, cnorm2, lmax_g, yc, m, l);
+    for (int m = 0; m <= lmax_g; ++m)
+        for (int l = m; l <= lmax_g; ++l)
+            band_post2_elem(comps, ncomp, part2, pps, pcs, nchunk, npol, w, nT, cnorm2, lmax_g, yc, m, l);
 }
 void launch_precond_diag(const CompDev* comps, int ncomp, const double* P, int lmax_pre, int nmaps_pre,
                          const double* in, double* out, hipStream_t) {
