@@ -21,7 +21,7 @@ static inline double eps_lm(int l, int m) {
 static constexpr int kStartExp = -280;
 
 void LegendreTables::build(int lmax_, const std::vector<double>& x_, const std::vector<double>& sth_, int R_,
-                           int Rs_, int nthreads) {
+                           int Rs_, int nthreads, const std::vector<int>* mlim_in) {
     lmax = lmax_;
     npair = (int)x_.size();
     R = R_;
@@ -37,7 +37,7 @@ void LegendreTables::build(int lmax_, const std::vector<double>& x_, const std::
     for (int p = 0; p < npair; ++p) {
         x[p] = x_[p];
         sth[p] = sth_[p];
-        mlim[p] = mlim_spin0(lmax, sth_[p]);
+        mlim[p] = mlim_in ? (*mlim_in)[p] : mlim_spin0(lmax, sth_[p]);
     }
     const int nm = lmax + 1;
     alpha.assign(ntrip(lmax), 0.0);
@@ -172,7 +172,7 @@ void LegendreTables::build(int lmax_, const std::vector<double>& x_, const std::
 
 // --------------------------------------------------------------------------------------------- spin-2 tables
 void Legendre2Tables::build(int lmax_, const std::vector<double>& x, const std::vector<double>& sth, int npair_pad_,
-                            int R_, int nthreads) {
+                            int R_, int nthreads, const std::vector<int>* mlim_in) {
     lmax = lmax_;
     npair_pad = npair_pad_;
     R = R_;
@@ -181,7 +181,7 @@ void Legendre2Tables::build(int lmax_, const std::vector<double>& x, const std::
     nchunk = npair_pad / per;
     const int nm = lmax + 1;
     mlim.assign(npair_pad, -1);
-    for (int p = 0; p < npair; ++p) mlim[p] = mlim_spin2(lmax, sth[p], x[p]);
+    for (int p = 0; p < npair; ++p) mlim[p] = mlim_in ? (*mlim_in)[p] : mlim_spin2(lmax, sth[p], x[p]);
     alpha.assign(ntrip(lmax), 0.0);
     beta.assign(ntrip(lmax), 0.0);
     cnorm.assign(ntrip(lmax), 0.0);
@@ -325,7 +325,9 @@ void ShtTables::build_spin2(int nthreads) {
     std::vector<double> x(leg.x.begin(), leg.x.begin() + leg.npair), sth(leg.sth.begin(), leg.sth.begin() + leg.npair);
     int R2 = 2;
     while (R2 > 1 && leg.npair_pad % (kWave * R2) != 0) R2 >>= 1;
-    leg2.build(lmax, x, sth, leg.npair_pad, R2, nthreads);
+    // leg.mlim is already the merged cut on polarised plans (ShtTables::build)
+    std::vector<int> ml(leg.mlim.begin(), leg.mlim.begin() + leg.npair);
+    leg2.build(lmax, x, sth, leg.npair_pad, R2, nthreads, &ml);
 }
 
 static int bitrev(int v, int bits) {
@@ -489,13 +491,18 @@ void ShtTables::build(int nside_, int lmax_, const std::vector<int>& rings_in, c
     if (const char* e = std::getenv("CMDR_LEG_R")) { const int v = std::atoi(e); if (v == 1 || v == 2 || v == 4) R = v; }
     if (const char* e = std::getenv("CMDR_LEG_RS")) { const int v = std::atoi(e); if (v == 1 || v == 2 || v == 4) Rs = v; }
     (void)max_maps;
-    leg.build(lmax, x, sth, R, Rs, nthreads);
-    std::vector<int> ml = leg.mlim;
-    if (pol) {   // the ring stage must carry every m either spin needs
-        build_spin2(nthreads);
-        for (size_t p = 0; p < ml.size(); ++p) ml[p] = std::max(ml[p], leg2.mlim[p]);
+    // One (m, ring pair) cut per plan.  The ring stage reads and rewrites every phase entry with m <= its cut for
+    // every map slot, so each Legendre synthesis must write exactly that set: on polarised plans the T (spin-0)
+    // tasks are built from the merged cut max(mlim_spin0, mlim_spin2) as well, otherwise the T slots would keep
+    // analysis output of an earlier call in the entries mlim0 < m <= mlim2 (22 per pair at Nside 1024 / lmax 2000).
+    std::vector<int> ml(np);
+    for (int p = 0; p < np; ++p) {
+        ml[p] = mlim_spin0(lmax, sth[p]);
+        if (pol) ml[p] = std::max(ml[p], mlim_spin2(lmax, sth[p], x[p]));
     }
-    ring.build(nside, lmax, rings, wring, ml);
+    leg.build(lmax, x, sth, R, Rs, nthreads, &ml);
+    if (pol) build_spin2(nthreads);
+    ring.build(nside, lmax, rings, wring, leg.mlim);
 }
 
 void gauss_legendre(int n, std::vector<double>& x, std::vector<double>& w) {

@@ -40,7 +40,7 @@ struct LegendreTables {
     int Rs = 1, nchunk_s = 0;
     std::vector<WaveTask> tasks_s;
     void build(int lmax, const std::vector<double>& x, const std::vector<double>& sth, int R, int Rs,
-               int nthreads = 0);
+               int nthreads = 0, const std::vector<int>* mlim_in = nullptr /*[npair]; default mlim_spin0*/);
 };
 
 // Spin-2 Legendre tables: the two spin-weighted chains (+2, -2) share alpha / cnorm and differ by the sign of beta:
@@ -55,7 +55,7 @@ struct Legendre2Tables {
     std::vector<double> seed;            // [(lmax+1) * npair_pad * 4]: mu+_ls, mu+_{ls-1}, mu-_ls, mu-_{ls-1}
     std::vector<WaveTask> tasks;         // R pairs per lane, 4 tasks per workgroup, longest first
     void build(int lmax, const std::vector<double>& x, const std::vector<double>& sth, int npair_pad, int R,
-               int nthreads = 0);
+               int nthreads = 0, const std::vector<int>* mlim_in = nullptr /*[npair]; default mlim_spin2*/);
 };
 
 inline int mlim_spin2(int lmax, double sth, double cth) {   // libsharp's cut with spin = 2

@@ -31,6 +31,15 @@ def pix_z(nside):
     return z
 
 
+def pix_phi(nside):
+    """Azimuth of every RING pixel."""
+    phi = np.empty(12 * nside * nside)
+    for ring in range(1, 4 * nside):
+        nphi, _, phi0, start = ring_info(nside, ring)
+        phi[start:start + nphi] = phi0 + 2.0 * np.pi * np.arange(nphi) / nphi
+    return phi
+
+
 def rank_rings(nside, rank, nranks):
     """Northern ring numbers owned by ``rank`` (comm_map_mod.f90:197: i = 1+myid, 2*nside, nprocs)."""
     return np.arange(1 + rank, 2 * nside + 1, nranks, dtype=np.int32)

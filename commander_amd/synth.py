@@ -80,9 +80,36 @@ def comp_Dl(name, lmax):
     return D
 
 
-def make_problem(cfg, nside=None, lmax=None, comp_lmax=None, pixels=None, pol=None, bands=None):
+def noise_rms(nside, sigma0, aniso=0.0):
+    """rms map of a band: sigma_0 (1 + 0.5 cos theta), optionally modulated in azimuth
+    (aniso > 0: x (1 + aniso cos(3 phi + 1) sin theta), the test variant whose N^-1 couples different m)."""
+    z = healpix.pix_z(nside)
+    rms = sigma0 * (1.0 + 0.5 * z)
+    if aniso:
+        rms = rms * (1.0 + aniso * np.cos(3.0 * healpix.pix_phi(nside) + 1.0) * np.sqrt(1.0 - z * z))
+    return rms
+
+
+def noise_mask(nside, aniso=0.0):
+    """True where siN = 0: |cos theta| < sin 12 deg; aniso > 0 tilts the band in azimuth (a
+    galactic-plane-like cut |z - 0.3 sin(phi)| < sin 12 deg) and adds a few round holes off the plane."""
+    z = healpix.pix_z(nside)
+    if not aniso:
+        return np.abs(z) < np.sin(np.radians(12.0))
+    phi = healpix.pix_phi(nside)
+    m = np.abs(z - 0.3 * np.sin(phi)) < np.sin(np.radians(12.0))
+    sth = np.sqrt(1.0 - z * z)
+    for z0, p0, rad in ((0.7, 0.5, 6.0), (-0.55, 2.5, 4.0), (0.95, 4.0, 5.0), (-0.98, 1.0, 3.0)):
+        s0 = np.sqrt(1.0 - z0 * z0)
+        m |= (sth * s0 * np.cos(phi - p0) + z * z0) > np.cos(np.radians(rad))
+    return m
+
+
+def make_problem(cfg, nside=None, lmax=None, comp_lmax=None, pixels=None, pol=None, bands=None, aniso=0.0):
     """Problem spec dict consumed by ``commander_amd.cr.build_context`` (and by the tests' oracle builder).
 
+    aniso: 0 = the benchmark noise of SURVEY.md 8d (rms and mask functions of cos theta only); > 0 = the parity-test
+    variant with azimuth-dependent rms and mask (every (m, m') block of Yt N^-1 Y is then populated).
     pixels: optional full-sky RING indices of a rank's local map (ring sharding); maps are then local.
     bands:  optional subset of band indices this rank holds (band sharding); F_mean / F_map rows follow."""
     band_subset = bands
@@ -102,9 +129,9 @@ def make_problem(cfg, nside=None, lmax=None, comp_lmax=None, pixels=None, pol=No
         l_half = int(below[0]) if below.size else lmax
         l_star = max(1, min(l_half, int(0.75 * lmax)))
         sigma0 = np.sqrt(Cl_cmb[l_star] * b_l[l_star] ** 2 * npix / (4.0 * np.pi))
-        rms = sigma0 * (1.0 + 0.5 * z)
+        rms = noise_rms(nside, sigma0, aniso)
         siN = 1.0 / rms
-        siN[np.abs(z) < np.sin(np.radians(12.0))] = 0.0
+        siN[noise_mask(nside, aniso)] = 0.0
         if pixels is not None:
             siN = siN[pixels]
         if pol:   # T, Q, U: polarisation noise sqrt(2) higher, same beam (read_beam default, comm_utils.f90:103-107)
@@ -139,7 +166,7 @@ def make_problem(cfg, nside=None, lmax=None, comp_lmax=None, pixels=None, pol=No
             comp["F_mean"] = comp["F_mean"][band_ids, :]
             if "F_map" in comp:
                 comp["F_map"] = {i: comp["F_map"][b] for i, b in enumerate(band_ids)}
-    return dict(bands=bands, comps=comps, nside=nside, lmax=lmax, pixels=pixels, band_ids=band_ids)
+    return dict(bands=bands, comps=comps, nside=nside, lmax=lmax, pixels=pixels, band_ids=band_ids, aniso=aniso)
 
 
 def ncr_of(spec):
@@ -204,8 +231,7 @@ def draw_inputs(spec):
     ids = spec.get("band_ids") or list(range(len(spec["bands"])))
     for b, i in zip(spec["bands"], ids):          # sub-streams follow the GLOBAL band index (band sharding)
         g = rng(1, i).standard_normal(npix)
-        z = healpix.pix_z(nside)
-        rms = b["sigma0"] * (1.0 + 0.5 * z)
+        rms = noise_rms(nside, b["sigma0"], spec.get("aniso", 0.0))
         d = rms * g
         x = rng(2, i).standard_normal(npix)
         nm = np.ndim(b["siN"]) > 1 and b["siN"].shape[1] or 1

@@ -316,3 +316,32 @@ def chisq_criterion_checks(_lib=None, nside=8, lmax=16):
             assert ng == no and sg == so and 2 <= ng < 200, (pol, tol_c, ng, no)
             # CG trajectories of two fp64 implementations drift apart at rounding level; the stopping iteration is the check
             assert rel(xg, xo) < 1e-5, (pol, tol_c, rel(xg, xo))
+
+
+def pol_pruned_checks(_lib=None, nside=256, lmax=512, tol=1e-11):
+    """Polarised CR operator at a size where the (m, ring) pruning is active and differs between spin 0 and spin 2
+    (Nside >= 256 / lmax 512), with azimuth-dependent noise and mask so that every m couples to every other.
+    Regression for the stale-phase bug of round 1 (T slots of a polarised plan kept analysis output in the entries
+    mlim_spin0 < m <= mlim_spin2): A x must repeat bit-identically whatever ran in between, and the later calls must
+    match the oracle like the first."""
+    from commander_amd import synth
+    from commander_amd.cr import build_context
+    spec = synth.make_problem("cfg4", nside=nside, lmax=lmax, aniso=0.3)
+    ctx = build_context(spec, _lib=_lib)
+    S = oracle_system(spec)
+    rng = np.random.default_rng(5)
+    x, y = rng.standard_normal(ctx.ncr), rng.standard_normal(ctx.ncr)
+    Ax1 = ctx.cr_matmulA(x)
+    Ay = ctx.cr_matmulA(y)
+    Ax3 = ctx.cr_matmulA(x)
+    assert np.array_equal(Ax1, Ax3), rel(Ax1, Ax3)
+    assert rel(Ax1, S.matmulA(x)) < tol
+    assert rel(Ay, S.matmulA(y)) < tol                     # the second call, after a first one left its phases behind
+    assert abs(y @ Ax1 - x @ Ay) < tol * abs(y @ Ax1)      # symmetry
+    resid, xi, eta = synth.draw_inputs(spec)
+    rhs = ctx.cr_computeRHS("sample", resid, xi, eta)
+    assert rel(rhs, S.computeRHS(resid, "sample", xi, eta)) < tol
+    assert np.array_equal(ctx.cr_matmulA(x), Ax1)          # ... and after an RHS (analysis-only calls)
+    ctx.initPrecond(); ctx.update_precond(); S.init_precond_diag(); S.update_precond_diag()
+    assert rel(ctx.cr_invM(x), S.invM(x)) < tol
+    assert np.array_equal(ctx.cr_matmulA(x), Ax1)

@@ -1,0 +1,96 @@
+"""GPU tier: HIP path against the oracle at BASELINE.json's FULL sizes.
+
+* configs[2] (the headline workload: 9 Planck-like bands, CMB T, Nside 1024, lmax 2000): cr_matmulA, cr_computeRHS
+  ('sample') and cr_invM, each <= 1e-11 (comm_cr_mod.f90:771-1024, 542-769, 1026-1077).  This is where the multi-map
+  batching of the Legendre kernels (5+4 / 3+3+3 maps per recursion), the XCD-ordered ring launches and k_band_post at
+  nine bands meet the oracle.
+* nine POLARISED bands at Nside 512 / lmax 1000 with azimuth-dependent noise: the two-pairs-per-wave spin-2 kernels
+  (k_leg2_*_np2), k_band_post2 and the merged (m, ring) cut of polarised plans.
+* configs[3] (T/E/B, Nside 2048, lmax 4000, one band): one matvec, the second call of the context.
+
+The oracle needs minutes of CPU per case (C + OpenMP restatement); every test stays below ~4 minutes."""
+import numpy as np
+import pytest
+
+from helpers import oracle_system, pol_pruned_checks, rel
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def cfg3():
+    from commander_amd import synth
+    from commander_amd.cr import build_context
+    spec = synth.make_problem("cfg3")
+    ctx = build_context(spec)
+    S = oracle_system(spec)
+    return spec, ctx, S
+
+
+def test_cfg3_matmulA_full_size_vs_oracle(cfg3):
+    spec, ctx, S = cfg3
+    rng = np.random.default_rng(1024)
+    x0, x = rng.standard_normal(ctx.ncr), rng.standard_normal(ctx.ncr)
+    ctx.cr_matmulA(x0)                      # leave a previous call's phases / partials behind
+    y = ctx.cr_matmulA(x)
+    assert rel(y, S.matmulA(x)) < 1e-11
+    assert np.array_equal(ctx.cr_matmulA(x), y)
+
+
+def test_cfg3_rhs_full_size_vs_oracle(cfg3):
+    from commander_amd import synth
+    spec, ctx, S = cfg3
+    resid, xi, eta = synth.draw_inputs(spec)
+    cols = lambda lst: [np.asarray(v)[:, None] for v in lst]  # noqa: E731
+    rhs = ctx.cr_computeRHS("sample", resid, xi, eta)
+    assert rel(rhs, S.computeRHS(cols(resid), "sample", cols(xi), eta)) < 1e-11
+
+
+def test_cfg3_invM_full_size_vs_oracle(cfg3):
+    spec, ctx, S = cfg3
+    ctx.initPrecond()
+    ctx.update_precond()
+    S.init_precond_diag()
+    S.update_precond_diag()
+    x = np.random.default_rng(2000).standard_normal(ctx.ncr)
+    assert rel(ctx.cr_invM(x), S.invM(x)) < 1e-11
+    for b in (0, 8):
+        assert rel(ctx.invN_diag(b)[:, 0], S.bands[b].invN_diag[:, 0]) < 1e-11
+
+
+def test_polarised_pruned_plan_repeats_and_matches_oracle():
+    """T slots of a polarised plan read stale phases for mlim_spin0 < m <= mlim_spin2."""
+    pol_pruned_checks(None, nside=256, lmax=512)
+
+
+def test_nine_polarised_bands_nside512_vs_oracle():
+    from commander_amd import synth
+    from commander_amd.cr import build_context
+    spec = synth.make_problem("cfg3", nside=512, lmax=1000, pol=True, aniso=0.3)
+    ctx = build_context(spec)
+    S = oracle_system(spec)
+    rng = np.random.default_rng(512)
+    x0, x = rng.standard_normal(ctx.ncr), rng.standard_normal(ctx.ncr)
+    ctx.cr_matmulA(x0)
+    y = ctx.cr_matmulA(x)
+    assert rel(y, S.matmulA(x)) < 1e-11
+    resid, xi, eta = synth.draw_inputs(spec)
+    assert rel(ctx.cr_computeRHS("sample", resid, xi, eta), S.computeRHS(resid, "sample", xi, eta)) < 1e-11
+    assert np.array_equal(ctx.cr_matmulA(x), y)
+
+
+def test_cfg4_matmulA_full_size_vs_oracle():
+    from commander_amd import synth
+    from commander_amd.cr import build_context
+    spec = synth.make_problem("cfg4", aniso=0.3)
+    ctx = build_context(spec)
+    S = oracle_system(spec)
+    rng = np.random.default_rng(4000)
+    x0, x = rng.standard_normal(ctx.ncr), rng.standard_normal(ctx.ncr)
+    ctx.cr_matmulA(x0)
+    y = ctx.cr_matmulA(x)
+    yo = S.matmulA(x)
+    assert rel(y, yo) < 1e-11
+    n = ctx.ncr // 3
+    for k in range(3):                       # T, E and B blocks each, not only the norm-dominating one
+        assert rel(y[k * n:(k + 1) * n], yo[k * n:(k + 1) * n]) < 1e-11

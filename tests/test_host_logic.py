@@ -5,7 +5,7 @@ not contain it); GPU parity proper lives in the -m gpu tests."""
 import numpy as np
 import pytest
 
-from helpers import emul_lib, oracle_system, rel
+from helpers import emul_lib, oracle_system, pol_pruned_checks, rel
 
 
 @pytest.fixture(scope="module")
@@ -444,3 +444,9 @@ def test_emul_compute_residual_vs_oracle(EL):
 def test_emul_chisq_convergence_criterion(EL):
     from helpers import chisq_criterion_checks
     chisq_criterion_checks(EL)
+
+
+def test_emul_polarised_pruned_plan_repeats_and_matches_oracle(EL):
+    """on polarised plans the spin-0 tasks must cover the merged (m, ring) cut the ring stage uses,
+    otherwise T slots keep analysis output of the previous call (history-dependent, non-symmetric A)."""
+    pol_pruned_checks(EL, nside=256, lmax=512)
