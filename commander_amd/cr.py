@@ -121,6 +121,26 @@ class CRContext:
             cbp = ctypes.cast(cb, _vp)
         check(self.L.cmdr_ctx_set_band_sharding(self._h, cbp, None, int(ring_replicas)), self.L)
 
+    # ---- RCCL inside the library (no callbacks): see include/cmdr_hip.h ----------------------------------------
+    def rccl_unique_id(self):
+        """128-byte ncclUniqueId (create on ONE rank, broadcast with the host language's own means)."""
+        buf = ctypes.create_string_buffer(128)
+        check(self.L.cmdr_rccl_unique_id(buf), self.L)
+        return buf.raw
+
+    def init_rccl(self, unique_id, rank, nranks):
+        """Collective: every rank passes the same id.  All sums over ranks then run as ncclAllReduce on the library stream."""
+        assert len(unique_id) == 128
+        check(self.L.cmdr_ctx_init_rccl(self._h, ctypes.c_char_p(bytes(unique_id)), int(rank), int(nranks)), self.L)
+
+    def rccl_split_rings(self, band_group, ring_index, ring_replicas):
+        """Band x ring-set hybrid: communicator of the ranks holding the same bands (ncclCommSplit); collective."""
+        check(self.L.cmdr_ctx_rccl_split_rings(self._h, int(band_group), int(ring_index), int(ring_replicas)), self.L)
+
+    def rccl_size(self):
+        """ncclCommCount read back from the communicator (0: none)."""
+        return int(self.L.cmdr_ctx_rccl_size(self._h))
+
     def set_only_pol(self, flag):
         check(self.L.cmdr_ctx_set_only_pol(self._h, int(bool(flag))), self.L)
 

@@ -253,6 +253,37 @@ int cmdr_ctx_set_band_sharding(cmdr_ctx* ctx, cmdr_allreduce_fn rings_fn, void* 
         ctx->sys->set_band_sharding(rings_fn, user, ring_replicas);
     });
 }
+int cmdr_rccl_unique_id(char* out128) {
+    return guarded([&] {
+        CMDR_REQUIRE(out128, "out is NULL");
+        cmdr::RcclComm::unique_id(out128);
+    });
+}
+int cmdr_rccl_version(void) {
+    int v = -1;
+    (void)guarded([&] { v = cmdr::RcclComm::version(); });
+    return v;
+}
+int cmdr_ctx_init_rccl(cmdr_ctx* ctx, const char* id128, int rank, int nranks) {
+    return guarded([&] {
+        CMDR_REQUIRE(ctx && id128, "bad arguments");
+        ctx->sys->init_rccl(id128, rank, nranks);
+    });
+}
+int cmdr_ctx_rccl_split_rings(cmdr_ctx* ctx, int band_group, int ring_index, int ring_replicas) {
+    return guarded([&] {
+        CMDR_REQUIRE(ctx, "ctx is NULL");
+        ctx->sys->rccl_split_rings(band_group, ring_index, ring_replicas);
+    });
+}
+int cmdr_ctx_rccl_size(cmdr_ctx* ctx) {
+    int n = -1;
+    (void)guarded([&] {
+        CMDR_REQUIRE(ctx, "ctx is NULL");
+        n = ctx->sys->rccl_size();
+    });
+    return n;
+}
 int cmdr_ctx_set_only_pol(cmdr_ctx* ctx, int only_pol) {
     return guarded([&] {
         CMDR_REQUIRE(ctx, "ctx is NULL");

@@ -14,6 +14,7 @@ CrSystem::CrSystem(int device) {
 }
 
 CrSystem::~CrSystem() {
+    if (stream_) (void)hipStreamSynchronize(stream_);   // nothing of ours (kernels, RCCL operations) still queued
     for (Group& G : groups_) {
         for (hipEvent_t e : G.ev_synth) (void)hipEventDestroy(e);
         for (hipEvent_t e : G.ev_ring) (void)hipEventDestroy(e);
@@ -691,14 +692,36 @@ void CrSystem::compact_precond_init() {
     }
 }
 
+void CrSystem::init_rccl(const char* id, int rank, int nranks) {
+    CMDR_REQUIRE(id, "id is NULL");
+    rccl_.init(id, rank, nranks);
+}
+
+void CrSystem::rccl_split_rings(int band_group, int ring_index, int ring_replicas) {
+    CMDR_REQUIRE(rccl_.ready(), "cmdr_ctx_init_rccl first");
+    CMDR_REQUIRE(ring_replicas >= 1 && ring_index >= 0 && ring_index < ring_replicas, "bad ring group");
+    rccl_rings_.split_from(rccl_, band_group, ring_index);       // collective: every rank of the world calls it
+    CMDR_REQUIRE(rccl_rings_.size() == ring_replicas, "ring group size does not match the communicator split");
+    ring_replicas_ = ring_replicas;
+    band_sharded_ = true;
+}
+
 void CrSystem::reduce_rings(double* v, int64_t n) {
     if (!band_sharded_) { reduce(v, n); return; }
+    if (rccl_rings_.ready()) {
+        if (ring_replicas_ > 1) rccl_rings_.allreduce_sum(v, n, reinterpret_cast<void*>(stream_));
+        return;
+    }
     if (!allreduce_rings_) return;           // one rank per ring group
     sync();
     allreduce_rings_(allreduce_rings_user_, v, n);
 }
 
 void CrSystem::reduce(double* v, int64_t n) {
+    if (rccl_.ready()) {  // RCCL on the library stream: stays queued behind the kernels that produced v
+        rccl_.allreduce_sum(v, n, reinterpret_cast<void*>(stream_));
+        return;
+    }
     if (allreduce_s_) {   // stream-ordered collective: stays queued behind the kernels that produced v
         allreduce_s_(allreduce_s_user_, v, n, reinterpret_cast<void*>(stream_));
         return;
@@ -904,7 +927,7 @@ double CrSystem::chisq_of(const double* x) {
     CMDR_HIP_CHECK(hipMemcpy(h, scal + 4, sizeof(double) * g, hipMemcpyDeviceToHost));
     double tot = 0.0;
     for (int k = 0; k < g; ++k) tot += h[k];
-    if (allreduce_ || allreduce_s_) {       // every (band, pixel) lives on exactly one rank in all sharding layouts
+    if (allreduce_ || allreduce_s_ || rccl_.ready()) {   // every (band, pixel) lives on exactly one rank in all sharding layouts
         CMDR_HIP_CHECK(hipMemcpy(scal + 4, &tot, sizeof(double), hipMemcpyHostToDevice));
         reduce(scal + 4, 1);
         sync();

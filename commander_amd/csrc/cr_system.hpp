@@ -16,6 +16,7 @@
 
 #include "common.hpp"
 #include "kernels.hpp"
+#include "rccl_dyn.hpp"
 #include "sht_plan.hpp"
 
 namespace cmdr {
@@ -72,6 +73,13 @@ class CrSystem {
         allreduce_rings_ = rings_fn; allreduce_rings_user_ = user; ring_replicas_ = ring_replicas; band_sharded_ = true;
     }
     void set_only_pol(bool v) { only_pol_ = v; }
+    // RCCL inside the library: every sum over ranks becomes an ncclAllReduce enqueued on the library stream (no
+    // callback, no host synchronisation).  id = the 128-byte ncclUniqueId one rank created and the host language
+    // broadcast.  Takes precedence over the callbacks.  split_rings: sub-communicator of the ranks that hold the
+    // same bands (band x ring-set hybrid), ncclCommSplit with color = band group; implies band sharding.
+    void init_rccl(const char* id, int rank, int nranks);
+    void rccl_split_rings(int band_group, int ring_index, int ring_replicas);
+    int rccl_size() const { return rccl_.ready() ? rccl_.size() : 0; }
 
     int64_t ncr() const { return ncr_; }
     int nband() const { return (int)bands_.size(); }
@@ -234,6 +242,7 @@ class CrSystem {
     void* allreduce_rings_user_ = nullptr;
     int ring_replicas_ = 1;
     bool band_sharded_ = false;
+    RcclComm rccl_, rccl_rings_;
 };
 
 }  // namespace cmdr

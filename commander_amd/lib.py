@@ -60,6 +60,12 @@ def _sig(L):
     L.cmdr_ctx_set_allreduce_stream.argtypes = [c_vp, c_vp, c_vp]
     L.cmdr_ctx_set_band_sharding.argtypes = [c_vp, c_vp, c_vp, c_int]
     L.cmdr_ctx_set_only_pol.argtypes = [c_vp, c_int]
+    L.cmdr_rccl_unique_id.argtypes = [ctypes.c_char_p]
+    L.cmdr_rccl_version.restype = c_int
+    L.cmdr_ctx_init_rccl.argtypes = [c_vp, ctypes.c_char_p, c_int, c_int]
+    L.cmdr_ctx_rccl_split_rings.argtypes = [c_vp, c_int, c_int, c_int]
+    L.cmdr_ctx_rccl_size.argtypes = [c_vp]
+    L.cmdr_ctx_rccl_size.restype = c_int
     L.cmdr_band_add.argtypes = [c_vp, c_int, c_int, c_int, dp, dp, c_dbl, dp, dp]
     L.cmdr_comp_add.argtypes = [c_vp, c_int, c_int, c_int, dp, dp, dp, dp, c_int]
     L.cmdr_finalize.argtypes = [c_vp]

@@ -104,6 +104,24 @@ int cmdr_ctx_set_allreduce_stream(cmdr_ctx* ctx, cmdr_allreduce_stream_fn fn, vo
  * the SAME bands (may be NULL when that group is one rank); the callback of cmdr_ctx_set_allreduce[_stream] sums over
  * all ranks.  ring_replicas = number of ranks per band subset.  Diagonal preconditioner only. */
 int cmdr_ctx_set_band_sharding(cmdr_ctx* ctx, cmdr_allreduce_fn rings_fn, void* user, int ring_replicas);
+/* RCCL inside the library (the MI355X-native form of the exchange; RCCL = backend "nccl" of torch.distributed, bound
+ * here with dlopen("librccl.so.1"), no link-time dependency).  One rank calls cmdr_rccl_unique_id and the host language
+ * broadcasts the 128 bytes (MPI_Bcast in the Fortran driver, exactly where it already broadcasts parameters;
+ * torch.distributed in bench.py); every rank then calls cmdr_ctx_init_rccl (collective; ncclCommInitRank on the
+ * context's device).  From then on the sum over ranks of cr_matmulA / cr_computeRHS / preconditioner setup --
+ * what libsharp2's MPI exchange + mpi_dot_product's MPI_Allreduce (comm_utils.f90:599-614) do in the reference --
+ * is one ncclAllReduce per call, enqueued on the library's own HIP stream: no callback, no host synchronisation, a
+ * whole fixed_iter solve stays queued ahead of the GPU.  Takes precedence over the callbacks above.
+ * cmdr_ctx_rccl_split_rings: band x ring-set hybrid without callbacks -- ncclCommSplit(color = band_group,
+ * key = ring_index) gives the communicator of the ranks holding the same bands; collective over ALL ranks (ranks
+ * outside any hybrid layout do not call it).  Replaces cmdr_ctx_set_band_sharding.
+ * cmdr_ctx_rccl_size: ncclCommCount read back from the communicator (0 = none).  cmdr_rccl_version: ncclGetVersion
+ * (< 0: librccl could not be loaded; cmdr_last_error says why). */
+int cmdr_rccl_unique_id(char* out128);
+int cmdr_rccl_version(void);
+int cmdr_ctx_init_rccl(cmdr_ctx* ctx, const char* id128, int rank, int nranks);
+int cmdr_ctx_rccl_split_rings(cmdr_ctx* ctx, int band_group, int ring_index, int ring_replicas);
+int cmdr_ctx_rccl_size(cmdr_ctx* ctx);
 int cmdr_ctx_set_only_pol(cmdr_ctx* ctx, int only_pol);
 
 /* data(i): comm_data_mod.f90:33-63.  siN = 1/rms (0 in masked pixels, comm_N_rms_mod.f90:179-193),
