@@ -276,6 +276,135 @@ __global__ void __launch_bounds__(256) k_leg_adj(LegArgs A, const WaveTask* __re
     }
 }
 
+// ---- Adjoint on the matrix unit ------------------------------------------------------------------------------------
+// a_lm = sum_pairs mu_l(x_pair) G_m(pair) IS a dense contraction over ring pairs once mu is laid out with l across
+// lanes: D[l][col] += A[l][pair] B[pair][col] with col = (map, re/im) -- v_mfma_f64_16x16x4_f64 does the multiply-
+// accumulate AND the sum over lanes that costs the VALU kernel above ~40 % of its instructions (wave_reduce16).
+//   * one workgroup = 2 waves = one wave task (m, 256 ring pairs); wave w owns 128 of the pairs as two 64-pair blocks.
+//   * recursion on the VALU, lane = ring pair, 32 consecutive l per group; mu goes through a wave-private LDS tile
+//     [32 l][64 pairs] (pitch 65 doubles: conflict-free for the lane = pair writes and for the transposed reads) and
+//     comes back as the A operand: lane i holds A[row = i & 15][k = i >> 4] = mu_{l0 + 2 row + parity}(pair 4q + k).
+//   * B operands stay in registers for the whole task: lane i holds G[pair 4q + (i >> 4)][col = i & 15], once as
+//     N + S (rows with even l - m) and once as N - S (odd): the north/south symmetry halves the contraction length.
+//   * D (rows = 16 l of one parity, cols = 8 maps x (re, im)) accumulates over the wave's 32 pair quads; the two waves
+//     exchange halves through LDS (wave 0 finishes the even rows, wave 1 the odd ones) and write the same
+//     part[map][chunk][padded triangle] layout as k_leg_adj.  Fixed summation order -> deterministic.
+// fp64 MFMA and fp64 VALU share one datapath on gfx950 (tools/microbench/fp64_mfma_coexec.hip), so this is not more
+// flops per clock -- it removes the cross-lane reduction and lets 8 maps share one recursion (2/8 + 2 instead of
+// 2/3 + 2 + 1.7-2.1 VALU-equivalents per (pair, l, map)).
+typedef double mx_d4 __attribute__((ext_vector_type(4)));
+constexpr int kMxL = 32;       // l per group (16 rows of each parity)
+constexpr int kMxPitch = 65;   // doubles per tile row
+
+// 32 recursion steps of one 64-pair block; mu_l of every step goes to the tile row of l.  No bound on l: the alpha table
+// has slack behind its last column (plan_tables.hpp ntrip), rows beyond lmax hold finite-or-not garbage that only reaches
+// D rows which are never stored (MFMA rows are independent).
+template <bool INJECT>
+__device__ __forceinline__ void mx_recur(const double* __restrict__ al, int l0, double x, double& mc, double& mp,
+                                         double sc, double sp, int ls, double* __restrict__ trow) {
+#pragma unroll
+    for (int j = 0; j < kMxL; ++j) {
+        const double al1 = al[l0 + j + 1];
+        if (INJECT) if (ls == l0 + j) { mc = sc; mp = sp; }
+        trow[j * kMxPitch] = mc;
+        const double t = al1 * x * mc - mp;
+        mp = mc;
+        mc = t;
+    }
+}
+
+__global__ void __launch_bounds__(128) k_leg_adj_mx(LegArgs A, const WaveTask* __restrict__ tasks, int ntasks,
+                                                    const double* __restrict__ ph, int64_t ph_stride, int k0, int nb,
+                                                    double* __restrict__ part, int64_t part_map_stride,
+                                                    int64_t part_chunk_stride) {
+    __shared__ __attribute__((aligned(16))) double tile[2][kMxL * kMxPitch];
+    const int wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    if ((int)blockIdx.x >= ntasks) return;
+    const WaveTask T = tasks[blockIdx.x];
+    if (T.chunk < 0) return;
+    const int m = __builtin_amdgcn_readfirstlane(T.m);
+    const int chunk = __builtin_amdgcn_readfirstlane(T.chunk);
+    const int lw = __builtin_amdgcn_readfirstlane(T.lw);
+    const int lAend = __builtin_amdgcn_readfirstlane(T.lAend);
+    const int lmax = A.lmax;
+    const int pbase = chunk * 256 + wid * 128;
+    double x[2], mc[2], mp[2], sc[2], sp[2];
+    int ls[2];
+#pragma unroll
+    for (int r = 0; r < 2; ++r) {
+        const int p = pbase + r * 64 + lane;
+        const int64_t idx = (int64_t)m * A.npair_pad + p;
+        x[r] = A.x[p];
+        ls[r] = A.ls[idx];
+        sc[r] = A.seedc[idx];
+        sp[r] = A.seedp[idx];
+        mc[r] = mp[r] = 0.0;
+    }
+    const int kq = lane >> 4, col = lane & 15, mk = col >> 1, reim = col & 1;
+    const bool on = mk < nb;
+    double Be[2][16], Bo[2][16];
+    {
+        const double* __restrict__ g0 = ph + (int64_t)(k0 + (on ? mk : 0)) * ph_stride + ((int64_t)m * A.npair_pad + pbase + kq) * 4 + reim;
+#pragma unroll
+        for (int r = 0; r < 2; ++r)
+#pragma unroll
+            for (int q = 0; q < 16; ++q) {
+                const double* g = g0 + (r * 64 + 4 * q) * 4;
+                const double n = on ? g[0] : 0.0, s = on ? g[2] : 0.0;
+                Be[r][q] = n + s;
+                Bo[r][q] = n - s;
+            }
+    }
+    const int64_t mo = d_moffp(lmax, m);
+    const double* __restrict__ al = A.alpha + (mo - m);
+    double* __restrict__ outp = part + chunk * part_chunk_stride + 2 * (mo - m) + (int64_t)(k0 + mk) * part_map_stride + reim;
+    double* __restrict__ Tw = tile[wid];
+    const double* __restrict__ To = tile[1 - wid];
+    const int arow = (lane & 15) * 2 * kMxPitch + kq;
+    for (int l0 = lw; l0 <= lmax; l0 += kMxL) {
+        mx_d4 De0 = {0.0, 0.0, 0.0, 0.0}, De1 = De0, Do0 = De0, Do1 = De0;
+#pragma unroll
+        for (int r = 0; r < 2; ++r) {
+            if (l0 < lAend) mx_recur<true>(al, l0, x[r], mc[r], mp[r], sc[r], sp[r], ls[r], Tw + lane);
+            else            mx_recur<false>(al, l0, x[r], mc[r], mp[r], sc[r], sp[r], ls[r], Tw + lane);
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#pragma unroll
+            for (int q = 0; q < 16; q += 2) {
+                const double ae0 = Tw[arow + 4 * q], ao0 = Tw[arow + kMxPitch + 4 * q];
+                const double ae1 = Tw[arow + 4 * q + 4], ao1 = Tw[arow + kMxPitch + 4 * q + 4];
+                De0 = __builtin_amdgcn_mfma_f64_16x16x4f64(ae0, Be[r][q], De0, 0, 0, 0);
+                Do0 = __builtin_amdgcn_mfma_f64_16x16x4f64(ao0, Bo[r][q], Do0, 0, 0, 0);
+                De1 = __builtin_amdgcn_mfma_f64_16x16x4f64(ae1, Be[r][q + 1], De1, 0, 0, 0);
+                Do1 = __builtin_amdgcn_mfma_f64_16x16x4f64(ao1, Bo[r][q + 1], Do1, 0, 0, 0);
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        }
+        De0 += De1;
+        Do0 += Do1;
+        // wave 0 finishes the even rows (l - l0 even), wave 1 the odd ones: hand the other half over
+        const mx_d4 give = wid == 0 ? Do0 : De0;
+        mx_d4 keep = wid == 0 ? De0 : Do0;
+#pragma unroll
+        for (int v = 0; v < 4; ++v) Tw[v * 64 + lane] = give[v];
+        __syncthreads();
+#pragma unroll
+        for (int v = 0; v < 4; ++v) keep[v] += To[v * 64 + lane];
+        if (on) {
+#pragma unroll
+            for (int v = 0; v < 4; ++v) {
+                const int l = l0 + 2 * (kq + 4 * v) + wid;
+                if (l <= lmax) outp[2 * l] = keep[v];
+            }
+        }
+        __syncthreads();
+    }
+}
+
 // maps sharing one recursion per wave (register budget).  Tuning knobs: CMDR_LEG_NB caps both kernels,
 // CMDR_LEG_NB_S / CMDR_LEG_NB_A set the synthesis / adjoint value (up to the compiled maximum).
 static int leg_batch(int R, bool adjoint, bool wg = false) {
@@ -354,6 +483,20 @@ void launch_leg_adj(const LegArgs& A, const WaveTask* tasks, int ntasks, const d
         }
         return;
     }
+    // matrix-unit form for batches of up to 8 maps (plans with 256-pair chunks); the rest through the VALU kernel
+    static const int mx_min = [] { const char* e = std::getenv("CMDR_ADJ_MX"); return e ? std::atoi(e) : 6; }();
+    int kdone = 0;
+    if (A.R == 4 && mx_min > 0)
+        while (nmaps - kdone >= mx_min) {
+            const int nb = std::min(8, nmaps - kdone);
+            hipLaunchKernelGGL(k_leg_adj_mx, dim3(ntasks), dim3(128), 0, s, A, tasks, ntasks, ph, ph_stride, kdone, nb, part,
+                               pms, pcs);
+            kdone += nb;
+        }
+    if (kdone == nmaps) return;
+    ph += (int64_t)kdone * ph_stride;
+    part += (int64_t)kdone * pms;
+    nmaps -= kdone;
     for_batches(nmaps, leg_batch(A.R, true), [&](int nb, int k0, int rep) {
 #define CMDR_A(RR, NN) case NN: adj_RN<RR, NN, false>(A, tasks, ntasks, ph, ph_stride, k0, rep, part, pms, pcs, s); break;
         if (A.R == 1) {

@@ -141,6 +141,13 @@ void LegendreTables::build(int lmax_, const std::vector<double>& x_, const std::
     std::stable_sort(tasks.begin(), tasks.end(), [](const WaveTask& a, const WaveTask& b) { return a.lw < b.lw; });
     while (tasks.size() % 4) { WaveTask t; t.m = 0; t.chunk = -1; t.lw = lmax + 1; t.lAend = lmax + 1; tasks.push_back(t); }
     group = 4;
+    if (std::getenv("CMDR_DEBUG_PLAN")) {
+        double slots = 0, slotsA = 0, steps = 0;
+        for (const WaveTask& t : tasks) if (t.chunk >= 0) { slots += (double)(lmax - t.lw + 1) * kWave * R; slotsA += (double)(std::min(t.lAend, lmax + 1) - t.lw) * kWave * R; }
+        for (int m = 0; m < nm; ++m) for (int p = 0; p < npair; ++p) { const int v = ls[(size_t)m * npair_pad + p]; if (v != kLsNever) steps += lmax - v + 1; }
+        std::fprintf(stderr, "[cmdr] legendre plan lmax=%d npair=%d R=%d: %zu tasks, lane-slot steps %.4g (phase A %.4g), pruned steps %.4g (%.1f%%)\n",
+                     lmax, npair, R, tasks.size(), slots, slotsA, steps, 100.0 * steps / slots);
+    }
     make_tasks(Rs, tm);
     tasks_s.clear();
     synth_wg = false;

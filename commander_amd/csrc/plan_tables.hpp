@@ -17,7 +17,7 @@ constexpr int kAdjL = 8;              // l per transpose-reduce group in the adj
 
 // Padded triangle: column m holds l = m..lmax+1 (one zero pad entry), so kernels may run l in (even, odd) pairs.
 inline int64_t moffp(int lmax, int m) { return (int64_t)m * (lmax + 2) - (int64_t)m * (m - 1) / 2; }
-inline int64_t ntrip(int lmax) { return moffp(lmax, lmax + 1) + 16; }  // + slack for look-ahead reads (l+4)
+inline int64_t ntrip(int lmax) { return moffp(lmax, lmax + 1) + 64; }  // + slack for look-ahead reads (k_leg_adj_mx: up to l+32)
 
 struct WaveTask {  // one wavefront's work item: 64*R colatitude pairs of one m
     int m, chunk, lw, lAend;

@@ -48,6 +48,6 @@ int main() {
         double fv = 2.0 * NV * iters * (double)nblk * 256, fm = 2.0 * NM * 1024.0 * iters * (double)nblk * 4;         \
         printf("NV=%2d NM=%d: %.3f ms   VALU %.1f TF  MFMA %.1f TF  sum %.1f TF\n", NV, NM, ms, fv / ms / 1e9, fm / ms / 1e9, (fv + fm) / ms / 1e9); \
     }
-    RUN(16, 0) RUN(0, 4) RUN(16, 1) RUN(16, 2) RUN(16, 4) RUN(8, 4) RUN(32, 2)
+    RUN(16, 0) RUN(0, 1) RUN(0, 2) RUN(0, 4) RUN(0, 8) RUN(2, 4) RUN(4, 8) RUN(16, 1) RUN(16, 4)
     return 0;
 }
