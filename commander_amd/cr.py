@@ -199,6 +199,19 @@ class CRContext:
         else:
             check(self.L.cmdr_precond_update_diag(self._h), self.L)
 
+    def set_lowl_precond(self, comp, lmax_pre_lowl, nside_lowres=None, siN_lowres=None):
+        """``CG_LMAX_PRECOND``: low-l dense preconditioner block of a diffuse component (updateLowlPrecond /
+        applyLowlPrecond); siN_lowres[b] = ``data(b)%N%siN_lowres`` (full-sky RING, temperature).  Rebuilt by every
+        ``update_precond``.  lmax_pre_lowl < 0 removes it."""
+        if lmax_pre_lowl < 0:
+            check(self.L.cmdr_precond_set_lowl(self._h, int(comp), -1, None, None), self.L)
+            return
+        ns = (ctypes.c_int * self.nband)(*[int(v) for v in nside_lowres])
+        keep = [np.ascontiguousarray(np.asarray(m, dtype=np.float64).reshape(12 * int(v) ** 2, -1)[:, 0])
+                for m, v in zip(siN_lowres, nside_lowres)]
+        arr = (_dp * self.nband)(*[_p(a) for a in keep])
+        check(self.L.cmdr_precond_set_lowl(self._h, int(comp), int(lmax_pre_lowl), ns, arr), self.L)
+
     def alpha_nu(self, band):
         out = np.zeros(self.band_shape[band][1])
         check(self.L.cmdr_get_alpha_nu(self._h, int(band), _p(out)), self.L)

@@ -332,6 +332,13 @@ int cmdr_precond_update_diag(cmdr_ctx* ctx) {
         ctx->sys->sync();
     });
 }
+int cmdr_precond_set_lowl(cmdr_ctx* ctx, int comp, int lmax_pre_lowl, const int* nside_lowres,
+                          const double* const* siN_lowres) {
+    return guarded([&] {
+        CMDR_REQUIRE(ctx, "ctx is NULL");
+        ctx->sys->set_lowl(comp, lmax_pre_lowl, nside_lowres, siN_lowres);
+    });
+}
 int cmdr_precond_init_pseudoinv(cmdr_ctx* ctx) {
     return guarded([&] {
         CMDR_REQUIRE(ctx, "ctx is NULL");

@@ -188,6 +188,18 @@ void launch_pix(int mode, const double* a, const double* b, const double* c, dou
     hipLaunchKernelGGL(k_pix, dim3(nb), dim3(256), 0, s, mode, a, b, c, out, n);
 }
 
+__global__ void k_index_copy(const double* __restrict__ src, const int64_t* __restrict__ idx, double* __restrict__ dst,
+                             int n, int scatter) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    if (scatter) dst[idx[i]] = src[i];
+    else dst[i] = src[idx[i]];
+}
+void launch_index_copy(const double* src, const int64_t* idx, double* dst, int n, bool scatter, hipStream_t s) {
+    if (n <= 0) return;
+    hipLaunchKernelGGL(k_index_copy, dim3((n + 255) / 256), dim3(256), 0, s, src, idx, dst, n, scatter ? 1 : 0);
+}
+
 // ----------------------------------------------------------------------------- CG vector algebra
 // Deterministic dot: fixed grid of kDotBlocks partial sums (wave shuffle -> LDS), then one block folds them in
 // a fixed order.  Results land in a small device scalar array so the host never waits inside an iteration.

@@ -329,6 +329,7 @@ void CrSystem::finalize() {
         G.bl.upload(bl);
         G.bm_stokes_dev.upload(G.bm_stokes);
         G.mul_ptrs.upload(mp);
+        G.plan->toeplitz_build(mp, G.that, stream_);       // N^-1 of the matvec in circulant form for the cap rings
         for (int b : G.bands) bands_[b].group = g;
     }
     (void)ncomp;
@@ -832,7 +833,7 @@ void CrSystem::matmulA(const double* x, double* y) {
         if (G.npol) P.synth2_from_stream(G.npol, G.nT, stream_);                     // (Q,U): spin 2, comm_map_mod.f90:446
         span_end();
         span_begin(1);
-        P.rings(2, nullptr, 0, G.mul_ptrs.get(), false, G.nbm, stream_);             // N^-1 :905 fused with both FFTs
+        P.rings(2, nullptr, 0, G.mul_ptrs.get(), false, G.nbm, stream_, G.that.get());   // N^-1 :905 fused with both FFTs
         span_end();
     }
     adjoint_groups_to_yc(false);                                                     // Yt :915, projectBand :920-948
@@ -1152,6 +1153,138 @@ void CrSystem::precond_init_diag() {
     precond_ready_ = false;
 }
 
+// ------------------------------------------------------------------------------------------------- low-l preconditioner
+void CrSystem::set_lowl(int comp, int L, const int* nside_lowres, const double* const* siN_lowres) {
+    CMDR_REQUIRE(finalized_, "finalize first");
+    CMDR_REQUIRE(comp >= 0 && comp < (int)comps_.size(), "bad comp");
+    sync();
+    for (size_t i = 0; i < lowl_.size(); ++i)
+        if (lowl_[i].comp == comp) { lowl_.erase(lowl_.begin() + (long)i); break; }
+    if (L < 0) return;
+    CMDR_REQUIRE(L <= comps_[comp].d.lmax, "lmax_pre_lowl exceeds the component's lmax");
+    CMDR_REQUIRE(L <= 200, "lmax_pre_lowl too large for a dense block");
+    CMDR_REQUIRE(nside_lowres && siN_lowres, "low-resolution noise maps are NULL");
+    lowl_.emplace_back();
+    LowL& W = lowl_.back();
+    W.comp = comp;
+    W.L = L;
+    for (int b = 0; b < (int)bands_.size(); ++b) {
+        const int ns = nside_lowres[b];
+        CMDR_REQUIRE(ns >= 1 && (ns & (ns - 1)) == 0 && siN_lowres[b], "bad low-resolution noise map");
+        const int64_t np = 12 * (int64_t)ns * ns;
+        W.nside.push_back(ns);
+        W.iN.emplace_back((size_t)np);
+        for (int64_t i = 0; i < np; ++i) W.iN.back()[i] = siN_lowres[b][i] * siN_lowres[b][i];   // InvN_lowres, comm_N_rms_mod.f90:281
+        W.iN_dev.push_back(std::make_unique<DevBuf<double>>());
+        W.iN_dev.back()->upload(W.iN.back());
+    }
+    const int n = (L + 1) * (L + 1);
+    const CompDev& C = comps_[comp].d;
+    std::vector<int64_t> idx(n);
+    for (int l = 0; l <= L; ++l)
+        for (int m = -l; m <= l; ++m) {
+            const int am = m < 0 ? -m : m;
+            idx[l * l + l + m] = C.pos + mind(C.lmax, am) + (am == 0 ? l : 2 * (l - am) + (m < 0 ? 1 : 0));
+        }
+    W.idx.upload(idx);
+    W.xl.alloc(n);
+    W.yl.alloc(n);
+}
+
+// updateLowlPrecond: the dense block delta + S^1/2 [sum_bands F b_l Yt N_low^-1 Y b_l F] S^1/2 on the temperature a_lm with
+// l <= L, probed column by column through low-resolution transforms (lmax 2 L), then inverted.
+void CrSystem::lowl_update(LowL& W) {
+    const Comp& C = comps_[W.comp];
+    const int L = W.L, l2 = 2 * L, n = (L + 1) * (L + 1);
+    const int64_t na2 = nalm_packed(l2);
+    const int nb = (int)bands_.size();
+    std::vector<double> M((size_t)n * n, 0.0);
+    auto packed2 = [&](int l, int m) {   // position of (l, m) in the packed a_lm of lmax 2 L
+        const int am = m < 0 ? -m : m;
+        return mind(l2, am) + (am == 0 ? l : 2 * (l - am) + (m < 0 ? 1 : 0));
+    };
+    const int B = std::min(n, 16);
+    std::vector<double> hin((size_t)B * na2), hout((size_t)B * na2);
+    DevBuf<double> din((size_t)B * na2), dout((size_t)B * na2);
+    for (int b = 0; b < nb; ++b) {
+        const Band& Bd = bands_[b];
+        const int ns = W.nside[b];
+        const int key = ns * 65536 + l2;
+        if (!lowl_plans_.count(key)) lowl_plans_[key] = std::make_unique<ShtPlan>(ns, l2, std::vector<int>{}, nullptr, 16);
+        ShtPlan& P = *lowl_plans_[key];
+        const int64_t np = P.npix_local();
+        DevBuf<double> maps((size_t)B * np);
+        std::vector<double> wl(L + 1, 0.0);    // sqrt(S)_TT * F_mean * b_l * mb_eff  (:5128, :5139-5141)
+        for (int l = 0; l <= L; ++l) {
+            double sq = 1.0;
+            if (C.d.lmax_cl >= 0) sq = l <= C.d.lmax_cl ? C.sqrtS[(size_t)C.d.nmaps * C.d.nmaps * l] : 0.0;
+            const double bl = l <= Bd.lmax ? Bd.b_l[l] * Bd.mb_eff : 0.0;
+            wl[l] = sq * C.F_mean[b] * bl;
+        }
+        for (int j0 = 0; j0 < n; j0 += B) {
+            const int nbat = std::min(B, n - j0);
+            std::fill(hin.begin(), hin.end(), 0.0);
+            for (int k = 0; k < nbat; ++k) {
+                const int i = j0 + k, l = (int)std::floor(std::sqrt((double)i)), m = i - l * l - l;
+                hin[(size_t)k * na2 + packed2(l, m)] = wl[l];
+            }
+            CMDR_HIP_CHECK(hipMemcpyAsync(din.get(), hin.data(), sizeof(double) * nbat * na2, hipMemcpyHostToDevice, stream_));
+            P.alm2map(din.get(), na2, maps.get(), np, nbat, false, stream_);                          // Y   :5147
+            for (int k = 0; k < nbat; ++k)
+                launch_pix(0, W.iN_dev[b]->get(), maps.get() + (int64_t)k * np, nullptr, maps.get() + (int64_t)k * np, np, stream_);
+            P.map2alm(maps.get(), np, dout.get(), na2, nbat, false, stream_);                         // Yt  :5159
+            sync();
+            CMDR_HIP_CHECK(hipMemcpy(hout.data(), dout.get(), sizeof(double) * nbat * na2, hipMemcpyDeviceToHost));
+            for (int k = 0; k < nbat; ++k)
+                for (int lp = 0; lp <= L; ++lp)
+                    for (int mp = -lp; mp <= lp; ++mp)
+                        M[(size_t)(j0 + k) * n + lp * lp + lp + mp] += wl[lp] * hout[(size_t)k * na2 + packed2(lp, mp)];
+        }
+    }
+    if (band_sharded_) {   // sum over the band groups; every ring replica of a group computed the same (full-sky) terms
+        DevBuf<double> tmp(M.size());
+        tmp.upload(M, stream_);
+        reduce(tmp.get(), (int64_t)M.size());
+        sync();
+        CMDR_HIP_CHECK(hipMemcpy(M.data(), tmp.get(), sizeof(double) * M.size(), hipMemcpyDeviceToHost));
+        for (double& v : M) v /= (double)ring_replicas_;
+    }
+    for (int i = 0; i < n; ++i) M[(size_t)i * n + i] += 1.0;                                          // :5205
+    // symmetric positive definite: Cholesky M = G G^t, inverse = G^-t G^-1 (invert_matrix(cholesky=.true.) :5229)
+    for (int j = 0; j < n; ++j) {
+        double d = M[(size_t)j * n + j];
+        for (int k = 0; k < j; ++k) d -= M[(size_t)j * n + k] * M[(size_t)j * n + k];
+        CMDR_REQUIRE(d > 0.0, "low-l preconditioner block is not positive definite");
+        d = std::sqrt(d);
+        M[(size_t)j * n + j] = d;
+        for (int i = j + 1; i < n; ++i) {
+            double v = 0.5 * (M[(size_t)i * n + j] + M[(size_t)j * n + i]);
+            for (int k = 0; k < j; ++k) v -= M[(size_t)i * n + k] * M[(size_t)j * n + k];
+            M[(size_t)i * n + j] = v / d;
+        }
+    }
+    std::vector<double> Gi((size_t)n * n, 0.0);               // G^-1, lower triangular
+    for (int c = 0; c < n; ++c) {
+        Gi[(size_t)c * n + c] = 1.0 / M[(size_t)c * n + c];
+        for (int i = c + 1; i < n; ++i) {
+            double v = 0.0;
+            for (int k = c; k < i; ++k) v -= M[(size_t)i * n + k] * Gi[(size_t)k * n + c];
+            Gi[(size_t)i * n + c] = v / M[(size_t)i * n + i];
+        }
+    }
+    std::vector<double> Minv((size_t)n * n, 0.0);
+    host_parallel_for(n, [&](int i) {
+        for (int j = 0; j <= i; ++j) {
+            double v = 0.0;
+            for (int k = i; k < n; ++k) v += Gi[(size_t)k * n + i] * Gi[(size_t)k * n + j];
+            Minv[(size_t)i * n + j] = v;
+            Minv[(size_t)j * n + i] = v;
+        }
+    });
+    W.Minv.upload(Minv, stream_);
+    W.ready = true;
+}
+
 void CrSystem::precond_update_diag() {
     CMDR_REQUIRE(!M0_.empty(), "precond_init_diag first");
     const int npre = (int)comps_.size();
@@ -1203,6 +1336,7 @@ void CrSystem::precond_update_diag() {
     P_.upload(P, stream_);
     precond_type_ = 0;
     precond_ready_ = true;
+    for (LowL& W : lowl_) lowl_update(W);      // update_precond rebuilds the low-l block every time (comm_cr_mod.f90:1136-1147)
 }
 
 // ------------------------------------------------------------------------------------------------- pseudo-inverse
@@ -1408,6 +1542,13 @@ void CrSystem::invM(const double* x, double* y) {
     launch_precond_diag(comps_dev_.get(), (int)comps_.size(), P_.get(), lmax_pre_, nmaps_pre_, x, y, stream_);
     for (Compact& K : compacts_)   // applyPtsrcPrecond / applyTemplatePrecond: the block's own dense inverse
         launch_dense_mv(K.Minv.get(), x + K.pos, y + K.pos, K.nparam, stream_);
+    for (LowL& W : lowl_) {        // applyLowlPrecond on the INPUT vector's entries (comm_cr_mod.f90:1058-1073)
+        if (!W.ready) continue;
+        const int n = (W.L + 1) * (W.L + 1);
+        launch_index_copy(x, W.idx.get(), W.xl.get(), n, false, stream_);
+        launch_dense_mv(W.Minv.get(), W.xl.get(), W.yl.get(), n, stream_);
+        launch_index_copy(W.yl.get(), W.idx.get(), y, n, true, stream_);
+    }
 }
 
 // ------------------------------------------------------------------------------------------------- PCG

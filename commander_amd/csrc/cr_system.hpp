@@ -11,6 +11,7 @@
 // varying mixing (Y . F . YtW branch, :2082-2084, :2155-2157), white per-pixel noise (comm_N_rms), T and T,Q,U bands;
 // diagonal and pseudo-inverse preconditioners.
 #pragma once
+#include <map>
 #include <memory>
 #include <vector>
 
@@ -89,6 +90,11 @@ class CrSystem {
 
     void precond_init_diag();     // initDiffPrecond_diagonal + compute_invN_lm
     void precond_update_diag();   // updateDiffPrecond_diagonal
+    // Low-l dense preconditioner of one diffuse component (CG_LMAX_PRECOND >= 0: updateLowlPrecond / applyLowlPrecond,
+    // comm_diffuse_comp_mod.f90:5098-5310, applied at comm_cr_mod.f90:1058-1073).  siN_lowres[b]: the band's
+    // N%siN_lowres (comm_N_rms_mod.f90:250-259), full-sky RING at nside_lowres[b], temperature column, host pointer.
+    // lmax_pre_lowl < 0 removes it.  The block is (re)built by precond_update_diag, as update_precond does.
+    void set_lowl(int comp, int lmax_pre_lowl, const int* nside_lowres, const double* const* siN_lowres);
     void precond_init_pseudoinv();    // alpha_nu (comm_N_rms_mod.f90:217-246) and the N maps of the T operator
     void precond_update_pseudoinv();  // updateDiffPrecond_pseudoinv (comm_diffuse_comp_mod.f90:1560-1658)
     const std::vector<double>& alpha_nu(int band) const { return bands_[band].alpha_nu; }
@@ -150,6 +156,18 @@ class CrSystem {
         DevBuf<double> sigma_dev, mean_dev, Minv;
         std::vector<CompactBand> P;
     };
+    struct LowL {
+        int comp = -1, L = -1;
+        std::vector<int> nside;                       // [nband]
+        std::vector<std::vector<double>> iN;          // [nband] siN_lowres^2, full sky
+        std::vector<std::unique_ptr<DevBuf<double>>> iN_dev;
+        DevBuf<double> Minv, xl, yl;                  // (L+1)^4, (L+1)^2, (L+1)^2
+        DevBuf<int64_t> idx;                          // stacked-vector position of (l, m), chain order l^2 + l + m
+        bool ready = false;
+    };
+    std::vector<LowL> lowl_;
+    std::map<int, std::unique_ptr<ShtPlan>> lowl_plans_;   // by nside_lowres * 65536 + 2 L
+    void lowl_update(LowL& W);
     struct MixCol { int bm, comp, stokes; };     // one scalar column / first column of a (Q,U) pair of a mixing batch
     struct MixBatch {
         std::vector<MixCol> T, P;
@@ -163,6 +181,7 @@ class CrSystem {
         DevBuf<double> w;                   // [nbm][ncomp][lmax+1]
         DevBuf<int> bm_stokes_dev;
         DevBuf<const double*> mul_ptrs;     // [nbm]
+        DevBuf<cd> that;                    // [nbm][that_elems]: circulant spectra of the mul maps (Toeplitz ring form)
         DevBuf<double> tmpmap;              // [nbm][npix_local] (RHS only; allocated lazily)
         std::vector<hipEvent_t> ev_synth, ev_ring;   // pipelined matvec: per batch of maps
         bool ring_pending = false;          // the adjoint must wait for ev_ring

@@ -800,7 +800,7 @@ __global__ void __launch_bounds__(1024) k_ring(const RingDev* __restrict__ rings
                                               const cd* __restrict__ tw, int log2Mmax,
                                               const cd* __restrict__ chirp, cd* __restrict__ scratch,
                                               int64_t scratch_map_stride, int scratch_line, int ncls, int nmaps,
-                                              int per, int xbl) {
+                                              int per, int xbl, const cd* __restrict__ that, int64_t that_stride) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     cd* buf = reinterpret_cast<cd*>(smem);
     // Workgroups with equal blockIdx % 8 share an XCD (and its L2).  Deal the class's ring pairs to the 8 groups in
@@ -816,13 +816,38 @@ __global__ void __launch_bounds__(1024) k_ring(const RingDev* __restrict__ rings
     const FftCtx c{(int)threadIdx.x, (int)blockDim.x};
     cd* sc = d.split ? scratch + imap * scratch_map_stride + (int64_t)(d.split - 1) * scratch_line : nullptr;
     ring_block<MODE>(buf, d, pair, ph + imap * ph_stride, npair_pad, map ? map + imap * map_stride : nullptr,
-                     mul ? mul[imap] : nullptr, weighted ? d.wgt : 1.0, tw, log2Mmax, chirp, sc, c);
+                     mul ? mul[imap] : nullptr, weighted ? d.wgt : 1.0, tw, log2Mmax, chirp, sc, c,
+                     that ? that + imap * that_stride : nullptr);
+}
+
+__global__ void __launch_bounds__(1024) k_ring_toeplitz_spec(const RingDev* __restrict__ rings, const int* __restrict__ cls,
+                                                            const double* __restrict__ td, int64_t npair_pad,
+                                                            cd* __restrict__ that, const cd* __restrict__ tw,
+                                                            int log2Mmax) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int pair = cls[blockIdx.x];
+    const RingDev d = rings[pair];
+    ring_toeplitz_spec(reinterpret_cast<cd*>(smem), d, td, npair_pad, pair, that, tw, log2Mmax,
+                       FftCtx{(int)threadIdx.x, (int)blockDim.x});
+}
+void launch_ring_toeplitz_spec(const RingDev* rings, const int* cls, int ncls, int log2M, const double* td,
+                               int64_t npair_pad, cd* that, const cd* tw, int log2Mmax, hipStream_t s) {
+    if (ncls == 0) return;
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_ring_toeplitz_spec),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        attr_set = true;
+    }
+    const int nthr = std::max(64, std::min(512, (1 << log2M) / 2));
+    hipLaunchKernelGGL(k_ring_toeplitz_spec, dim3(ncls), dim3(nthr), sizeof(cd) * (size_t)lds_elems(log2M), s, rings, cls, td,
+                       npair_pad, that, tw, log2Mmax);
 }
 
 void launch_ring(int mode, const RingDev* rings, const int* cls, int ncls, int log2M, double* ph,
                  int64_t ph_stride, int64_t npair_pad, double* map, int64_t map_stride, const double* const* mul,
                  int weighted, const cd* tw, int log2Mmax, const cd* chirp, cd* scratch, int64_t scratch_map_stride,
-                 int scratch_line, int nmaps, hipStream_t s) {
+                 int scratch_line, int nmaps, hipStream_t s, const cd* that, int64_t that_stride) {
     if (ncls == 0 || nmaps == 0) return;
     const size_t lds = sizeof(cd) * (size_t)lds_elems(log2M);
     int nthr = 512;   // measured: 512 > 256 threads per ring pair (more waves to cover LDS / global latency)
@@ -843,7 +868,7 @@ void launch_ring(int mode, const RingDev* rings, const int* cls, int ncls, int l
         }                                                                                                        \
         hipLaunchKernelGGL(k_ring<MM>, grid, dim3(nthr), lds, s, rings, cls, ph, ph_stride, npair_pad, map,      \
                            map_stride, mul, weighted, tw, log2Mmax, chirp, scratch, scratch_map_stride,          \
-                           scratch_line, ncls, nmaps, per, xbl);                                                 \
+                           scratch_line, ncls, nmaps, per, xbl, that, that_stride);                              \
     } while (0)
     if (mode == 0) CMDR_RING(0);
     else if (mode == 1) CMDR_RING(1);

@@ -22,7 +22,10 @@ void launch_leg_adj(const LegArgs& A, const WaveTask* tasks, int ntasks, const d
 void launch_ring(int mode, const RingDev* rings, const int* cls, int ncls, int log2M, double* ph,
                  int64_t ph_stride, int64_t npair_pad, double* map, int64_t map_stride, const double* const* mul,
                  int weighted, const cd* tw, int log2Mmax, const cd* chirp, cd* scratch, int64_t scratch_map_stride,
-                 int scratch_line, int nmaps, hipStream_t s);
+                 int scratch_line, int nmaps, hipStream_t s, const cd* that = nullptr, int64_t that_stride = 0);
+// multiplier spectra of the Toeplitz pairs in cls (class log2M = their circulant size) from t_d in phase layout
+void launch_ring_toeplitz_spec(const RingDev* rings, const int* cls, int ncls, int log2M, const double* td,
+                               int64_t npair_pad, cd* that, const cd* tw, int log2Mmax, hipStream_t s);
 void launch_alm_to_stream(const double* alm, int64_t alm_stride, double* ast, const double* cnorm, int lmax,
                           int nmaps, hipStream_t s);
 void launch_part_to_alm(const double* part, int64_t pms, int64_t pcs, int nchunk, double* alm, int64_t alm_stride,
@@ -82,6 +85,9 @@ void launch_dense_mv(const double* M, const double* x, double* y, int n, hipStre
 // mode 0: out = a * s ; 1: out = a / s ; 2: out = a * s + b ; 3: out = a * s + b + c / s  (b, c nullable -> 0)
 void launch_vec_scale(int mode, const double* a, const double* sc, const double* b, const double* c, double* out, int n,
                       hipStream_t s);
+// dst[i] = src[idx[i]] (scatter = false) or dst[idx[i]] = src[i] (scatter = true), i < n: the low-l preconditioner's
+// (l, m) <-> stacked-vector bookkeeping
+void launch_index_copy(const double* src, const int64_t* idx, double* dst, int n, bool scatter, hipStream_t s);
 void launch_phase_share(double* base, int64_t slot_stride, int n, int64_t elems, bool sum, hipStream_t s);
 void launch_alm_chain(double* alm, int64_t alm_stride, float* c32, int lmax, int nmaps, bool to_chain, hipStream_t s);
 void launch_sigma_l(const double* alm, int64_t stride, int lmax, int nmaps, double* out, hipStream_t s);

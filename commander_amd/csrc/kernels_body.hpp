@@ -609,6 +609,8 @@ struct RingDev {  // device mirror of RingPairDesc
     long long chirp_off;   // per-length table: rot[n] (, w[nt], chat[M] for Bluestein; nt = n or n/2 if split)
     int ring;
     int split;             // 0, or 1 + index of this pair's scratch line (ring transformed as two half-length pieces)
+    int log2T;             // 0, or log2 of the circulant size of this pair's Toeplitz form of Y^t diag(mul) Y (below)
+    long long that_off;    // offset of the pair's multiplier spectrum in a per-map array (complex units)
 };
 
 // HEALPix rings have n*phi0 = pi (phi0 = pi/(4i), n = 4i; belt: pi/(4N), n = 4N) or phi0 = 0, hence
@@ -836,6 +838,76 @@ CMDR_HD cd ring_split_input(const double* __restrict__ ph, int64_t npair_pad, in
     return cmul(csub(a, b), rot[2 * j2]);
 }
 
+// ---------------------------------------------------------------------------------------------------------
+// Toeplitz form of the fused ring operator (mode 2) for rings whose length is not a power of two.
+// On one ring  G_m = sum_k mul_k e^{-i m phi_k} sum_{m'} F_m' e^{+i m' phi_k} = sum_{m'} t_{m-m'} F_m' ,
+//   t_d = sum_k mul_k e^{-i d phi_k}   (|d| <= 2 mmax; t_{-d} = conj t_d; F_{-m} = conj F_m),
+// a Toeplitz product, i.e. a circular convolution of any length M >= 4 mmax + 1 -- a power of two, so the two
+// Bluestein transforms per direction (4 FFTs of M_B >= 2 n - 1) become 2 radix-2 FFTs of M_T <= M_B, with no chirp
+// products and no e^{i m phi0} rotations (they are inside t_d).  The pixel multiplier is replaced by its circulant
+// spectrum  tau(k) / M = (1/M) sum_d t_d e^{2 pi i d k / M}  (real), built once per multiplier map by
+// ring_toeplitz_spec from t_d (= the mode-1 transform of the multiplier map itself, run up to 2 mmax).
+// North and south ring share one complex FFT exactly as in the pixel form (real part north, imaginary part south).
+CMDR_HD void ring_toeplitz_load(cd* buf, int lg, int mmax, const double* __restrict__ ph, int64_t npair_pad, int pair,
+                                FftCtx c) {
+    const int M = 1 << lg;
+    for (int j = mmax + 1 + c.tid; j < M - mmax; j += c.nthr) buf[lds_pad(d_bitrev(j, lg))] = {0.0, 0.0};
+    constexpr int U = 4;
+    for (int m0 = c.tid; m0 <= mmax; m0 += U * c.nthr) {
+        double f[U][4];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int m = m0 + u * c.nthr;
+            const double* q = ph + ((int64_t)(m <= mmax ? m : mmax) * npair_pad + pair) * 4;
+            f[u][0] = q[0]; f[u][1] = q[1]; f[u][2] = q[2]; f[u][3] = q[3];
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int m = m0 + u * c.nthr;
+            if (m > mmax) continue;
+            buf[lds_pad(d_bitrev(m, lg))] = {f[u][0] - f[u][3], f[u][1] + f[u][2]};                    // F^N_m + i F^S_m
+            if (m > 0) buf[lds_pad(d_bitrev(M - m, lg))] = {f[u][0] + f[u][3], f[u][2] - f[u][1]};     // conj F^N + i conj F^S
+        }
+    }
+    CMDR_BLOCK_SYNC();
+}
+
+// phases (in place) -> G = T F for one ring pair; that = this map's multiplier spectra
+CMDR_HD void ring_toeplitz_apply(cd* buf, const RingDev& d, double* __restrict__ ph, int64_t npair_pad, int pair,
+                                 const cd* __restrict__ that, const cd* __restrict__ tw, int log2Mmax, FftCtx c) {
+    const int lg = d.log2T, M = 1 << lg, mmax = d.mmax_eff;
+    ring_toeplitz_load(buf, lg, mmax, ph, npair_pad, pair, c);
+    fft_dit_plus(buf, lg, tw, log2Mmax, c);                       // x(k) = sum_j Z_j e^{+2 pi i jk/M}: (north, south) real signals
+    const cd* __restrict__ T = that + d.that_off;
+    for (int k = c.tid; k < M; k += c.nthr) {
+        const cd z = buf[lds_pad(k)], t = T[k];
+        buf[lds_pad(k)] = {z.x * t.x, -(z.y * t.y)};              // conj(y_k): input form of the forward transform
+    }
+    CMDR_BLOCK_SYNC();
+    fft_dif_plus(buf, lg, tw, log2Mmax, c);                       // Y_j = conj(buf[bitrev j])
+    for (int j = c.tid; j <= mmax; j += c.nthr) {
+        const cd a = cconj(buf[lds_pad(d_bitrev(j, lg))]);
+        const cd b = buf[lds_pad(d_bitrev(j == 0 ? 0 : M - j, lg))];   // conj(Y_{M-j})
+        double* o = ph + ((int64_t)j * npair_pad + pair) * 4;
+        o[0] = 0.5 * (a.x + b.x); o[1] = 0.5 * (a.y + b.y);           // G^N_j = (Y_j + conj Y_{M-j}) / 2
+        o[2] = 0.5 * (a.y - b.y); o[3] = -0.5 * (a.x - b.x);          // G^S_j = (Y_j - conj Y_{M-j}) / (2i)
+    }
+}
+
+// multiplier spectrum of one ring pair: td = phase-layout array holding t_d (north, south) for d <= 2 mmax
+CMDR_HD void ring_toeplitz_spec(cd* buf, const RingDev& d, const double* __restrict__ td, int64_t npair_pad, int pair,
+                                cd* __restrict__ that, const cd* __restrict__ tw, int log2Mmax, FftCtx c) {
+    const int lg = d.log2T, M = 1 << lg;
+    ring_toeplitz_load(buf, lg, 2 * d.mmax_eff, td, npair_pad, pair, c);
+    fft_dit_plus(buf, lg, tw, log2Mmax, c);                       // tau^N(k) + i tau^S(k), both real
+    const double inv = 1.0 / (double)M;
+    cd* __restrict__ T = that + d.that_off;
+    for (int k = c.tid; k < M; k += c.nthr) {
+        const cd v = buf[lds_pad(k)];
+        T[k] = {v.x * inv, v.y * inv};
+    }
+}
+
 // Whole ring-pair job of one workgroup.  MODE 0: phases -> map (* mul * weight); 1: map (* mul * weight) -> phases;
 // 2: phases -> pixels * mul -> phases (the fused Y^t N^-1 Y core of the matvec; the map never exists in HBM).
 // Every pointwise step (Bluestein's closing chirp factor, the pixel multiplier, the analysis input form, zero padding)
@@ -878,7 +950,11 @@ template <int MODE>
 CMDR_HD void ring_block(cd* buf, const RingDev& d, int pair, double* __restrict__ php, int64_t npair_pad,
                         double* __restrict__ mp, const double* __restrict__ mu, double wg,
                         const cd* __restrict__ tw, int log2Mmax, const cd* __restrict__ chirp,
-                        cd* __restrict__ scratch, FftCtx c) {
+                        cd* __restrict__ scratch, FftCtx c, const cd* __restrict__ that = nullptr) {
+    if (MODE == 2 && that && d.log2T) {
+        ring_toeplitz_apply(buf, d, php, npair_pad, pair, that, tw, log2Mmax, c);
+        return;
+    }
     const int n = d.nphi;
     const FftSub f = ring_fft_desc(d, chirp);
     if (!d.split) {

@@ -387,6 +387,7 @@ void RingTables::build(int nside_, int lmax_, const std::vector<int>& rings, con
     }
     npix_local = off;
     log2Mmax = 1;
+    that_elems = 0;
     nsplit = 0;
     split_line = 0;
     constexpr int kMaxLog2M = 13;   // 8192 complex + padding = 147 KB of the 160 KB LDS
@@ -458,12 +459,37 @@ void RingTables::build(int nside_, int lmax_, const std::vector<int>& rings, con
             d.chirp_off = it->second;
         }
         log2Mmax = std::max(log2Mmax, d.log2M);
+        // Toeplitz form of the fused operator: worth it when its power-of-two circulant is no longer than the
+        // Bluestein image (2 radix-2 FFTs instead of 4); split rings keep the pixel form
+        d.log2T = 0;
+        d.that_off = 0;
+        if (d.bluestein && !d.split && d.mmax_eff >= 0) {
+            int lt = 1;
+            while ((1 << lt) < 4 * d.mmax_eff + 1) ++lt;
+            if (lt <= d.log2M) {
+                d.log2T = lt;
+                d.that_off = that_elems;
+                that_elems += (int64_t)1 << lt;
+            }
+        }
     }
-    if (std::getenv("CMDR_DEBUG_PLAN")) std::fprintf(stderr, "[cmdr] ring plan nside=%d: %d pairs, %d split (line %d), log2Mmax %d\n", nside, npair, nsplit, split_line, log2Mmax);
+    if (const char* e = std::getenv("CMDR_RING_TOEPLITZ")) if (std::atoi(e) == 0) { for (auto& d : pairs) d.log2T = 0; that_elems = 0; }
+    if (std::getenv("CMDR_DEBUG_PLAN")) {
+        int nt = 0;
+        for (const RingPairDesc& d : pairs) nt += d.log2T != 0;
+        std::fprintf(stderr, "[cmdr] ring plan nside=%d: %d pairs, %d split (line %d), log2Mmax %d, %d pairs in Toeplitz form (%lld spectrum entries per map)\n",
+                     nside, npair, nsplit, split_line, log2Mmax, nt, (long long)that_elems);
+    }
     classes.assign(log2Mmax + 1, {});
     // launch classes = LDS image size; the short rings (a few hundred workgroups per size) share one launch
     const int kMinClass = std::min(log2Mmax, 10);
-    for (int p = 0; p < npair; ++p) classes[std::max(pairs[p].log2M, kMinClass)].push_back(p);
+    classes_t.assign(log2Mmax + 1, {});
+    classes_tb.assign(log2Mmax + 1, {});
+    for (int p = 0; p < npair; ++p) {
+        classes[std::max(pairs[p].log2M, kMinClass)].push_back(p);
+        classes_t[std::max(pairs[p].log2T ? pairs[p].log2T : pairs[p].log2M, kMinClass)].push_back(p);
+        if (pairs[p].log2T) classes_tb[std::max(pairs[p].log2M, kMinClass)].push_back(p);
+    }
     const int Mmax = 1 << log2Mmax;
     twiddle.resize(Mmax);  // Mmax/2 complex
     for (int k = 0; k < Mmax / 2; ++k) {

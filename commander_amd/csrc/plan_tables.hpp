@@ -82,6 +82,8 @@ struct RingPairDesc {   // one north/south ring pair (or the equator alone: star
     double wgt;         // analysis weight W_ring * 4 pi / Npix
     int64_t chirp_off;  // offset into chirp table (Bluestein only)
     int ring;           // northern ring number 1..2*nside
+    int log2T;          // 0, or log2 of the circulant size M_T >= 4 mmax_eff + 1 of the pair's Toeplitz form (mode 2)
+    int64_t that_off;   // offset of the pair's multiplier spectrum (complex units) in a per-map array of that_elems
 };
 
 struct RingTables {
@@ -89,6 +91,10 @@ struct RingTables {
     int64_t npix_local = 0;
     std::vector<RingPairDesc> pairs;          // [npair]
     std::vector<std::vector<int>> classes;    // classes[log2M] = pair indices
+    // mode 2 with multiplier spectra (kernels_body.hpp, Toeplitz form): pairs classed by the LDS image they then need;
+    // classes_tb = the Toeplitz pairs by their Bluestein class (setup: t_d comes from a mode-1 transform)
+    std::vector<std::vector<int>> classes_t, classes_tb;
+    int64_t that_elems = 0;
     int log2Mmax = 0;
     int nsplit = 0, split_line = 0;           // number of split pairs, complex elements per scratch line (max n/2)
     std::vector<double> twiddle;              // [2 * Mmax/2]  exp(2 pi i k / Mmax), k < Mmax/2 (re,im)

@@ -78,13 +78,28 @@ ShtPlan::ShtPlan(int nside, int lmax, const std::vector<int>& rings, const doubl
         r.chirp_off = d.chirp_off;
         r.ring = d.ring;
         r.split = d.split;
+        r.log2T = d.log2T;
+        r.that_off = d.that_off;
     }
     rings_.upload(rd);
-    cls_.resize(T_.ring.classes.size());
-    ncls_.resize(T_.ring.classes.size());
-    for (size_t c = 0; c < T_.ring.classes.size(); ++c) {
-        ncls_[c] = (int)T_.ring.classes[c].size();
-        if (ncls_[c]) cls_[c].upload(T_.ring.classes[c]);
+    auto up = [](const std::vector<std::vector<int>>& src, std::vector<DevBuf<int>>& dst, std::vector<int>& n) {
+        dst.resize(src.size());
+        n.resize(src.size());
+        for (size_t c = 0; c < src.size(); ++c) {
+            n[c] = (int)src[c].size();
+            if (n[c]) dst[c].upload(src[c]);
+        }
+    };
+    up(T_.ring.classes, cls_, ncls_);
+    if (T_.ring.that_elems) {
+        up(T_.ring.classes_t, cls_t_, ncls_t_);
+        up(T_.ring.classes_tb, cls_tb_, ncls_tb_);
+        std::vector<std::vector<int>> ts(T_.ring.classes_t.size());      // the Toeplitz pairs by circulant class
+        for (size_t c = 0; c < ts.size(); ++c)
+            for (int p : T_.ring.classes_t[c]) if (T_.ring.pairs[p].log2T) ts[c].push_back(p);
+        up(ts, cls_ts_, ncls_ts_);
+        for (int p = 0; p < T_.ring.npair; ++p) if (rd[p].log2T) rd[p].mmax_eff *= 2;
+        rings_t2_.upload(rd);
     }
     tw_.upload(T_.ring.twiddle);
     chirp_.upload(T_.ring.chirp);
@@ -114,15 +129,43 @@ void ShtPlan::synth_from_stream(int nmaps, hipStream_t s) {
 }
 
 void ShtPlan::rings(int mode, double* d_map, int64_t map_stride, const double* const* d_mul, bool weighted,
-                    int nmaps, hipStream_t s) {
-    for (size_t c = 0; c < cls_.size(); ++c) {
-        if (!ncls_[c]) continue;
-        launch_ring(mode, rings_.get(), cls_[c].get(), ncls_[c], (int)c, ph_.get(), leg_.ph_elems(),
+                    int nmaps, hipStream_t s, const cd* that) {
+    const bool tz = mode == 2 && that && T_.ring.that_elems;      // classes follow the LDS image each pair then needs
+    const std::vector<DevBuf<int>>& cls = tz ? cls_t_ : cls_;
+    const std::vector<int>& ncls = tz ? ncls_t_ : ncls_;
+    for (size_t c = 0; c < cls.size(); ++c) {
+        if (!ncls[c]) continue;
+        launch_ring(mode, rings_.get(), cls[c].get(), ncls[c], (int)c, ph_.get(), leg_.ph_elems(),
                     leg_.npair_pad, d_map, map_stride, d_mul, weighted ? 1 : 0,
                     reinterpret_cast<const cd*>(tw_.get()), T_.ring.log2Mmax,
                     reinterpret_cast<const cd*>(chirp_.get()), reinterpret_cast<cd*>(ring_scratch_.get()),
-                    (int64_t)T_.ring.nsplit * T_.ring.split_line, T_.ring.split_line, nmaps, s);
+                    (int64_t)T_.ring.nsplit * T_.ring.split_line, T_.ring.split_line, nmaps, s, tz ? that : nullptr,
+                    T_.ring.that_elems);
     }
+}
+
+void ShtPlan::toeplitz_build(const std::vector<const double*>& mul_host, DevBuf<cd>& out, hipStream_t s) {
+    const int64_t ne = T_.ring.that_elems;
+    if (!ne || mul_host.empty()) { out.release(); return; }
+    out.alloc((size_t)ne * mul_host.size());
+    // t_d = sum_k mul_k e^{-i d phi_k}, d <= 2 mmax: the analysis ring transform (mode 1) of the multiplier map itself,
+    // stored like phases in a scratch array of 2 lmax + 1 rows
+    int rows = 1;
+    for (const RingPairDesc& d : T_.ring.pairs) if (d.log2T) rows = std::max(rows, 2 * d.mmax_eff + 1);
+    DevBuf<double> td((size_t)rows * leg_.npair_pad * 4);
+    const cd* tw = reinterpret_cast<const cd*>(tw_.get());
+    for (size_t k = 0; k < mul_host.size(); ++k) {
+        for (size_t c = 0; c < cls_tb_.size(); ++c)
+            if (ncls_tb_[c])
+                launch_ring(1, rings_t2_.get(), cls_tb_[c].get(), ncls_tb_[c], (int)c, td.get(), 0, leg_.npair_pad,
+                            const_cast<double*>(mul_host[k]), 0, nullptr, 0, tw, T_.ring.log2Mmax,
+                            reinterpret_cast<const cd*>(chirp_.get()), nullptr, 0, 0, 1, s);
+        for (size_t c = 0; c < cls_ts_.size(); ++c)
+            if (ncls_ts_[c])
+                launch_ring_toeplitz_spec(rings_.get(), cls_ts_[c].get(), ncls_ts_[c], (int)c, td.get(), leg_.npair_pad,
+                                          out.get() + (int64_t)k * ne, tw, T_.ring.log2Mmax, s);
+    }
+    CMDR_HIP_CHECK(hipStreamSynchronize(s));   // td is released on return
 }
 
 void ShtPlan::synth_range(int k0, int n, int nbs, hipStream_t s) {

@@ -77,8 +77,14 @@ class ShtPlan {
     double* partials() { return part_.get(); }             // [max_maps][nchunk][tri_elems]
     int64_t part_map_stride() const { return (int64_t)leg_.nchunk * leg_.tri_elems(); }
     void synth_from_stream(int nmaps, hipStream_t s);                                // stream -> phases
+    // that (mode 2 only): multiplier spectra from toeplitz_build() for the same d_mul maps -> cap rings take the
+    // Toeplitz form (kernels_body.hpp) instead of two Bluestein transforms per direction
     void rings(int mode, double* d_map, int64_t map_stride, const double* const* d_mul, bool weighted, int nmaps,
-               hipStream_t s);                                                       // see launch_ring
+               hipStream_t s, const cd* that = nullptr);                             // see launch_ring
+    // Circulant spectra of nmaps pixel multiplier maps (HOST array of device pointers, the maps rings(2, ...) will be
+    // given): [nmaps][that_elems()] complex.  Setup-time (once per noise / mixing map); empty plan part -> size 0.
+    int64_t that_elems() const { return T_.ring.that_elems; }
+    void toeplitz_build(const std::vector<const double*>& mul_host, DevBuf<cd>& out, hipStream_t s);
     void adjoint_to_partials(int nmaps, bool square, hipStream_t s);                 // phases -> partials
     // the same three stages on maps k0 .. k0+n-1 of a stream holding nbs maps (pipelined matvec: the ring stage of
     // one batch runs beside the Legendre stage of the next)
@@ -94,9 +100,9 @@ class ShtPlan {
     int max_maps_;
     bool pol_ = false;
     DevBuf<double> st2_, part2_;
-    DevBuf<RingDev> rings_;
-    std::vector<DevBuf<int>> cls_;
-    std::vector<int> ncls_;
+    DevBuf<RingDev> rings_, rings_t2_;           // rings_t2_: Toeplitz pairs with mmax_eff doubled (t_d setup transform)
+    std::vector<DevBuf<int>> cls_, cls_t_, cls_tb_, cls_ts_;
+    std::vector<int> ncls_, ncls_t_, ncls_tb_, ncls_ts_;
     DevBuf<double> tw_, chirp_, ring_scratch_;   // ring_scratch_: one line of n/2 complex per split ring pair and map
     DevBuf<double> ast_, ph_, part_;
     DevBuf<double> share_map_;   // pixel maps of sandwich()'s shared scalar columns (allocated on first use)

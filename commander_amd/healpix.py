@@ -53,3 +53,67 @@ def local_pixels(nside, rings):
         nphi, _, _, start = ring_info(nside, i)
         out.append(np.arange(start, start + nphi))
     return np.concatenate(out)
+
+
+# ---- RING <-> (x, y, face) of the published HEALPix scheme: what HEALPix' udgrade needs (a pixel's parent at a lower
+# resolution is (x >> k, y >> k) on the same base face).  Used to build the low-resolution noise maps that Commander's
+# comm_N_rms keeps (siN_lowres, comm_N_rms_mod.f90:250-259) for the synthetic test problems; the library receives them
+# from the driver like every other per-band data product.
+_JRLL = np.array([2, 2, 2, 2, 3, 3, 3, 3, 4, 4, 4, 4])
+_JPLL = np.array([1, 3, 5, 7, 0, 2, 4, 6, 1, 3, 5, 7])
+
+
+def ring2xyf(nside, pix):
+    pix = np.asarray(pix, dtype=np.int64)
+    N = int(nside)
+    ncap, npix, nl2 = 2 * N * (N - 1), 12 * N * N, 2 * N
+    iring, iphi, kshift, nr, face = (np.zeros(pix.shape, dtype=np.int64) for _ in range(5))
+    north, south = pix < ncap, pix >= npix - ncap
+    belt = ~(north | south)
+    p = pix[north]
+    ir = (1 + np.floor(np.sqrt(1.0 + 2.0 * p)).astype(np.int64)) >> 1
+    ir = np.where(2 * ir * (ir - 1) > p, ir - 1, ir)                    # guard the float square root
+    ir = np.where(2 * ir * (ir + 1) <= p, ir + 1, ir)
+    iring[north], iphi[north], nr[north] = ir, p + 1 - 2 * ir * (ir - 1), ir
+    face[north] = (iphi[north] - 1) // ir
+    p = pix[belt] - ncap
+    tmp = p // (4 * N)
+    iring[belt], iphi[belt], nr[belt] = tmp + N, p - tmp * 4 * N + 1, N
+    kshift[belt] = (tmp + N + N) & 1
+    ire, irm = tmp + 1, nl2 + 1 - tmp
+    ifm, ifp = (iphi[belt] - ire // 2 + N - 1) // N, (iphi[belt] - irm // 2 + N - 1) // N
+    face[belt] = np.where(ifp == ifm, ifp | 4, np.where(ifp < ifm, ifp, ifm + 8))
+    p = npix - pix[south]
+    ir = (1 + np.floor(np.sqrt(2.0 * p - 1.0)).astype(np.int64)) >> 1
+    ir = np.where(2 * ir * (ir - 1) >= p, ir - 1, ir)
+    ir = np.where(2 * ir * (ir + 1) < p, ir + 1, ir)
+    iphi[south], nr[south] = 4 * ir + 1 - (p - 2 * ir * (ir - 1)), ir
+    iring[south] = 2 * nl2 - ir
+    face[south] = 8 + (iphi[south] - 1) // ir
+    irt = iring - _JRLL[face] * N + 1
+    ipt = 2 * iphi - _JPLL[face] * nr - kshift - 1
+    ipt = np.where(ipt >= nl2, ipt - 8 * N, ipt)
+    return (ipt - irt) >> 1, (-ipt - irt) >> 1, face
+
+
+def xyf2ring(nside, ix, iy, face):
+    N = int(nside)
+    ncap, npix, nl4 = 2 * N * (N - 1), 12 * N * N, 4 * N
+    jr = _JRLL[face] * N - ix - iy - 1
+    north, south = jr < N, jr > 3 * N
+    nr = np.where(north, jr, np.where(south, nl4 - jr, N))
+    n_before = np.where(north, 2 * nr * (nr - 1), np.where(south, npix - 2 * (nr + 1) * nr, ncap + (jr - N) * nl4))
+    kshift = np.where(north | south, 0, (jr - N) & 1)
+    jp = (_JPLL[face] * nr + ix - iy + 1 + kshift) // 2
+    jp = np.where(jp > nl4, jp - nl4, jp)
+    jp = np.where(jp < 1, jp + nl4, jp)
+    return n_before + jp - 1
+
+
+def udgrade_sum_ring(m, nside_in, nside_out):
+    """Sum of a RING map over the children of every pixel of the coarser RING map (nside_out divides nside_in)."""
+    assert nside_in % nside_out == 0
+    k = int(np.log2(nside_in // nside_out))
+    ix, iy, f = ring2xyf(nside_in, np.arange(12 * nside_in * nside_in))
+    parent = xyf2ring(nside_out, ix >> k, iy >> k, f)
+    return np.bincount(parent, weights=np.asarray(m, dtype=np.float64), minlength=12 * nside_out * nside_out)

@@ -76,6 +76,7 @@ def _sig(L):
     L.cmdr_precond_init_diag.argtypes = [c_vp]
     L.cmdr_precond_update_diag.argtypes = [c_vp]
     L.cmdr_get_invN_diag.argtypes = [c_vp, c_int, dp]
+    L.cmdr_precond_set_lowl.argtypes = [c_vp, c_int, c_int, ip, pdp]
     L.cmdr_precond_init_pseudoinv.argtypes = [c_vp]
     L.cmdr_precond_update_pseudoinv.argtypes = [c_vp]
     L.cmdr_get_alpha_nu.argtypes = [c_vp, c_int, dp]

@@ -244,3 +244,15 @@ def draw_inputs(spec):
         xi.append(x)
     eta = rng(3, 0).standard_normal(ncr_of(spec))
     return resid, xi, eta
+
+
+def lowres_noise(spec, nside_lowres):
+    """``data(b)%N%siN_lowres`` of every band (comm_N_rms_mod.f90:250-259): sqrt(udgrade(siN^2)) * nside / nside_lowres,
+    i.e. the square root of the summed inverse variance of a coarse pixel's children.  Needs full-sky bands (the driver
+    side of a sharded run builds it before scattering the maps)."""
+    out = []
+    for b in spec["bands"]:
+        s = np.asarray(b["siN"], dtype=np.float64).reshape(12 * b["nside"] ** 2, -1)[:, 0]
+        ns = min(int(nside_lowres), b["nside"])
+        out.append((ns, np.sqrt(healpix.udgrade_sum_ring(s * s, b["nside"], ns))))
+    return out

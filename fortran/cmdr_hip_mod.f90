@@ -103,6 +103,43 @@ module cmdr_hip_mod
        integer(c_int)        :: ierr
      end function cmdr_ctx_set_band_sharding
 
+     ! RCCL inside the library: id = 128 bytes from cmdr_rccl_unique_id on ONE rank, MPI_Bcast by the driver, then
+     ! every rank calls cmdr_ctx_init_rccl (collective).  All sums over ranks of the CR path then run as ncclAllReduce
+     ! on the library's own stream: what mpi_dot_product / libsharp2's exchange do in comm_cr_mod (comm_utils.f90:599-614)
+     function cmdr_rccl_unique_id(out128) bind(c, name='cmdr_rccl_unique_id') result(ierr)
+       import :: c_int, c_char
+       character(kind=c_char), intent(out) :: out128(128)
+       integer(c_int)                      :: ierr
+     end function cmdr_rccl_unique_id
+
+     function cmdr_rccl_version() bind(c, name='cmdr_rccl_version') result(v)
+       import :: c_int
+       integer(c_int) :: v
+     end function cmdr_rccl_version
+
+     function cmdr_ctx_init_rccl(ctx, id128, rank, nranks) bind(c, name='cmdr_ctx_init_rccl') result(ierr)
+       import :: c_int, c_ptr, c_char
+       type(c_ptr),    value              :: ctx
+       character(kind=c_char), intent(in) :: id128(128)
+       integer(c_int), value              :: rank, nranks
+       integer(c_int)                     :: ierr
+     end function cmdr_ctx_init_rccl
+
+     ! band x ring-set hybrid without callbacks: ncclCommSplit(color = band_group, key = ring_index); collective
+     function cmdr_ctx_rccl_split_rings(ctx, band_group, ring_index, ring_replicas) &
+          & bind(c, name='cmdr_ctx_rccl_split_rings') result(ierr)
+       import :: c_int, c_ptr
+       type(c_ptr),    value :: ctx
+       integer(c_int), value :: band_group, ring_index, ring_replicas
+       integer(c_int)        :: ierr
+     end function cmdr_ctx_rccl_split_rings
+
+     function cmdr_ctx_rccl_size(ctx) bind(c, name='cmdr_ctx_rccl_size') result(n)
+       import :: c_int, c_ptr
+       type(c_ptr), value :: ctx
+       integer(c_int)     :: n
+     end function cmdr_ctx_rccl_size
+
      function cmdr_band_add(ctx, nside, lmax, nmaps, siN, b_l, mb_eff, sg_mask, wring) &
           & bind(c, name='cmdr_band_add') result(idx)
        import :: c_int, c_ptr, c_double

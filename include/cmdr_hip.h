@@ -167,6 +167,19 @@ int64_t cmdr_band_npix(const cmdr_ctx* ctx, int band);    /* local pixels per St
  * then updateDiffPrecond_diagonal (:1313-1557). */
 int cmdr_precond_init_diag(cmdr_ctx* ctx);
 int cmdr_precond_update_diag(cmdr_ctx* ctx);
+/* Low-l dense preconditioner of one diffuse component (CG_LMAX_PRECOND = lmax_pre_lowl >= 0 with the diagonal type;
+ * the reference enables it for the CMB component: comm_diffuse_comp_mod.f90:217-225).  updateLowlPrecond (:5098-5251)
+ * probes the (lmax_pre_lowl+1)^2 temperature block of A with unit vectors through low-resolution transforms
+ * (nside = N%nside_chisq_lowres, lmax = 2 lmax_pre_lowl) and the coadded noise InvN_lowres, adds the unit prior term
+ * and Cholesky-inverts; applyLowlPrecond (:5254-5310, called from cr_invM, comm_cr_mod.f90:1058-1073) overwrites the
+ * l <= lmax_pre_lowl temperature entries of M^-1 x with that inverse applied to the same entries of x.
+ *   nside_lowres[band], siN_lowres[band]: data(band)%N%siN_lowres (comm_N_rms_mod.f90:250-259: sqrt(udgrade(siN^2)) *
+ *   nside/nside_lowres), full-sky RING temperature map of 12 nside_lowres^2 doubles, produced by the driver (HEALPix
+ *   udgrade stays on the Fortran side like every other per-band data product).
+ * After cmdr_finalize; the block is (re)built by every cmdr_precond_update_diag, as update_precond does
+ * (comm_cr_mod.f90:1136-1147).  lmax_pre_lowl < 0 switches it off again. */
+int cmdr_precond_set_lowl(cmdr_ctx* ctx, int comp, int lmax_pre_lowl, const int* nside_lowres,
+                          const double* const* siN_lowres);
 /* Pseudo-inverse preconditioner, cg_precond = 'pseudoinv': alpha_nu of every band (comm_N_rms_mod.f90:217-246),
  * then updateDiffPrecond_pseudoinv (comm_diffuse_comp_mod.f90:1560-1658; SVD pseudo-inverse math_tools.f90:234-292).
  * cr_invM then runs applyDiffPrecond_pseudoinv (:2238-2380).  Whichever of the two update calls ran last selects the

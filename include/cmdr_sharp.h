@@ -10,9 +10,14 @@
  * any caller and is rejected.  Like libsharp2 the functions return void; on an unsupported request or a HIP failure
  * they print the reason and abort() -- libsharp2's own convention ("library aborts internally").
  *
- * Distribution: libsharp2 redistributes a_lm (by m) and rings across MPI ranks inside sharp_execute_mpi_fortran.
- * This library keeps a_lm replicated per GPU instead, so the literal entry point supports a chain of
- * ONE rank per communicator (every m local); multi-GPU runs use the CR-level API of cmdr_hip.h.
+ * Distribution: libsharp2 redistributes a_lm (by m) and rings across the MPI ranks of `comm` inside
+ * sharp_execute_mpi_fortran (ownership: comm_map_mod.f90:193-261 -- rank r of P owns rings r+1, r+1+P, ... with their
+ * mirrors and m = r, r+P, ...).  Here every rank transforms ITS rings with ALL m on its GPU, so the exchange is one sum
+ * of the full packed a_lm over the communicator (before the transform for Y / WY, after it for Yt / YtW).  The library
+ * does not link MPI: the driver registers, per communicator handle, a routine that sums a host buffer of doubles over
+ * that communicator (cmdr_sharp_register_comm; INTEGRATION.md shows the 6-line MPI_Allreduce wrapper).  An
+ * unregistered communicator must be a one-rank chain (every m and ring local).  The CR-level API of cmdr_hip.h keeps
+ * vectors resident and is the fast path; this level exists so that `module sharp` links unchanged.
  */
 #ifndef CMDR_SHARP_H
 #define CMDR_SHARP_H
@@ -43,7 +48,11 @@ void sharp_destroy_geom_info(sharp_geom_info* info);                          /*
 /* sharp.f90:86-94: alm / map = arrays of column pointers (void**) */
 void sharp_execute(int type, int spin, void* alm, void* map, const sharp_geom_info* geom_info,
                    const sharp_alm_info* alm_info, int flags, double* time, unsigned long long* opcnt);
-/* sharp.f90:96-104: comm = Fortran MPI communicator handle; must be a one-rank communicator here */
+/* In-place sum of n doubles at a HOST address over the ranks of one communicator; comm = the Fortran handle
+ * (MPI_Fint) the driver later passes to sharp_execute_mpi_fortran.  fn = NULL removes the registration. */
+typedef void (*cmdr_sharp_allreduce_fn)(void* user, double* host_buf, long long n);
+void cmdr_sharp_register_comm(int comm, cmdr_sharp_allreduce_fn fn, void* user);
+/* sharp.f90:96-104: comm = Fortran MPI communicator handle (registered above, or a one-rank communicator) */
 void sharp_execute_mpi_fortran(int comm, int type, int spin, void* alm, void* map, const sharp_geom_info* geom_info,
                                const sharp_alm_info* alm_info, int flags, double* time, unsigned long long* opcnt);
 

@@ -47,6 +47,14 @@ class Band:
         self.wring = wring
         self.info = healpix.AlmInfo(lmax)
         self.invN_diag = None
+        self.nside_lowres, self.siN_lowres = None, None   # comm_N_rms_mod.f90:250-259 (set_lowres)
+
+    def set_lowres(self, nside_lowres, siN_lowres):
+        """``N%siN_lowres`` of comm_N_rms (comm_N_rms_mod.f90:250-259): sqrt(udgrade(siN^2)) * (nside/nside_lowres), the
+        noise of the coadded low-resolution pixels; produced by the driver (HEALPix udgrade), consumed by InvN_lowres."""
+        s = np.asarray(siN_lowres, dtype=np.float64)
+        self.nside_lowres = int(nside_lowres)
+        self.siN_lowres = s.reshape(12 * self.nside_lowres ** 2, -1)
 
     def set_qucov(self, iN, siN_mat):
         """comm_N_QUcov (comm_N_QUcov_mod.f90:236-290): dense inverse covariance iN and its symmetric square root on the
@@ -252,6 +260,13 @@ class CompactBlock:
         self.active = active
         self.nmaps = 1
         self.cltype = "compact"
+
+
+class _LowBand:
+    """geometry holder for the low-resolution transforms of the low-l preconditioner (unit ring weights)"""
+
+    def __init__(self, nside):
+        self.nside, self.wring = int(nside), None
 
 
 class CRSystem:
@@ -734,7 +749,60 @@ class CRSystem:
         for k, Minv in getattr(self, "_compact_inv", {}).items():    # applyPtsrcPrecond / applyTemplatePrecond
             pos, n, _ = self.ind_comp[k]
             res[pos:pos + n] = Minv @ np.asarray(x)[pos:pos + n]
+        for k, (L, Minv) in getattr(self, "_lowl", {}).items():      # low-l preconditioner, comm_cr_mod.f90:1058-1073
+            self._apply_lowl(k, L, Minv, np.asarray(x), res)
         return res
+
+    # ------------------------------------------------------------------ low-l preconditioner (CG_LMAX_PRECOND >= 0)
+    def set_lowl(self, k, lmax_pre_lowl):
+        """comm_diffuse_comp_mod.f90:217-225: CMB component with the diagonal preconditioner type."""
+        self._lowl_cfg = getattr(self, "_lowl_cfg", {})
+        self._lowl_cfg[k] = int(lmax_pre_lowl)
+
+    def update_lowl(self):
+        """updateLowlPrecond (comm_diffuse_comp_mod.f90:5098-5251): dense (L+1)^2 block of A on the temperature a_lm with
+        l <= L, probed with unit vectors through low-resolution transforms (nside = N%nside_chisq_lowres, lmax = 2L) and
+        the coadded noise InvN_lowres; Cholesky-inverted.  Index of (l, m) in the block: l^2 + l + m."""
+        self._lowl = {}
+        for k, L in getattr(self, "_lowl_cfg", {}).items():
+            c = self.comps[k]
+            n = (L + 1) ** 2
+            info = healpix.AlmInfo(2 * L)                                       # :5117 (nside = 2 plays no role)
+            M = np.zeros((n, n))
+            for l in range(L + 1):
+                for m in range(-l, l + 1):
+                    alm = np.zeros((info.nalm, c.nmaps))
+                    alm[info.lm2i(l, m), 0] = 1.0                               # :5124-5126
+                    alm = c.Cl.sqrtS(alm, info)                                 # :5128
+                    tot = np.zeros((info.nalm, c.nmaps))
+                    for ib, b in enumerate(self.bands):                         # :5132-5181
+                        nm = min(c.nmaps, b.nmaps)
+                        a2 = alm[:, :nm] * c.F_mean[ib, :nm][None, :]
+                        a2 = b.conv(a2, info)                                   # :5141
+                        lowb = _LowBand(b.nside_lowres)
+                        mp = self._Y(lowb, a2, 2 * L)                           # :5147
+                        mp = mp * b.siN_lowres[:, :nm] ** 2                     # InvN_lowres, comm_N_rms_mod.f90:276-285
+                        a2 = b.conv(self._Yt(lowb, mp, 2 * L), info)            # :5159-5163
+                        tot[:, 0] += a2[:, 0] * c.F_mean[ib, 0]                 # :5168-5176: temperature column only
+                    tot = c.Cl.sqrtS(tot, info)                                 # :5184
+                    i = l * l + l + m
+                    for lp in range(L + 1):                                     # :5196-5210
+                        for mp_ in range(-lp, lp + 1):
+                            j = lp * lp + lp + mp_
+                            M[i, j] = tot[info.lm2i(lp, mp_), 0] + (1.0 if i == j else 0.0)
+            self._lowl[k] = (L, np.linalg.inv(M))                               # invert_matrix(cholesky) :5229
+
+    def _apply_lowl(self, k, L, Minv, x, res):
+        """applyLowlPrecond (:5254-5310): temperature a_lm with l <= L of cr_invM's result are replaced by the dense
+        inverse applied to the same entries of the INPUT vector (comm_cr_mod.f90:1064-1067)."""
+        c = self.comps[k]
+        alm_in = self.extract(k, x)
+        alm_out = self.extract(k, res)
+        ls = [(l, m) for l in range(L + 1) for m in range(-l, l + 1)]
+        idx = np.array([c.info.lm2i(l, m) for l, m in ls])
+        y = Minv @ alm_in[idx, 0]                                               # y = matmul(invM_lowl, yloc), invM_lowl(i, q) = invM(i, k_q)
+        alm_out[idx, 0] = y
+        self.insert(k, False, alm_out, res)
 
     # ------------------------------------------------------------------ solve_cr_eqn_by_CG
     def compute_chisq(self, x, resid):

@@ -345,3 +345,36 @@ def pol_pruned_checks(_lib=None, nside=256, lmax=512, tol=1e-11):
     ctx.initPrecond(); ctx.update_precond(); S.init_precond_diag(); S.update_precond_diag()
     assert rel(ctx.cr_invM(x), S.invM(x)) < tol
     assert np.array_equal(ctx.cr_matmulA(x), Ax1)
+
+
+def lowl_precond_checks(_lib=None, nside=16, lmax=32, L=6, nside_low=4, tol=1e-10):
+    """CG_LMAX_PRECOND: the low-l dense preconditioner block (updateLowlPrecond / applyLowlPrecond,
+    comm_diffuse_comp_mod.f90:5098-5310; cr_invM, comm_cr_mod.f90:1058-1073) against the oracle: cr_invM itself, a
+    fixed_iter solve through it, the rebuild after new C_l, and switching it off again."""
+    from commander_amd import synth
+    from commander_amd.cr import build_context
+    for pol in (False, True):
+        spec = synth.make_problem("cfg2", nside=nside, lmax=lmax, pol=pol, aniso=0.3)
+        low = synth.lowres_noise(spec, nside_low)
+        S = oracle_system(spec)
+        for B, (ns, m) in zip(S.bands, low):
+            B.set_lowres(ns, m)
+        ctx = build_context(spec, _lib=_lib)
+        ctx.initPrecond(); ctx.update_precond()
+        S.init_precond_diag(); S.update_precond_diag()
+        x = np.random.default_rng(8).standard_normal(ctx.ncr)
+        plain = ctx.cr_invM(x)
+        ctx.set_lowl_precond(0, L, [ns for ns, _ in low], [m for _, m in low])
+        ctx.update_precond()
+        S.set_lowl(0, L); S.update_lowl()
+        got, want = ctx.cr_invM(x), S.invM(x)
+        assert rel(got, want) < tol, rel(got, want)
+        n_low = (L + 1) ** 2
+        assert np.count_nonzero(got != plain) == n_low            # exactly the T entries with l <= L changed
+        resid, xi, eta = synth.draw_inputs(spec)
+        b = S.computeRHS(resid, "sample", xi, eta)
+        xg, ng, _, res = ctx.solve_cr_eqn_by_CG(b, "fixed_iter", maxiter=12)
+        xo, no, _ = S.solve(b, "fixed_iter", maxiter=12)
+        assert ng == no == 12 and rel(xg, xo) < 1e-8
+        ctx.set_lowl_precond(0, -1)
+        assert np.array_equal(ctx.cr_invM(x), plain)

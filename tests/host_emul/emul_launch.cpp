@@ -190,7 +190,7 @@ void launch_part2_to_alm(const double* part, int64_t part_pol_stride, int64_t pc
 void launch_ring(int mode, const RingDev* rings, const int* cls, int ncls, int log2M, double* ph,
                  int64_t ph_stride, int64_t npair_pad, double* map, int64_t map_stride, const double* const* mul,
                  int weighted, const cd* tw, int log2Mmax, const cd* chirp, cd* scratch, int64_t scratch_map_stride,
-                 int scratch_line, int nmaps, hipStream_t) {
+                 int scratch_line, int nmaps, hipStream_t, const cd* that, int64_t that_stride) {
     std::vector<cd> bufv((size_t)lds_elems(log2M));
     cd* buf = bufv.data();
     const FftCtx c{0, 1};
@@ -205,8 +205,18 @@ void launch_ring(int mode, const RingDev* rings, const int* cls, int ncls, int l
             cd* sc = d.split ? scratch + imap * scratch_map_stride + (int64_t)(d.split - 1) * scratch_line : nullptr;
             if (mode == 0) ring_block<0>(buf, d, pair, php, npair_pad, mp, mu, wg, tw, log2Mmax, chirp, sc, c);
             else if (mode == 1) ring_block<1>(buf, d, pair, php, npair_pad, mp, mu, wg, tw, log2Mmax, chirp, sc, c);
-            else ring_block<2>(buf, d, pair, php, npair_pad, mp, mu, wg, tw, log2Mmax, chirp, sc, c);
+            else ring_block<2>(buf, d, pair, php, npair_pad, mp, mu, wg, tw, log2Mmax, chirp, sc, c,
+                               that ? that + imap * that_stride : nullptr);
         }
+}
+
+void launch_ring_toeplitz_spec(const RingDev* rings, const int* cls, int ncls, int log2M, const double* td,
+                               int64_t npair_pad, cd* that, const cd* tw, int log2Mmax, hipStream_t) {
+    std::vector<cd> bufv((size_t)lds_elems(log2M));
+    for (int ib = 0; ib < ncls; ++ib) {
+        const int pair = cls[ib];
+        ring_toeplitz_spec(bufv.data(), rings[pair], td, npair_pad, pair, that, tw, log2Mmax, FftCtx{0, 1});
+    }
 }
 
 void launch_alm_to_stream(const double* alm, int64_t alm_stride, double* ast, const double* cnorm, int lmax,
@@ -317,6 +327,12 @@ void launch_cg_xr(double* x, double* r, const double* d, const double* q, int64_
 void launch_cg_d(double* d, const double* sv, int64_t n, const double* scal, int num, int den, hipStream_t) {
     const double beta = scal[num] / scal[den];
     for (int64_t i = 0; i < n; ++i) d[i] = sv[i] + beta * d[i];
+}
+void launch_index_copy(const double* src, const int64_t* idx, double* dst, int n, bool scatter, hipStream_t) {
+    for (int i = 0; i < n; ++i) {
+        if (scatter) dst[idx[i]] = src[i];
+        else dst[i] = src[idx[i]];
+    }
 }
 void launch_axpby(const double* a, const double* b, double cb, double* out, int64_t n, hipStream_t) {
     for (int64_t i = 0; i < n; ++i) out[i] = a[i] + cb * b[i];

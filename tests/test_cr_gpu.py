@@ -352,3 +352,9 @@ def test_compute_residual_and_chisq_full_size_properties_gpu():
     assert n == 3 and stat == 1 and np.all(np.isfinite(x))
     xf, nf, _, _ = ctx.solve_cr_eqn_by_CG(rhs, "fixed_iter", 1e-30, 5, 3, 1)
     assert nf == 3 and np.array_equal(x, xf)              # evaluating chisq does not disturb the iteration
+
+
+def test_lowl_preconditioner_gpu():
+    """CG_LMAX_PRECOND low-l dense block (updateLowlPrecond / applyLowlPrecond) on the GPU vs the oracle."""
+    from helpers import lowl_precond_checks
+    lowl_precond_checks(None, nside=32, lmax=64, L=8, nside_low=8)

@@ -450,3 +450,9 @@ def test_emul_polarised_pruned_plan_repeats_and_matches_oracle(EL):
     """on polarised plans the spin-0 tasks must cover the merged (m, ring) cut the ring stage uses,
     otherwise T slots keep analysis output of the previous call (history-dependent, non-symmetric A)."""
     pol_pruned_checks(EL, nside=256, lmax=512)
+
+
+def test_emul_lowl_preconditioner(EL):
+    """CG_LMAX_PRECOND low-l dense block, product vs oracle (T and T,Q,U components)."""
+    from helpers import lowl_precond_checks
+    lowl_precond_checks(EL)
