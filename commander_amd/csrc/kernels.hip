@@ -800,7 +800,8 @@ __global__ void __launch_bounds__(1024) k_ring(const RingDev* __restrict__ rings
                                               const cd* __restrict__ tw, int log2Mmax,
                                               const cd* __restrict__ chirp, cd* __restrict__ scratch,
                                               int64_t scratch_map_stride, int scratch_line, int ncls, int nmaps,
-                                              int per, int xbl, const cd* __restrict__ that, int64_t that_stride) {
+                                              int per, int xbl, const cd* __restrict__ that, int64_t that_stride,
+                                              int tw_off) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     cd* buf = reinterpret_cast<cd*>(smem);
     // Workgroups with equal blockIdx % 8 share an XCD (and its L2).  Deal the class's ring pairs to the 8 groups in
@@ -813,7 +814,8 @@ __global__ void __launch_bounds__(1024) k_ring(const RingDev* __restrict__ rings
     if (pl >= per || idx >= ncls) return;
     const int pair = cls[idx];
     const RingDev d = rings[pair];
-    const FftCtx c{(int)threadIdx.x, (int)blockDim.x};
+    FftCtx c{(int)threadIdx.x, (int)blockDim.x};
+    if (tw_off) ring_tw_fill(buf + tw_off, tw, log2Mmax, c);   // visible after the first block barrier (before any FFT pass)
     cd* sc = d.split ? scratch + imap * scratch_map_stride + (int64_t)(d.split - 1) * scratch_line : nullptr;
     ring_block<MODE>(buf, d, pair, ph + imap * ph_stride, npair_pad, map ? map + imap * map_stride : nullptr,
                      mul ? mul[imap] : nullptr, weighted ? d.wgt : 1.0, tw, log2Mmax, chirp, sc, c,
@@ -849,7 +851,9 @@ void launch_ring(int mode, const RingDev* rings, const int* cls, int ncls, int l
                  int weighted, const cd* tw, int log2Mmax, const cd* chirp, cd* scratch, int64_t scratch_map_stride,
                  int scratch_line, int nmaps, hipStream_t s, const cd* that, int64_t that_stride) {
     if (ncls == 0 || nmaps == 0) return;
-    const size_t lds = sizeof(cd) * (size_t)lds_elems(log2M);
+    static const int use_ldstw = [] { const char* e = std::getenv("CMDR_RING_LDSTW"); return e ? std::atoi(e) : 1; }();
+    const int tw_off = use_ldstw ? lds_elems(log2M) : 0;      // two-level twiddle table behind the FFT image
+    const size_t lds = sizeof(cd) * (size_t)(lds_elems(log2M) + (use_ldstw ? ring_tw_elems(log2Mmax) : 0));
     int nthr = 512;   // measured: 512 > 256 threads per ring pair (more waves to cover LDS / global latency)
     if (const char* e = std::getenv("CMDR_RING_THREADS")) { const int v = std::atoi(e); if (v == 256 || v == 512 || v == 1024) nthr = v; }
     if (nthr > (1 << log2M) / 2) nthr = std::max(64, (1 << log2M) / 2);
@@ -868,7 +872,7 @@ void launch_ring(int mode, const RingDev* rings, const int* cls, int ncls, int l
         }                                                                                                        \
         hipLaunchKernelGGL(k_ring<MM>, grid, dim3(nthr), lds, s, rings, cls, ph, ph_stride, npair_pad, map,      \
                            map_stride, mul, weighted, tw, log2Mmax, chirp, scratch, scratch_map_stride,          \
-                           scratch_line, ncls, nmaps, per, xbl, that, that_stride);                              \
+                           scratch_line, ncls, nmaps, per, xbl, that, that_stride, tw_off);                      \
     } while (0)
     if (mode == 0) CMDR_RING(0);
     else if (mode == 1) CMDR_RING(1);

@@ -468,7 +468,26 @@ CMDR_HD void part2_to_alm_elem(const double* __restrict__ p, int64_t part_chunk_
 // butterflies): 12 stages = 4 passes = 4 barriers instead of 12.
 struct FftCtx {
     int tid, nthr;
+    // optional two-level twiddle table held in LDS (ring_tw_fill): exp(2 pi i k / Mmax) = hi[k >> s] * lo[k & (2^s - 1)],
+    // so that the register passes carry no global load (one L2 round trip per pass and barrier otherwise)
+    const cd* tw_hi = nullptr;
+    const cd* tw_lo = nullptr;
+    int tw_s = 0;
 };
+CMDR_HD cd fft_tw(const cd* __restrict__ tw, const FftCtx& c, int k) {
+    if (!c.tw_hi) return tw[k];
+    return cmul(c.tw_hi[k >> c.tw_s], c.tw_lo[k & ((1 << c.tw_s) - 1)]);
+}
+CMDR_HD int ring_tw_split(int log2Mmax) { return log2Mmax / 2; }                 // s: lo has 2^s entries, hi 2^(log2Mmax-1-s)
+CMDR_HD int ring_tw_elems(int log2Mmax) { return (1 << ring_tw_split(log2Mmax)) + (1 << (log2Mmax - 1 - ring_tw_split(log2Mmax))); }
+// fill the two-level table at dst (LDS); visible after the caller's next block barrier
+CMDR_HD void ring_tw_fill(cd* dst, const cd* __restrict__ tw, int log2Mmax, FftCtx& c) {
+    const int s = ring_tw_split(log2Mmax), nlo = 1 << s, nhi = 1 << (log2Mmax - 1 - s);
+    for (int j = c.tid; j < nlo + nhi; j += c.nthr) dst[j] = j < nlo ? tw[j] : tw[(j - nlo) << s];
+    c.tw_lo = dst;
+    c.tw_hi = dst + nlo;
+    c.tw_s = s;
+}
 
 #if defined(__HIPCC__) && defined(__HIP_DEVICE_COMPILE__)
 #define CMDR_BLOCK_SYNC() __syncthreads()
@@ -508,7 +527,7 @@ CMDR_HD void fft_dit_pass(cd* buf, int log2M, int hl, const cd* __restrict__ tw,
         const int pos = g & hmask;
         const int i0 = ((g >> hl) << (hl + K)) + pos;
         cd bt[K];
-        bt[K - 1] = tw[pos << (log2Mmax - (hl + K))];
+        bt[K - 1] = fft_tw(tw, c, pos << (log2Mmax - (hl + K)));
 #pragma unroll
         for (int t = K - 1; t > 0; --t) bt[t - 1] = csqr(bt[t]);
         cd v[N];
@@ -544,7 +563,7 @@ CMDR_HD void fft_dif_pass(cd* buf, int log2M, int hl, const cd* __restrict__ tw,
         const int pos = g & hmask;
         const int i0 = ((g >> hl) << (hl + K)) + pos;
         cd bt[K];
-        bt[K - 1] = tw[pos << (log2Mmax - (hl + K))];
+        bt[K - 1] = fft_tw(tw, c, pos << (log2Mmax - (hl + K)));
 #pragma unroll
         for (int t = K - 1; t > 0; --t) bt[t - 1] = csqr(bt[t]);
         cd v[N];
