@@ -141,6 +141,10 @@ class CRContext:
         """ncclCommCount read back from the communicator (0: none)."""
         return int(self.L.cmdr_ctx_rccl_size(self._h))
 
+    def set_literal_quirks(self, flag):
+        """Reproduce cr_matmulA's stale pmap%alm above a component's lmax (comm_cr_mod.f90:846-861) literally."""
+        check(self.L.cmdr_ctx_set_literal_quirks(self._h, int(bool(flag))), self.L)
+
     def set_only_pol(self, flag):
         check(self.L.cmdr_ctx_set_only_pol(self._h, int(bool(flag))), self.L)
 
@@ -477,3 +481,29 @@ def alm_from_chain_order(chain32, lmax, _lib=None):
     out = np.zeros(c.shape, order="F")
     check(L.cmdr_alm_from_chain_order(c.ctypes.data_as(ctypes.POINTER(ctypes.c_float)), int(lmax), c.shape[1], _p(out)), L)
     return out
+
+
+def chain_write_comp(chainfile, iteration, label, alm, lmax, unit_scale=None, sigma_l=None, Dl=None, _lib=None):
+    """Write one component's sample into the HDF5 chain file the way ``comm_diffuse_comp%dumpFITS`` does
+    (``/<iter>/<label>/amp_alm`` float32 in l^2+l+m order, ``amp_lmax``, ``amp_nmaps``, ``sigma_l``, ``Dl``)."""
+    L = _lib if _lib is not None else _libmod.lib()
+    a = _f(np.asarray(alm, dtype=np.float64).reshape((lmax + 1) ** 2, -1))
+    nmaps = a.shape[1]
+    us = None if unit_scale is None else np.ascontiguousarray(unit_scale, dtype=np.float64)
+    sg = None if sigma_l is None else _f(np.asarray(sigma_l, dtype=np.float64).reshape(lmax + 1, -1))
+    dl = None if Dl is None else _f(np.asarray(Dl, dtype=np.float64).reshape(lmax + 1, -1))
+    check(L.cmdr_chain_write_comp(str(chainfile).encode(), int(iteration), label.encode(), _p(a), int(lmax), nmaps,
+                                  None if us is None else _p(us), None if sg is None else _p(sg),
+                                  None if dl is None else _p(dl)), L)
+
+
+def chain_read_comp(chainfile, iteration, label, lmax, nmaps, unit_scale=None, read_Dl=False, _lib=None):
+    """``initDiffuseHDF``: amplitudes (nalm, nmaps) in the units of ``c%x`` (and Dl (lmax+1, nspec) if asked) of one
+    stored sample."""
+    L = _lib if _lib is not None else _libmod.lib()
+    a = np.zeros(((lmax + 1) ** 2, nmaps), order="F")
+    us = None if unit_scale is None else np.ascontiguousarray(unit_scale, dtype=np.float64)
+    dl = np.zeros((lmax + 1, nmaps * (nmaps + 1) // 2), order="F") if read_Dl else None
+    check(L.cmdr_chain_read_comp(str(chainfile).encode(), int(iteration), label.encode(), int(lmax), int(nmaps),
+                                 None if us is None else _p(us), _p(a), None if dl is None else _p(dl)), L)
+    return (a, dl) if read_Dl else a

@@ -27,6 +27,10 @@ int guarded(F&& f) {
 }
 }  // namespace
 
+namespace cmdr {
+void set_last_error(const char* msg) { g_err = msg ? msg : ""; }   // for the entry points that live in other files
+}
+
 struct cmdr_sht_plan {
     std::unique_ptr<cmdr::ShtPlan> p;
     cmdr::DevBuf<double> alm, map;  // staging for the host-pointer entry point
@@ -206,7 +210,10 @@ int cmdr_sht_execute(cmdr_sht_plan* plan, int job, int nmaps, double* const* alm
 struct cmdr_ctx {
     std::unique_ptr<cmdr::CrSystem> sys;
     cmdr::DevBuf<double> hx, hy, hz;           // staging for the host-pointer entry points
-    std::vector<cmdr::DevBuf<double>> hmaps;   // staged band maps (resid, xi)
+    std::vector<cmdr::DevBuf<double>> hmaps;   // staged band maps (resid, xi) of the last cmdr_compute_rhs: the 'chisq'
+                                               // criterion of a later cmdr_solve reads the residuals, so nothing else
+                                               // may be staged here
+    std::vector<cmdr::DevBuf<double>> hres;    // staging of cmdr_compute_residual (data, resid)
 };
 
 extern "C" {
@@ -288,6 +295,12 @@ int cmdr_ctx_set_only_pol(cmdr_ctx* ctx, int only_pol) {
     return guarded([&] {
         CMDR_REQUIRE(ctx, "ctx is NULL");
         ctx->sys->set_only_pol(only_pol != 0);
+    });
+}
+int cmdr_ctx_set_literal_quirks(cmdr_ctx* ctx, int on) {
+    return guarded([&] {
+        CMDR_REQUIRE(ctx, "ctx is NULL");
+        ctx->sys->set_literal_quirks(on != 0);
     });
 }
 int cmdr_band_add(cmdr_ctx* ctx, int nside, int lmax, int nmaps, const double* siN, const double* b_l,
@@ -555,17 +568,17 @@ int cmdr_compute_residual(cmdr_ctx* ctx, const double* amp, const double* const*
         CMDR_REQUIRE(ctx && amp && data && resid, "bad arguments");
         const int nb = ctx->sys->nband();
         const size_t n = (size_t)ctx->sys->ncr();
-        ctx->hmaps.resize(2 * (size_t)nb);
+        ctx->hres.resize(2 * (size_t)nb);
         std::vector<const double*> dd(nb);
         std::vector<double*> dr(nb);
         std::vector<size_t> tot(nb);
         for (int b = 0; b < nb; ++b) {
             tot[b] = (size_t)ctx->sys->band_npix(b) * (size_t)ctx->sys->band_nmaps(b);
-            ctx->hmaps[2 * b].ensure(tot[b]);
-            ctx->hmaps[2 * b + 1].ensure(tot[b]);
-            CMDR_HIP_CHECK(hipMemcpy(ctx->hmaps[2 * b].get(), data[b], tot[b] * sizeof(double), hipMemcpyHostToDevice));
-            dd[b] = ctx->hmaps[2 * b].get();
-            dr[b] = ctx->hmaps[2 * b + 1].get();
+            ctx->hres[2 * b].ensure(tot[b]);
+            ctx->hres[2 * b + 1].ensure(tot[b]);
+            CMDR_HIP_CHECK(hipMemcpy(ctx->hres[2 * b].get(), data[b], tot[b] * sizeof(double), hipMemcpyHostToDevice));
+            dd[b] = ctx->hres[2 * b].get();
+            dr[b] = ctx->hres[2 * b + 1].get();
         }
         ctx->hx.ensure(n);
         CMDR_HIP_CHECK(hipMemcpy(ctx->hx.get(), amp, n * sizeof(double), hipMemcpyHostToDevice));

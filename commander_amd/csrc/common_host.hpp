@@ -20,6 +20,8 @@ struct Error : std::runtime_error {
         if (!(cond)) throw ::cmdr::Error(std::string(msg) + " [" #cond "]"); \
     } while (0)
 
+void set_last_error(const char* msg);   // c_api.cpp: the message cmdr_last_error() returns on this thread
+
 // Strided parallel for on host threads (plan construction only; never on the per-iteration path).
 inline void host_parallel_for(int n, const std::function<void(int)>& fn, int nthreads = 0) {
     if (nthreads <= 0) nthreads = (int)std::min<unsigned>(std::max(1u, std::thread::hardware_concurrency()), 32u);

@@ -361,7 +361,35 @@ void CrSystem::rebuild_weights() {
             }
         }
         G.w.upload(w);
+        if (!literal_quirks_) { G.w_fwd.release(); continue; }
+        // literal comm_cr_mod.f90:846-861: component c reads, above its own lmax, what the last earlier active component
+        // of the list with lmax >= l (and enough Stokes columns) left in pmap%alm -- times c's own F_mean and the beam
+        std::vector<double> wf = w;
+        for (int bm = 0; bm < G.nbm; ++bm) {
+            const int b = G.bm_band[bm], j = G.bm_stokes[bm];
+            const Band& B = bands_[b];
+            for (int c = 0; c < ncomp; ++c) {
+                const Comp& C = comps_[c];
+                if (!C.d.active || j >= C.d.nmaps) continue;
+                CMDR_REQUIRE(C.F_map[b].empty() || C.d.lmax >= G.lmax, "literal_quirks: components with a mixing map must reach the band's lmax");
+                if (!C.F_map[b].empty()) continue;
+                const double F = C.F_mean[b + (size_t)bands_.size() * j];
+                for (int l = C.d.lmax + 1; l <= G.lmax; ++l) {
+                    int src = -1;
+                    for (int p = c - 1; p >= 0; --p)      // last writer of (l, column j) before c
+                        if (comps_[p].d.active && comps_[p].d.lmax >= l && j < comps_[p].d.nmaps) { src = p; break; }
+                    if (src < 0) continue;
+                    wf[((size_t)bm * ncomp + src) * (G.lmax + 1) + l] += F * B.b_l[l + (size_t)(B.lmax + 1) * j] * B.mb_eff;
+                }
+            }
+        }
+        G.w_fwd.upload(wf);
     }
+}
+
+void CrSystem::set_literal_quirks(bool v) {
+    literal_quirks_ = v;
+    if (finalized_) { sync(); rebuild_weights(); }
 }
 
 void CrSystem::set_mixing_map(int comp, int band, const double* F, int nmaps) {
@@ -778,10 +806,11 @@ void CrSystem::matmulA(const double* x, double* y) {
         ShtPlan& P = *G.plan;
         const double* extra = nullptr;
         if (!G.mix.empty()) { mix_forward(G, sx_.get()); extra = G.E.get(); }            // varying mixing :2082-2084
-        launch_band_prep(comps_dev_.get(), ncomp, sx_.get(), G.w.get(), G.bm_stokes_dev.get(), P.stream(),
+        const double* wfwd = literal_quirks_ ? G.w_fwd.get() : G.w.get();
+        launch_band_prep(comps_dev_.get(), ncomp, sx_.get(), wfwd, G.bm_stokes_dev.get(), P.stream(),
                          P.leg().cnorm.get(), G.lmax, G.nT, stream_, extra);
         if (G.npol)
-            launch_band_prep2(comps_dev_.get(), ncomp, sx_.get(), G.w.get(), G.nT, P.stream2(), G.npol,
+            launch_band_prep2(comps_dev_.get(), ncomp, sx_.get(), wfwd, G.nT, P.stream2(), G.npol,
                               P.leg2().cnorm.get(), G.lmax, stream_, extra);
         if (group_has_compact(G)) {
             // compact objects live in pixel space (:872-897, :935-948): the map has to exist, so this plan runs the ring

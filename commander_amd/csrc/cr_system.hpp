@@ -74,6 +74,11 @@ class CrSystem {
         allreduce_rings_ = rings_fn; allreduce_rings_user_ = user; ring_replicas_ = ring_replicas; band_sharded_ = true;
     }
     void set_only_pol(bool v) { only_pol_ = v; }
+    // Reproduce cr_matmulA's buffer re-use literally (comm_cr_mod.f90:846-861): pmap%alm is allocated once per band and
+    // set_alm (comm_map_mod.f90:1193-1210) only overwrites the (l, m) a component HAS, so a component with a smaller
+    // lmax_amp than an earlier one of the list feeds getBand with the earlier component's coefficients above its own
+    // lmax.  Default off: the intended zero-filled semantics (deviation 1).  Constant-mixing components only.
+    void set_literal_quirks(bool v);
     // RCCL inside the library: every sum over ranks becomes an ncclAllReduce enqueued on the library stream (no
     // callback, no host synchronisation).  id = the 128-byte ncclUniqueId one rank created and the host language
     // broadcast.  Takes precedence over the callbacks.  split_rings: sub-communicator of the ranks that hold the
@@ -179,6 +184,7 @@ class CrSystem {
         std::vector<int> bands, bm_band, bm_stokes;
         std::unique_ptr<ShtPlan> plan;
         DevBuf<double> w;                   // [nbm][ncomp][lmax+1]
+        DevBuf<double> w_fwd;               // forward weights of cr_matmulA when literal_quirks_ is set (else unused)
         DevBuf<int> bm_stokes_dev;
         DevBuf<const double*> mul_ptrs;     // [nbm]
         DevBuf<cd> that;                    // [nbm][that_elems]: circulant spectra of the mul maps (Toeplitz ring form)
@@ -238,7 +244,7 @@ class CrSystem {
     std::vector<std::pair<int, int>> order_;   // stacked-vector order: (0, diffuse index) | (1, compact index)
     std::vector<Group> groups_;
     std::vector<std::pair<int, std::vector<int>>> ring_sets_;
-    bool finalized_ = false, only_pol_ = false, profile_ = false;
+    bool finalized_ = false, only_pol_ = false, profile_ = false, literal_quirks_ = false;
     int64_t ncr_ = 0;
     int lmax_max_ = -1;
     DevBuf<CompDev> comps_dev_;

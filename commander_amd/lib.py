@@ -60,6 +60,7 @@ def _sig(L):
     L.cmdr_ctx_set_allreduce_stream.argtypes = [c_vp, c_vp, c_vp]
     L.cmdr_ctx_set_band_sharding.argtypes = [c_vp, c_vp, c_vp, c_int]
     L.cmdr_ctx_set_only_pol.argtypes = [c_vp, c_int]
+    L.cmdr_ctx_set_literal_quirks.argtypes = [c_vp, c_int]
     L.cmdr_rccl_unique_id.argtypes = [ctypes.c_char_p]
     L.cmdr_rccl_version.restype = c_int
     L.cmdr_ctx_init_rccl.argtypes = [c_vp, ctypes.c_char_p, c_int, c_int]
@@ -112,6 +113,8 @@ def _sig(L):
     L.cmdr_profile_read.argtypes = [c_vp, dp, ctypes.POINTER(ctypes.c_longlong)]
     L.cmdr_alm_to_chain_order.argtypes = [dp, c_int, c_int, ctypes.POINTER(ctypes.c_float)]
     L.cmdr_alm_from_chain_order.argtypes = [ctypes.POINTER(ctypes.c_float), c_int, c_int, dp]
+    L.cmdr_chain_write_comp.argtypes = [ctypes.c_char_p, c_int, ctypes.c_char_p, dp, c_int, c_int, dp, dp, dp]
+    L.cmdr_chain_read_comp.argtypes = [ctypes.c_char_p, c_int, ctypes.c_char_p, c_int, c_int, dp, dp, dp]
     L.cmdr_problem_info.argtypes = [c_vp, ctypes.POINTER(c_i64)]
     L.cmdr_solve.argtypes = [c_vp, dp, dp, c_int, c_dbl, c_int, c_int, c_int, dp, pint, dp, pint]
     L.cmdr_solve_dev.argtypes = [c_vp, c_vp, c_vp, c_int, c_dbl, c_int, c_int, c_int, c_vp, pint, dp, pint]

@@ -140,6 +140,34 @@ module cmdr_hip_mod
        integer(c_int)     :: n
      end function cmdr_ctx_rccl_size
 
+     ! chain-file I/O of one component's sample (/<iter>/<label>/amp_alm, amp_lmax, amp_nmaps, sigma_l, Dl)
+     function cmdr_chain_write_comp(chainfile, iter, label, alm, lmax, nmaps, unit_scale, sigma_l, Dl) &
+          & bind(c, name='cmdr_chain_write_comp') result(ierr)
+       import :: c_int, c_ptr, c_double, c_char
+       character(kind=c_char), intent(in) :: chainfile(*), label(*)      ! null-terminated
+       integer(c_int), value              :: iter, lmax, nmaps
+       real(c_double), intent(in)         :: alm(*)
+       type(c_ptr),    value              :: unit_scale, sigma_l, Dl     ! c_loc(...) or c_null_ptr
+       integer(c_int)                     :: ierr
+     end function cmdr_chain_write_comp
+
+     function cmdr_chain_read_comp(chainfile, iter, label, lmax, nmaps, unit_scale, alm, Dl) &
+          & bind(c, name='cmdr_chain_read_comp') result(ierr)
+       import :: c_int, c_ptr, c_double, c_char
+       character(kind=c_char), intent(in) :: chainfile(*), label(*)
+       integer(c_int), value              :: iter, lmax, nmaps
+       type(c_ptr),    value              :: unit_scale, Dl
+       real(c_double), intent(out)        :: alm(*)
+       integer(c_int)                     :: ierr
+     end function cmdr_chain_read_comp
+
+     function cmdr_ctx_set_literal_quirks(ctx, on) bind(c, name='cmdr_ctx_set_literal_quirks') result(ierr)
+       import :: c_int, c_ptr
+       type(c_ptr),    value :: ctx
+       integer(c_int), value :: on
+       integer(c_int)        :: ierr
+     end function cmdr_ctx_set_literal_quirks
+
      function cmdr_band_add(ctx, nside, lmax, nmaps, siN, b_l, mb_eff, sg_mask, wring) &
           & bind(c, name='cmdr_band_add') result(idx)
        import :: c_int, c_ptr, c_double
@@ -184,6 +212,18 @@ module cmdr_hip_mod
        type(c_ptr), value :: ctx
        integer(c_int)     :: ierr
      end function cmdr_precond_update_diag
+
+     ! CG_LMAX_PRECOND: low-l dense preconditioner block (updateLowlPrecond / applyLowlPrecond); siN_lowres = array of
+     ! c_loc(data(b)%N%siN_lowres%map), nside_lowres(b) = data(b)%N%nside_chisq_lowres
+     function cmdr_precond_set_lowl(ctx, comp, lmax_pre_lowl, nside_lowres, siN_lowres) &
+          & bind(c, name='cmdr_precond_set_lowl') result(ierr)
+       import :: c_int, c_ptr
+       type(c_ptr),    value      :: ctx
+       integer(c_int), value      :: comp, lmax_pre_lowl
+       integer(c_int), intent(in) :: nside_lowres(*)
+       type(c_ptr),    intent(in) :: siN_lowres(*)
+       integer(c_int)             :: ierr
+     end function cmdr_precond_set_lowl
 
      function cmdr_precond_init_pseudoinv(ctx) bind(c, name='cmdr_precond_init_pseudoinv') result(ierr)
        import :: c_int, c_ptr

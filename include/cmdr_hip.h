@@ -123,6 +123,12 @@ int cmdr_ctx_init_rccl(cmdr_ctx* ctx, const char* id128, int rank, int nranks);
 int cmdr_ctx_rccl_split_rings(cmdr_ctx* ctx, int band_group, int ring_index, int ring_replicas);
 int cmdr_ctx_rccl_size(cmdr_ctx* ctx);
 int cmdr_ctx_set_only_pol(cmdr_ctx* ctx, int only_pol);
+/* on != 0: reproduce cr_matmulA's re-use of pmap%alm across the components of a band literally
+ * (comm_cr_mod.f90:846-861 with set_alm, comm_map_mod.f90:1193-1210): a component with a smaller lmax_amp than an
+ * earlier active one of compList then feeds getBand with the EARLIER component's coefficients above its own lmax, and A
+ * is not symmetric.  Needed to match a reference run with mixed lmax_amp bit for bit; default 0 = the intended
+ * zero-filled semantics (identical whenever all active components share one lmax_amp).  Constant-mixing components. */
+int cmdr_ctx_set_literal_quirks(cmdr_ctx* ctx, int on);
 
 /* data(i): comm_data_mod.f90:33-63.  siN = 1/rms (0 in masked pixels, comm_N_rms_mod.f90:179-193),
  * [npix_local x nmaps]; b_l(0:lmax, nmaps) (comm_B_bl_mod.f90); sg_mask = samp_group_mask or NULL
@@ -292,6 +298,22 @@ int cmdr_problem_info(cmdr_ctx* ctx, int64_t* out);
  * them.  Host pointers; alm: (lmax+1)^2 x nmaps doubles, chain32: (lmax+1)^2 x nmaps floats. */
 int cmdr_alm_to_chain_order(const double* alm, int lmax, int nmaps, float* chain32);
 int cmdr_alm_from_chain_order(const float* chain32, int lmax, int nmaps, double* alm);
+
+/* Chain-file I/O of one component's amplitude sample, in the layout Commander's HDF5 chain files
+ * have, so that chains produced through this library can be diffed against reference chains and restarted from either:
+ *   /<iter, 6 digits>/<label>/amp_alm (float32, index l^2 + l + m, nmaps columns), amp_lmax, amp_nmaps (int32),
+ *   sigma_l and Dl (float64, (0:lmax, nspec))
+ * -- comm_diffuse_comp%dumpFITS / comm_map%writeFITS (comm_diffuse_comp_mod.f90:2459-2524, comm_map_mod.f90:712-745),
+ * write_Dl_to_FITS (comm_Cl_mod.f90:1335); read back by initDiffuseHDF / readHDF / comm_Cl%initHDF
+ * (comm_diffuse_comp_mod.f90:2687-2728, comm_map_mod.f90:860-889, comm_Cl_mod.f90:1393).
+ * alm: packed a_lm (nalm x nmaps) in the units of c%x; unit_scale[nmaps] = RJ2unit_ * cg_scale (written values are
+ * alm * unit_scale, read values are divided by it; NULL = 1).  sigma_l / Dl: (lmax+1) x nspec column-major or NULL.
+ * The file is created if it does not exist; an existing group / dataset of the same iteration is replaced.
+ * HDF5 (>= 1.10) is loaded at run time (dlopen libhdf5; CMDR_HDF5_LIB overrides the search); host pointers. */
+int cmdr_chain_write_comp(const char* chainfile, int iter, const char* label, const double* alm, int lmax, int nmaps,
+                          const double* unit_scale, const double* sigma_l, const double* Dl);
+int cmdr_chain_read_comp(const char* chainfile, int iter, const char* label, int lmax, int nmaps,
+                         const double* unit_scale, double* alm, double* Dl);
 
 #ifdef __cplusplus
 }

@@ -272,9 +272,12 @@ class _LowBand:
 class CRSystem:
     """The stacked linear system: ``ncr`` / ``ind_comp`` (comm_signal_mod.f90:113-125, comm_cr_utils.f90:25-33)."""
 
-    def __init__(self, bands, comps, only_pol=False):
+    def __init__(self, bands, comps, only_pol=False, literal_quirks=False):
         self.bands, self.comps = list(bands), list(comps)
         self.only_pol = only_pol
+        # True: pmap%alm is re-used across the components of a band exactly as comm_cr_mod.f90:846-861 does (set_alm only
+        # overwrites what the component has, comm_map_mod.f90:1193-1210); False: zero-filled (intended semantics)
+        self.literal_quirks = literal_quirks
         self.ind_comp = []
         pos = 0
         for c in self.comps:
@@ -419,6 +422,7 @@ class CRSystem:
         for ib, b in enumerate(self.bands):  # :843
             map_alm = np.zeros((b.info.nalm, b.nmaps))
             pmap = np.zeros(b.npix * b.nmaps)                        # compact objects, pixel space (:872-882)
+            pmap_alm = np.zeros((b.info.nalm, b.nmaps))              # :847 pmap => comm_map(data(i)%info), allocated once per band
             for k, c in enumerate(self.comps):
                 if not c.active:
                     continue
@@ -429,7 +433,14 @@ class CRSystem:
                     continue
                 alm = self.extract(k, sqrtS_x)
                 alm[c.info.l > b.lmax, :] = 0.0                      # :858-860
-                pm = healpix.alm_equal(alm, c.info, b.info, nmaps_dst=b.nmaps)  # :861 set_alm (zero-filled)
+                if self.literal_quirks:                              # :861 set_alm: only the component's own (l, m), columns
+                    j = b.info.lm2i_vec(c.info.l, c.info.m)
+                    ok = j >= 0
+                    q = min(b.nmaps, c.nmaps)
+                    pmap_alm[j[ok], :q] = alm[ok, :q]
+                    pm = pmap_alm.copy()
+                else:
+                    pm = healpix.alm_equal(alm, c.info, b.info, nmaps_dst=b.nmaps)  # zero-filled (intended semantics)
                 map_alm += self.getBand_alm(c, ib, pm)               # :865-867
             if lmax > -1:
                 info_buff = healpix.AlmInfo(lmax)                    # :888-892

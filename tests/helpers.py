@@ -12,7 +12,7 @@ def rel(a, b):
     return float(np.linalg.norm(np.asarray(a) - np.asarray(b)) / np.linalg.norm(b))
 
 
-def oracle_system(spec, only_pol=False):
+def oracle_system(spec, only_pol=False, literal_quirks=False):
     from oracle import cr_oracle as cro
     bands = [cro.Band(b["nside"], b["lmax"], b["siN"], b["b_l"], b.get("mb_eff", 1.0), b.get("sg_mask"), b.get("wring"))
              for b in spec["bands"]]
@@ -32,7 +32,7 @@ def oracle_system(spec, only_pol=False):
             assert np.allclose(cl.sqrtS_mat, c["sqrtS_mat"], rtol=1e-13, atol=0)
         comps.append(cro.DiffuseComp(c["lmax"], c["nmaps"], cl, c["F_mean"], active=c.get("active", True),
                                      F_map=c.get("F_map")))
-    return cro.CRSystem(bands, comps, only_pol=only_pol)
+    return cro.CRSystem(bands, comps, only_pol=only_pol, literal_quirks=literal_quirks)
 
 
 def emul_lib():
@@ -378,3 +378,36 @@ def lowl_precond_checks(_lib=None, nside=16, lmax=32, L=6, nside_low=4, tol=1e-1
         assert ng == no == 12 and rel(xg, xo) < 1e-8
         ctx.set_lowl_precond(0, -1)
         assert np.array_equal(ctx.cr_invM(x), plain)
+
+
+def literal_quirks_checks(_lib=None, nside=16, lmax=32, tol=1e-11):
+    """cr_matmulA's literal buffer re-use (comm_cr_mod.f90:846-861): with components of different lmax_amp the later,
+    smaller one reads the earlier one's coefficients above its own lmax.  Product and oracle agree in both modes, the
+    modes differ, and only the literal one is non-symmetric (T and T,Q,U; three components with mixed lmax)."""
+    from commander_amd import synth
+    from commander_amd.cr import build_context
+    rng = np.random.default_rng(21)
+    for pol in (False, True):
+        cfg = dict(synth.CONFIGS["cfg2"], comps=["cmb", "synch", "dust"])
+        spec = synth.make_problem(cfg, nside=nside, lmax=lmax, comp_lmax=[lmax, lmax - 8, lmax - 3], pol=pol)
+        ctx = build_context(spec, _lib=_lib)
+        x, y = rng.standard_normal(ctx.ncr), rng.standard_normal(ctx.ncr)
+        S0, S1 = oracle_system(spec), oracle_system(spec, literal_quirks=True)
+        A0 = ctx.cr_matmulA(x)
+        assert rel(A0, S0.matmulA(x)) < tol
+        ctx.set_literal_quirks(True)
+        A1, A1y = ctx.cr_matmulA(x), ctx.cr_matmulA(y)
+        assert rel(A1, S1.matmulA(x)) < tol
+        assert rel(A1, A0) > 1e-6                                        # the quirk is not a rounding effect
+        assert abs(y @ A1 - x @ A1y) > 1e-8 * abs(y @ A1)                # ... and it breaks the symmetry of A
+        assert abs(y @ A0 - x @ ctx_sym(ctx, y)) <= 1e-11 * abs(y @ A0)
+        # the RHS and the preconditioner do not go through the re-used buffer
+        resid, xi, eta = synth.draw_inputs(spec)
+        assert rel(ctx.cr_computeRHS("sample", resid, xi, eta), S1.computeRHS(resid, "sample", xi, eta)) < tol
+
+
+def ctx_sym(ctx, v):
+    ctx.set_literal_quirks(False)
+    out = ctx.cr_matmulA(v)
+    ctx.set_literal_quirks(True)
+    return out

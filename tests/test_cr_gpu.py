@@ -358,3 +358,8 @@ def test_lowl_preconditioner_gpu():
     """CG_LMAX_PRECOND low-l dense block (updateLowlPrecond / applyLowlPrecond) on the GPU vs the oracle."""
     from helpers import lowl_precond_checks
     lowl_precond_checks(None, nside=32, lmax=64, L=8, nside_low=8)
+
+
+def test_literal_quirks_switch_gpu():
+    from helpers import literal_quirks_checks
+    literal_quirks_checks(None, nside=32, lmax=64)

@@ -456,3 +456,9 @@ def test_emul_lowl_preconditioner(EL):
     """CG_LMAX_PRECOND low-l dense block, product vs oracle (T and T,Q,U components)."""
     from helpers import lowl_precond_checks
     lowl_precond_checks(EL)
+
+
+def test_emul_literal_quirks_switch(EL):
+    """the reference's stale-l behaviour in cr_matmulA is available behind a switch (oracle + product)."""
+    from helpers import literal_quirks_checks
+    literal_quirks_checks(EL)
