@@ -1,34 +1,37 @@
 """How the ranks of one chain split the amplitude-sampling matvec: A = 1 + S^1/2 sum_bands sum_rings (...)
 S^1/2 is a double sum, so ranks may own a subset of the bands, a subset of the ring pairs, or both (hybrid).  Pure ring
 sharding balances perfectly but shrinks the per-rank Legendre problem (256 ring pairs at Nside 1024 on 8 GPUs run at
-57 % of the single-GPU efficiency, measured with tools/cr_time_rank.py); pure band sharding keeps the kernels large
+52 % of the single-GPU efficiency, measured with tools/cr_time_rank.py); pure band sharding keeps the kernels large
 but balances badly (9 bands on 8 GPUs).  ``plan_shards`` picks the factorisation world = band_parts x ring_parts with
 the smallest estimated time."""
 
-# measured on MI355X at the cfg3 geometry (tools/cr_time_rank.py): compute efficiency of one rank's share
-# under ring_parts-way ring sharding, and the penalty of holding fewer bands (smaller map batches per launch)
-RING_EFF = {1: 1.0, 2: 0.89, 4: 0.76, 8: 0.57}
+# measured on MI355X at the cfg3 geometry with the round-2 kernels (tools/cr_time_rank.py; one rank's
+# matvec + invM: 9.3 ms alone, 5.22 / 3.11 / 2.25 ms as 1 of 2 / 4 / 8 ring sets): compute efficiency of one rank's
+# share under ring_parts-way ring sharding, and the penalty of holding fewer bands (smaller map batches per launch:
+# below 6 maps the adjoint leaves the matrix-unit kernel; 2 x 2: 3.55 ms, 2 x 4: 2.20 ms, 4 x 2: 2.25 ms)
+RING_EFF = {1: 1.0, 2: 0.89, 4: 0.75, 8: 0.52}
 
 
 def _eff(r):
     if r in RING_EFF:
         return RING_EFF[r]
-    return 0.57 * 8.0 / r if r > 8 else 1.0
+    return 0.52 * 8.0 / r if r > 8 else 1.0
 
 
 def _band_penalty(nb):
-    return 1.0 if nb >= 9 else (1.12 if nb >= 5 else (1.07 if nb >= 3 else (1.19 if nb == 2 else 1.25)))
+    return 1.0 if nb >= 9 else (1.25 if nb >= 5 else (1.28 if nb >= 3 else (1.35 if nb == 2 else 1.4)))
 
 
 def plan_shards(nband, world):
-    """-> (band_parts, ring_parts) minimising  max_bands_per_group / (ring_parts * eff(ring_parts))."""
+    """-> (band_parts, ring_parts) minimising  max_bands_per_group / (ring_parts * eff(ring_parts)).  Pure ring sharding
+    (one communicator, perfect balance) is kept unless a hybrid layout is estimated at least 5 % faster."""
     best = None
     for bp in range(1, world + 1):
         if world % bp or bp > nband:
             continue
         rp = world // bp
         mb = -(-nband // bp)                       # bands of the most loaded group
-        cost = mb * (_band_penalty(mb) if bp > 1 else 1.0) / (rp * _eff(rp))
+        cost = mb * (_band_penalty(mb) if bp > 1 else 1.0) / (rp * _eff(rp)) * (1.05 if bp > 1 else 1.0)
         if best is None or cost < best[0] - 1e-12:
             best = (cost, bp, rp)
     return best[1], best[2]

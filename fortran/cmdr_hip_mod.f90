@@ -161,6 +161,15 @@ module cmdr_hip_mod
        integer(c_int)                     :: ierr
      end function cmdr_chain_read_comp
 
+     ! include/cmdr_sharp.h: the sum over one communicator that sharp_execute_mpi_fortran needs when a chain has more
+     ! than one rank (fn(user, host_buf, n) = MPI_Allreduce(MPI_IN_PLACE, host_buf, n, MPI_DOUBLE_PRECISION, MPI_SUM, comm))
+     subroutine cmdr_sharp_register_comm(comm, fn, user) bind(c, name='cmdr_sharp_register_comm')
+       import :: c_int, c_ptr, c_funptr
+       integer(c_int), value :: comm
+       type(c_funptr), value :: fn
+       type(c_ptr),    value :: user
+     end subroutine cmdr_sharp_register_comm
+
      function cmdr_ctx_set_literal_quirks(ctx, on) bind(c, name='cmdr_ctx_set_literal_quirks') result(ierr)
        import :: c_int, c_ptr
        type(c_ptr),    value :: ctx

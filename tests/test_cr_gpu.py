@@ -276,7 +276,9 @@ def test_gibbs_loop_updates_gpu():
     """Two Gibbs iterations (amplitudes | C_l, C_l | amplitudes) through getSigmaL / sampleCls_binned / updateS /
     cmdr_comp_set_cl / update_precond, then the sampling-group and mixing updates, against the oracle."""
     from helpers import gibbs_loop_checks
-    gibbs_loop_checks(None, nside=16, lmax=32)
+    # converged solves of two fp64 implementations agree to the stated 1e-6 (SURVEY 8c), not to rounding: the CG
+    # trajectories separate at the 1e-16 level and the criterion stops both at 1e-12 of the preconditioned residual
+    gibbs_loop_checks(None, nside=16, lmax=32, tol=1e-6)
 
 
 @pytest.mark.gpu
