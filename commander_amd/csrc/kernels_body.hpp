@@ -518,8 +518,14 @@ CMDR_HD cd rot_const(cd v, int jl) {   // v * exp(2 pi i jl / 2^(T+1)), jl < 2^T
 
 // K radix-2 DIT stages (halves h, 2h, .. h<<(K-1), h = 1<<hl) on the 2^K elements i0 + j*h held in registers.
 // bit-reversed order in -> natural order out, kernel exp(+2 pi i jk/M)
-template <int K>
-CMDR_HD void fft_dit_pass(cd* buf, int log2M, int hl, const cd* __restrict__ tw, int log2Mmax, FftCtx c) {
+// post (last pass only): a pointwise step rides on the store that leaves the transform in natural order --
+// buf[i] = post(i, value) -- instead of costing its own LDS round trip and barrier
+struct NoPost {
+    CMDR_HD cd operator()(int, cd v) const { return v; }
+};
+template <int K, class Post = NoPost>
+CMDR_HD void fft_dit_pass(cd* buf, int log2M, int hl, const cd* __restrict__ tw, int log2Mmax, FftCtx c,
+                          const Post& post = Post{}, bool last = false) {
     constexpr int N = 1 << K;
     const int ngroups = 1 << (log2M - K);
     const int hmask = (1 << hl) - 1;
@@ -545,8 +551,13 @@ CMDR_HD void fft_dit_pass(cd* buf, int log2M, int hl, const cd* __restrict__ tw,
                 v[j + (1 << t)] = csub(u, x);
             }
         }
+        if (last) {
 #pragma unroll
-        for (int j = 0; j < N; ++j) buf[lds_pad(i0 + (j << hl))] = v[j];
+            for (int j = 0; j < N; ++j) buf[lds_pad(i0 + (j << hl))] = post(i0 + (j << hl), v[j]);
+        } else {
+#pragma unroll
+            for (int j = 0; j < N; ++j) buf[lds_pad(i0 + (j << hl))] = v[j];
+        }
     }
     CMDR_BLOCK_SYNC();
 }
@@ -594,12 +605,14 @@ CMDR_HD void fft_dif_pass(cd* buf, int log2M, int hl, const cd* __restrict__ tw,
     CMDR_BLOCK_SYNC();
 }
 
-CMDR_HD void fft_dit_plus(cd* buf, int log2M, const cd* __restrict__ tw, int log2Mmax, FftCtx c) {
+template <class Post = NoPost>
+CMDR_HD void fft_dit_plus(cd* buf, int log2M, const cd* __restrict__ tw, int log2Mmax, FftCtx c,
+                          const Post& post = Post{}) {
     int hl = 0;
     const int k0 = log2M % 3;
-    if (k0 == 1) { fft_dit_pass<1>(buf, log2M, 0, tw, log2Mmax, c); hl = 1; }
-    else if (k0 == 2) { fft_dit_pass<2>(buf, log2M, 0, tw, log2Mmax, c); hl = 2; }
-    for (; hl < log2M; hl += 3) fft_dit_pass<3>(buf, log2M, hl, tw, log2Mmax, c);
+    if (k0 == 1) { fft_dit_pass<1, Post>(buf, log2M, 0, tw, log2Mmax, c, post, log2M == 1); hl = 1; }
+    else if (k0 == 2) { fft_dit_pass<2, Post>(buf, log2M, 0, tw, log2Mmax, c, post, log2M == 2); hl = 2; }
+    for (; hl < log2M; hl += 3) fft_dit_pass<3, Post>(buf, log2M, hl, tw, log2Mmax, c, post, hl + 3 == log2M);
 }
 
 CMDR_HD void fft_dif_plus(cd* buf, int log2M, const cd* __restrict__ tw, int log2Mmax, FftCtx c,
@@ -765,8 +778,15 @@ CMDR_HD FftSub ring_fft_desc(const RingDev& d, const cd* __restrict__ chirp) {
 }
 
 // Full inverse (synthesis) ring transform in LDS: on return buf[lds_pad(k)], k<n holds y^N_k + i y^S_k.
+struct PixelPost {           // (y_N, y_S) -> conj(mul_N y_N, mul_S y_S); no southern ring: imaginary part 0
+    const double* __restrict__ a;
+    const double* __restrict__ b;
+    CMDR_HD cd operator()(int k, cd z) const { return {z.x * a[k], b ? -(z.y * b[k]) : 0.0}; }
+};
 CMDR_HD void ring_synth_lds(cd* buf, const RingDev& d, const double* __restrict__ ph, int64_t npair_pad, int pair,
-                            const cd* __restrict__ tw, int log2Mmax, const cd* __restrict__ chirp, FftCtx c) {
+                            const cd* __restrict__ tw, int log2Mmax, const cd* __restrict__ chirp, FftCtx c,
+                            bool fuse_mul = false, const double* __restrict__ mulN = nullptr,
+                            const double* __restrict__ mulS = nullptr) {
     const int n = d.nphi, M = 1 << d.log2M;
     const bool flip = d.phi0 != 0.0;
     const cd* rot = chirp + d.chirp_off;   // rot_j, j < n
@@ -785,7 +805,8 @@ CMDR_HD void ring_synth_lds(cd* buf, const RingDev& d, const double* __restrict_
         }
         CMDR_BLOCK_SYNC();
     }
-    idft_core(buf, f, tw, log2Mmax, c);
+    if (fuse_mul) fft_dit_plus(buf, f.log2M, tw, log2Mmax, c, PixelPost{mulN, mulS});   // power-of-two rings only
+    else idft_core(buf, f, tw, log2Mmax, c);
 }
 
 // Extract G^N_m, G^S_m (m <= mmax_eff) from the packed spectrum Z_j = spec(j) and store them as phases for the
@@ -891,18 +912,22 @@ CMDR_HD void ring_toeplitz_load(cd* buf, int lg, int mmax, const double* __restr
     CMDR_BLOCK_SYNC();
 }
 
+struct ToeplitzPost {
+    const cd* __restrict__ T;
+    CMDR_HD cd operator()(int k, cd z) const {
+        const cd t = T[k];
+        return {z.x * t.x, -(z.y * t.y)};
+    }
+};
 // phases (in place) -> G = T F for one ring pair; that = this map's multiplier spectra
 CMDR_HD void ring_toeplitz_apply(cd* buf, const RingDev& d, double* __restrict__ ph, int64_t npair_pad, int pair,
                                  const cd* __restrict__ that, const cd* __restrict__ tw, int log2Mmax, FftCtx c) {
     const int lg = d.log2T, M = 1 << lg, mmax = d.mmax_eff;
+    (void)M;
     ring_toeplitz_load(buf, lg, mmax, ph, npair_pad, pair, c);
-    fft_dit_plus(buf, lg, tw, log2Mmax, c);                       // x(k) = sum_j Z_j e^{+2 pi i jk/M}: (north, south) real signals
-    const cd* __restrict__ T = that + d.that_off;
-    for (int k = c.tid; k < M; k += c.nthr) {
-        const cd z = buf[lds_pad(k)], t = T[k];
-        buf[lds_pad(k)] = {z.x * t.x, -(z.y * t.y)};              // conj(y_k): input form of the forward transform
-    }
-    CMDR_BLOCK_SYNC();
+    // x(k) = sum_j Z_j e^{+2 pi i jk/M}: (north, south) real signals; the multiplier spectrum rides on the last pass's
+    // store, which leaves conj(tau(k) x(k)): the input form of the forward transform
+    fft_dit_plus(buf, lg, tw, log2Mmax, c, ToeplitzPost{that + d.that_off});
     fft_dif_plus(buf, lg, tw, log2Mmax, c);                       // Y_j = conj(buf[bitrev j])
     for (int j = c.tid; j <= mmax; j += c.nthr) {
         const cd a = cconj(buf[lds_pad(d_bitrev(j, lg))]);
@@ -977,6 +1002,15 @@ CMDR_HD void ring_block(cd* buf, const RingDev& d, int pair, double* __restrict_
     const int n = d.nphi;
     const FftSub f = ring_fft_desc(d, chirp);
     if (!d.split) {
+        if (MODE == 2 && !d.bluestein) {
+            // power-of-two ring of the fused pass: the pixel multiplier (and the conjugation the forward transform
+            // wants) ride on the last synthesis pass's store; no separate pixel pass
+            ring_synth_lds(buf, d, php, npair_pad, pair, tw, log2Mmax, chirp, c, true, mu + d.startN,
+                           d.startS >= 0 ? mu + d.startS : nullptr);
+            dft_core(buf, f, tw, log2Mmax, c);
+            ring_store_phases(SpecDirect{buf, f}, d, php, npair_pad, pair, chirp, c);
+            return;
+        }
         if (MODE == 0 || MODE == 2) ring_synth_lds(buf, d, php, npair_pad, pair, tw, log2Mmax, chirp, c);
         ring_pixels<MODE>(buf, f, n, 0, 1, d, mp, mu, wg, c);
         if (MODE == 0) return;
