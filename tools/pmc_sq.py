@@ -12,7 +12,8 @@ for d in sys.argv[2:]:
                 continue
             acc[k][r["Counter_Name"]] += float(r["Counter_Value"])
             cnt[k][r["Counter_Name"]] += 1
-out = {"command": "rocprofv3 --pmc <SQ counters, a few per pass> --output-format csv -- python3 tools/cr_time.py cfg3",
+out = {"command": "rocprofv3 --pmc <SQ counters, four per pass> --output-format csv -- python3 bench.py --steps 1 --warmup 0 "
+                  "--no-cpu-baseline --no-extras   (tools/collect_profiles.sh)",
        "note": "per-dispatch means; SQ_* counters are summed over the shader engines",
        "kernels": {k: {c: v / cnt[k][c] for c, v in sorted(cs.items())} | {"dispatches": max(cnt[k].values())}
                    for k, cs in sorted(acc.items())}}

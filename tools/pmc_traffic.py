@@ -32,11 +32,18 @@ def span(prefix, nspan):
 nspan_adj = nspan_mv + max(fc.get("cmdr::k_pix", 0) // 9, 0)          # the RHS adds one adjoint span per 9 k_pix launches
 out = {"command": "rocprofv3 --pmc FETCH_SIZE (and, separately, --pmc WRITE_SIZE) --output-format csv -- python3 bench.py "
                   "--steps 1 --warmup 0 --no-cpu-baseline",
-       "note": "FETCH_SIZE/WRITE_SIZE in KB per dispatch as reported (no x2 correction applied: the Legendre reads are "
-               "scalar-cache 64-B requests and 8-B/lane vector loads, not 16-B/lane streams)",
+       "note": "FETCH_SIZE/WRITE_SIZE in KB per dispatch as reported.  MI355X_MICROARCH.md (HBM): FETCH_SIZE halves 16-B/lane "
+               "coalesced streaming reads, other widths are uncalibrated; the Legendre kernels read through 8-B/lane vector "
+               "loads and scalar-cache requests, so no x2 correction is applied and the absolute numbers carry that caveat",
        "kernels": kern,
-       "legendre_span_bytes": {"synth_9maps": span("cmdr::k_leg_synth", nspan_mv), "adjoint_9maps": span("cmdr::k_leg_adj<4", nspan_adj)}}
+       "legendre_span_bytes": {"synth_9maps": span("cmdr::k_leg_synth", nspan_mv),
+                               "adjoint_9maps": span("cmdr::k_leg_adj<4", nspan_adj) + span("cmdr::k_leg_adj_mx", nspan_adj)}}
 ls = out["legendre_span_bytes"]
 ls["mean"] = 0.5 * (ls["synth_9maps"] + ls["adjoint_9maps"])
+mx = kern.get("cmdr::k_leg_adj_mx")
+if mx:   # the dominant kernel of round 2: one launch = the Legendre adjoint of 8 maps on the matrix unit
+    out["adjoint_launch_bytes"] = {"kernel": "cmdr::k_leg_adj_mx",
+                                   "mean": (mx["FETCH_SIZE_KB_per_dispatch"] + mx["WRITE_SIZE_KB_per_dispatch"]) * 1024.0,
+                                   "fetch": mx["FETCH_SIZE_KB_per_dispatch"] * 1024.0, "write": mx["WRITE_SIZE_KB_per_dispatch"] * 1024.0}
 json.dump(out, open(sys.argv[3], "w"), indent=1)
 print(json.dumps(ls))
