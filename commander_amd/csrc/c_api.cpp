@@ -628,6 +628,12 @@ int cmdr_profile_read(cmdr_ctx* ctx, double* ms_sum, long long* count) {
         ctx->sys->read_profile(ms_sum, count);
     });
 }
+int cmdr_profile_read_ext(cmdr_ctx* ctx, int nkinds, double* ms_sum, long long* count) {
+    return guarded([&] {
+        CMDR_REQUIRE(ctx && ms_sum && count, "bad arguments");
+        ctx->sys->read_profile(ms_sum, count, nkinds);
+    });
+}
 int cmdr_problem_info(cmdr_ctx* ctx, int64_t* out) {
     return guarded([&] {
         CMDR_REQUIRE(ctx && out, "bad arguments");

@@ -40,10 +40,10 @@ void CrSystem::pipeline_events(Group& G, int nbatch) {
 void CrSystem::sync() { CMDR_HIP_CHECK(hipStreamSynchronize(stream_)); }
 
 void CrSystem::set_profile(bool on) {
-    double ms[4];
-    long long n[4];
-    read_profile(ms, n);
-    for (int k = 0; k < 4; ++k) { prof_ms_[k] = 0; prof_n_[k] = 0; }
+    double ms[kProfKinds];
+    long long n[kProfKinds];
+    read_profile(ms, n, kProfKinds);
+    for (int k = 0; k < kProfKinds; ++k) { prof_ms_[k] = 0; prof_n_[k] = 0; }
     profile_ = on;
 }
 
@@ -80,7 +80,8 @@ void CrSystem::span_end() {
     open_.pop_back();
 }
 
-void CrSystem::read_profile(double* ms_sum, long long* count) {
+void CrSystem::read_profile(double* ms_sum, long long* count, int nkinds) {
+    CMDR_REQUIRE(nkinds >= 1 && nkinds <= kProfKinds, "bad number of profile kinds");
     if (!spans_.empty()) {
         sync();
         CMDR_HIP_CHECK(hipStreamSynchronize(stream_ring_));
@@ -94,7 +95,7 @@ void CrSystem::read_profile(double* ms_sum, long long* count) {
         }
         spans_.clear();
     }
-    for (int k = 0; k < 4; ++k) { ms_sum[k] = prof_ms_[k]; count[k] = prof_n_[k]; }
+    for (int k = 0; k < nkinds; ++k) { ms_sum[k] = prof_ms_[k]; count[k] = prof_n_[k]; }
 }
 
 void CrSystem::set_rings(int nside, const std::vector<int>& rings) {
@@ -776,7 +777,14 @@ void CrSystem::adjoint_groups_to_yc(bool from_maps) {
             }
             G.ring_pending = false;
         } else {
-            P.adjoint_to_partials(G.nT, false, stream_);
+            // the matrix-unit launch(es) and the VALU launch(es) of the remaining maps are timed on their own (kinds 4, 5)
+            span_begin(4);
+            P.adjoint_to_partials(G.nT, false, stream_, [&](int nmx) {
+                if (nmx > 0) span_end();
+                else if (profile_) { spans_[open_.back()].kind = 5; return; }
+                span_begin(5);
+            });
+            span_end();
             if (G.npol) P.adjoint2_to_partials(G.npol, G.nT, stream_);
         }
         span_end();

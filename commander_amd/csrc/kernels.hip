@@ -473,7 +473,8 @@ static void adj_RN(const LegArgs& A, const WaveTask* tasks, int ntasks, const do
                        ph_stride, k0, rep, part, pms, pcs);
 }
 void launch_leg_adj(const LegArgs& A, const WaveTask* tasks, int ntasks, const double* ph, int64_t ph_stride,
-                    double* part, int64_t pms, int64_t pcs, int nmaps, bool square, hipStream_t s) {
+                    double* part, int64_t pms, int64_t pcs, int nmaps, bool square, hipStream_t s,
+                    const std::function<void(int)>& between) {
     if (ntasks == 0 || nmaps == 0) return;
     if (square) {  // setup-time only (noise diagonal): one map at a time
         for (int k0 = 0; k0 < nmaps; ++k0) {
@@ -493,6 +494,7 @@ void launch_leg_adj(const LegArgs& A, const WaveTask* tasks, int ntasks, const d
                                pms, pcs);
             kdone += nb;
         }
+    if (between) between(kdone);
     if (kdone == nmaps) return;
     ph += (int64_t)kdone * ph_stride;
     part += (int64_t)kdone * pms;

@@ -3,6 +3,7 @@
 #include <hip/hip_runtime.h>
 
 #include <cstdint>
+#include <functional>
 
 #include "cr_body.hpp"
 #include "kernels_body.hpp"
@@ -15,9 +16,11 @@ int leg_max_batch(int R);
 // nbs: maps interleaved in the stream buffer (default nmaps); a sub-range of maps is addressed by shifting ast / ph
 void launch_leg_synth(const LegArgs& A, const WaveTask* tasks, int ntasks, const double* ast, double* ph,
                       int64_t ph_stride, int nmaps, hipStream_t s, int nbs = -1);
+// between(nmx): called once after the matrix-unit launches (nmx maps went through k_leg_adj_mx; 0 = none) and before
+// the VALU launches of the remaining maps (profiling hook; may be empty)
 void launch_leg_adj(const LegArgs& A, const WaveTask* tasks, int ntasks, const double* ph, int64_t ph_stride,
                     double* part, int64_t part_map_stride, int64_t part_chunk_stride, int nmaps, bool square,
-                    hipStream_t s);
+                    hipStream_t s, const std::function<void(int)>& between = nullptr);
 // mode 0: phases->map, 1: map->phases, 2: phases -> *mul -> phases (in place)
 void launch_ring(int mode, const RingDev* rings, const int* cls, int ncls, int log2M, double* ph,
                  int64_t ph_stride, int64_t npair_pad, double* map, int64_t map_stride, const double* const* mul,

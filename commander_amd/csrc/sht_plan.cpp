@@ -190,9 +190,9 @@ void ShtPlan::adjoint_range(int k0, int n, hipStream_t s) {
                    part_.get() + (int64_t)k0 * part_map_stride(), part_map_stride(), leg_.tri_elems(), n, false, s);
 }
 
-void ShtPlan::adjoint_to_partials(int nmaps, bool square, hipStream_t s) {
+void ShtPlan::adjoint_to_partials(int nmaps, bool square, hipStream_t s, const std::function<void(int)>& between) {
     launch_leg_adj(leg_.args(), leg_.tasks.get(), leg_.ntasks, ph_.get(), leg_.ph_elems(), part_.get(),
-                   part_map_stride(), leg_.tri_elems(), nmaps, square, s);
+                   part_map_stride(), leg_.tri_elems(), nmaps, square, s, between);
 }
 
 void ShtPlan::alm2map(const double* d_alm, int64_t alm_stride, double* d_map, int64_t map_stride, int nmaps,

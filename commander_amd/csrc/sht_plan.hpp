@@ -2,6 +2,7 @@
 // adjoint partial columns).  One plan per distinct (nside, lmax, ring subset); Commander keeps the equivalent
 // libsharp handles in its comm_mapinfo cache (commander3/src/comm_map_mod.f90:126-127,157-169).
 #pragma once
+#include <functional>
 #include <memory>
 #include <vector>
 
@@ -85,7 +86,8 @@ class ShtPlan {
     // given): [nmaps][that_elems()] complex.  Setup-time (once per noise / mixing map); empty plan part -> size 0.
     int64_t that_elems() const { return T_.ring.that_elems; }
     void toeplitz_build(const std::vector<const double*>& mul_host, DevBuf<cd>& out, hipStream_t s);
-    void adjoint_to_partials(int nmaps, bool square, hipStream_t s);                 // phases -> partials
+    // phases -> partials; between(nmx) is called after the matrix-unit launches (nmx maps, 0 = none) and before the VALU ones
+    void adjoint_to_partials(int nmaps, bool square, hipStream_t s, const std::function<void(int)>& between = nullptr);
     // the same three stages on maps k0 .. k0+n-1 of a stream holding nbs maps (pipelined matvec: the ring stage of
     // one batch runs beside the Legendre stage of the next)
     void synth_range(int k0, int n, int nbs, hipStream_t s);

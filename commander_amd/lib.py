@@ -111,6 +111,7 @@ def _sig(L):
     L.cmdr_sigma_l_dev.argtypes = [c_vp, c_i64, c_int, c_int, c_vp]
     L.cmdr_profile_enable.argtypes = [c_vp, c_int]
     L.cmdr_profile_read.argtypes = [c_vp, dp, ctypes.POINTER(ctypes.c_longlong)]
+    L.cmdr_profile_read_ext.argtypes = [c_vp, c_int, dp, ctypes.POINTER(ctypes.c_longlong)]
     L.cmdr_alm_to_chain_order.argtypes = [dp, c_int, c_int, ctypes.POINTER(ctypes.c_float)]
     L.cmdr_alm_from_chain_order.argtypes = [ctypes.POINTER(ctypes.c_float), c_int, c_int, dp]
     L.cmdr_chain_write_comp.argtypes = [ctypes.c_char_p, c_int, ctypes.c_char_p, dp, c_int, c_int, dp, dp, dp]

@@ -170,6 +170,15 @@ module cmdr_hip_mod
        type(c_ptr),    value :: user
      end subroutine cmdr_sharp_register_comm
 
+     function cmdr_profile_read_ext(ctx, nkinds, ms_sum, count) bind(c, name='cmdr_profile_read_ext') result(ierr)
+       import :: c_int, c_ptr, c_double, c_long_long
+       type(c_ptr),    value         :: ctx
+       integer(c_int), value         :: nkinds
+       real(c_double), intent(out)   :: ms_sum(*)
+       integer(c_long_long), intent(out) :: count(*)
+       integer(c_int)                :: ierr
+     end function cmdr_profile_read_ext
+
      function cmdr_ctx_set_literal_quirks(ctx, on) bind(c, name='cmdr_ctx_set_literal_quirks') result(ierr)
        import :: c_int, c_ptr
        type(c_ptr),    value :: ctx

@@ -288,6 +288,9 @@ int cmdr_cl_apply_apod(int lmax, int nmaps, int l_apod, int lmax_prior, double* 
  * launches, 1 fused ring-stage launches, 2 Legendre adjoint launches, 3 whole cr_matmulA.  ms_sum[4], count[4]. */
 int cmdr_profile_enable(cmdr_ctx* ctx, int on);
 int cmdr_profile_read(cmdr_ctx* ctx, double* ms_sum, long long* count);
+/* the same with nkinds <= 6 entries: kind 4 = launches of the matrix-unit Legendre adjoint kernel (k_leg_adj_mx, up to 8
+ * maps per launch: the dominant kernel), kind 5 = the VALU adjoint launches of the maps it leaves over; 4 + 5 = kind 2 */
+int cmdr_profile_read_ext(cmdr_ctx* ctx, int nkinds, double* ms_sum, long long* count);
 /* out[0] = number of (band, Stokes) maps, out[1] = wave tasks of the first plan, out[2] = total (ring pair, l, m)
  * recursion steps one Legendre launch of the first plan performs for ONE map (algorithmic work, mlim-pruned) */
 int cmdr_problem_info(cmdr_ctx* ctx, int64_t* out);

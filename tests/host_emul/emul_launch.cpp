@@ -82,7 +82,9 @@ static void adj_RN(const LegArgs& A, const WaveTask* tasks, int ntasks, const do
     }
 }
 void launch_leg_adj(const LegArgs& A, const WaveTask* tasks, int ntasks, const double* ph, int64_t ph_stride,
-                    double* part, int64_t pms, int64_t pcs, int nmaps, bool square, hipStream_t) {
+                    double* part, int64_t pms, int64_t pcs, int nmaps, bool square, hipStream_t,
+                    const std::function<void(int)>& between) {
+    if (between && !square) between(0);
     if (square) {
         for (int k0 = 0; k0 < nmaps; ++k0) {
             if (A.R == 1) adj_RN<1, 1, true>(A, tasks, ntasks, ph, ph_stride, k0, part, pms, pcs);
