@@ -1471,6 +1471,7 @@ void CrSystem::precond_init_pseudoinv() {
         }
         for (int bm = 0; bm < G.nbm; ++bm) mp[bm] = bands_[G.bm_band[bm]].mulP.get() + (int64_t)G.bm_stokes[bm] * np;
         G.mulP_ptrs.upload(mp);
+        G.plan->toeplitz_build(mp, G.thatP, stream_);
     }
     lmax_pre_ = -1;
     nmaps_pre_ = 0;
@@ -1557,7 +1558,7 @@ void CrSystem::apply_pseudoinv(const double* x, double* y) {
                               P.leg2().cnorm.get(), G.lmax, stream_);
         P.synth_from_stream(G.nT, stream_);                                              // WY        :2295
         if (G.npol) P.synth2_from_stream(G.npol, G.nT, stream_);
-        P.rings(2, nullptr, 0, G.mulP_ptrs.get(), false, G.nbm, stream_);                // N         :2297
+        P.rings(2, nullptr, 0, G.mulP_ptrs.get(), false, G.nbm, stream_, G.thatP.get());  // N         :2297
         P.adjoint_to_partials(G.nT, false, stream_);                                     // YtW       :2299
         if (G.npol) P.adjoint2_to_partials(G.npol, G.nT, stream_);
         launch_band_post(comps_dev_.get(), ncomp, lmax_max_, P.partials(), P.part_map_stride(), P.leg().tri_elems(),

@@ -199,6 +199,7 @@ class CrSystem {
         // pseudo-inverse preconditioner
         DevBuf<double> w_pin, w_pout;       // [nbm][ncomp][lmax+1]
         DevBuf<const double*> mulP_ptrs;    // [nbm]
+        DevBuf<cd> thatP;                   // circulant spectra of the mulP maps (Toeplitz ring form of the N operator)
     };
     CellBase cell_base(int band) const;
     void compact_forward(Group& G, const double* sx, double* maps);     // maps += P (sigma already applied: sx)

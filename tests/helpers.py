@@ -411,3 +411,22 @@ def ctx_sym(ctx, v):
     out = ctx.cr_matmulA(v)
     ctx.set_literal_quirks(True)
     return out
+
+
+def pinv_toeplitz_checks(_lib=None, nside=256, lmax=512, tol=1e-10):
+    """Pseudo-inverse preconditioner at a size where the polar-cap rings take the Toeplitz (circulant) ring form
+    (Nside >= 256): applyDiffPrecond_pseudoinv's N operator (WY . N . YtW, comm_diffuse_comp_mod.f90:2293-2299) against
+    the oracle, with azimuth-dependent noise."""
+    from commander_amd import synth
+    from commander_amd.cr import build_context
+    spec = synth.make_problem("cfg2", nside=nside, lmax=lmax, aniso=0.3)
+    ctx = build_context(spec, _lib=_lib)
+    S = oracle_system(spec)
+    ctx.initPrecond("pseudoinv"); ctx.update_precond()
+    S.init_precond_pseudoinv(); S.update_precond_pseudoinv()
+    for b in range(len(spec["bands"])):
+        assert abs(ctx.alpha_nu(b)[0] / S.bands[b].alpha_nu[0] - 1.0) < 1e-11
+    x = np.random.default_rng(17).standard_normal(ctx.ncr)
+    got = ctx.cr_invM(x)
+    assert rel(got, S.invM(x)) < tol
+    assert np.array_equal(ctx.cr_invM(x), got)

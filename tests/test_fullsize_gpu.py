@@ -94,3 +94,8 @@ def test_cfg4_matmulA_full_size_vs_oracle():
     n = ctx.ncr // 3
     for k in range(3):                       # T, E and B blocks each, not only the norm-dominating one
         assert rel(y[k * n:(k + 1) * n], yo[k * n:(k + 1) * n]) < 1e-11
+
+
+def test_pseudoinv_with_toeplitz_rings_vs_oracle():
+    from helpers import pinv_toeplitz_checks
+    pinv_toeplitz_checks(None, nside=256, lmax=512)

@@ -462,3 +462,8 @@ def test_emul_literal_quirks_switch(EL):
     """the reference's stale-l behaviour in cr_matmulA is available behind a switch (oracle + product)."""
     from helpers import literal_quirks_checks
     literal_quirks_checks(EL)
+
+
+def test_emul_pseudoinv_with_toeplitz_rings(EL):
+    from helpers import pinv_toeplitz_checks
+    pinv_toeplitz_checks(EL)
