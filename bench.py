@@ -261,17 +261,39 @@ def main():
         dev = "cuda:%d" % local_rank
         if collective == "rccl-native":
             # RCCL inside the library: ncclUniqueId from rank 0 through torch.distributed, then every sum over ranks is
-            # an ncclAllReduce the library enqueues on its own stream (include/cmdr_hip.h, cmdr_ctx_init_rccl)
-            idt = torch.zeros(128, dtype=torch.uint8, device=dev)
-            if rank == 0:
-                idt.copy_(torch.frombuffer(bytearray(ctx.rccl_unique_id()), dtype=torch.uint8))
-            dist.broadcast(idt, src=0)
-            ctx.init_rccl(bytes(idt.cpu().numpy().tobytes()), rank, world)
-            if lay["band_parts"] > 1:
-                ctx.rccl_split_rings(rank // lay["ring_parts"], lay["ring_index"], lay["ring_parts"])
-            rccl_world = ctx.rccl_size()
-            assert rccl_world == world, (rccl_world, world)
-        else:
+            # an ncclAllReduce the library enqueues on its own stream (include/cmdr_hip.h, cmdr_ctx_init_rccl).  If the
+            # run-time binding fails on ANY rank (librccl not loadable, communicator refused) all ranks switch together
+            # to the same collective through torch.distributed on the library stream, and the JSON line says so.
+            ok = 1
+            try:
+                idt = torch.zeros(128, dtype=torch.uint8, device=dev)
+                if rank == 0:
+                    idt.copy_(torch.frombuffer(bytearray(ctx.rccl_unique_id()), dtype=torch.uint8))
+            except Exception as e:
+                sys.stderr.write("bench.py rank %d: native RCCL unavailable (%r)\n" % (rank, e))
+                ok = 0
+            flag = torch.tensor([ok], dtype=torch.int32, device=dev)
+            dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+            if int(flag.item()) == 1:
+                dist.broadcast(idt, src=0)
+                try:
+                    ctx.init_rccl(bytes(idt.cpu().numpy().tobytes()), rank, world)
+                    if lay["band_parts"] > 1:
+                        ctx.rccl_split_rings(rank // lay["ring_parts"], lay["ring_index"], lay["ring_parts"])
+                    rccl_world = ctx.rccl_size()
+                except Exception as e:
+                    sys.stderr.write("bench.py rank %d: native RCCL init failed (%r)\n" % (rank, e))
+                    ok = 0
+                flag = torch.tensor([ok], dtype=torch.int32, device=dev)
+                dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+            if int(flag.item()) != 1:
+                collective = "torch-stream (native RCCL binding failed, see stderr)"
+                if lay["band_parts"] > 1 and lay["ring_parts"] > 1:
+                    ring_groups = [dist.new_group([bg * lay["ring_parts"] + i for i in range(lay["ring_parts"])])
+                                   for bg in range(lay["band_parts"])]
+            else:
+                assert rccl_world == world, (rccl_world, world)
+        if collective != "rccl-native":
             views = {}
 
             def host_view(ptr, n):   # rehearsal: "device" memory of the emulation is host memory
