@@ -23,13 +23,20 @@ program api_tour
   integer(c_int),     allocatable     :: par(:)
   real(c_double),     allocatable     :: val(:)
   real(c_double) :: res(2), sgm(2), mean(2), lhs, rhs
-  real(c_double), allocatable :: Dl(:), u(:)
+  real(c_double), allocatable, target :: Dl(:)
+  real(c_double), allocatable :: u(:)
   type(cmdr_cl_bin), allocatable :: bins(:)
   integer(c_int) :: nused, niter2
   integer(c_size_t) :: mem_free, mem_total, nb
   type(c_ptr) :: dx, dy, dz
   integer :: l, i, n
   integer(8) :: seed
+  character(kind=c_char) :: rid(128)
+  real(c_double), allocatable, target :: siN_low(:)
+  integer(c_int) :: nside_low(2)
+  type(c_ptr)    :: low_p(2)
+  real(c_double) :: pms(6)
+  integer(c_long_long) :: pcnt(6)
 
   if (cmdr_device_count() < 1) then
      write(*,*) 'api_tour: no GPU visible (libcmdr_hip has no CPU path)'
@@ -161,6 +168,56 @@ program api_tour
        & niter, res, stat), 'second solve')
   if (stat /= 0) stop 'api_tour: second CG did not converge'
   write(*,'(a,i4,a)') ' second sample (new C_l) converged in ', niter, ' iterations'
+
+  ! ---- round-2 entry points ------------------------------------------------------------------------------------
+  ! RCCL inside the library with a communicator of one rank: the id would be MPI_Bcast by the driver (INTEGRATION.md)
+  if (cmdr_rccl_version() > 0) then
+     call cmdr_check(cmdr_rccl_unique_id(rid), 'rccl id')
+     call cmdr_check(cmdr_ctx_init_rccl(ctx, rid, 0_c_int, 1_c_int), 'rccl init')
+     if (cmdr_ctx_rccl_size(ctx) /= 1) stop 'api_tour: rccl communicator size'
+     call cmdr_check(cmdr_matmulA(ctx, x, ay), 'cr_matmulA through ncclAllReduce')
+     if (any(ay /= ax)) stop 'api_tour: a one-rank all-reduce changed the matvec'
+  else
+     write(*,*) 'api_tour: librccl not loadable, RCCL leg skipped'
+  end if
+  ! literal pmap%alm re-use of cr_matmulA (both components have the same lmax here: no effect, by construction)
+  call cmdr_check(cmdr_ctx_set_literal_quirks(ctx, 1_c_int), 'literal quirks on')
+  call cmdr_check(cmdr_matmulA(ctx, x, ay), 'cr_matmulA, literal')
+  if (any(ay /= ax)) stop 'api_tour: literal_quirks changed A although all lmax are equal'
+  call cmdr_check(cmdr_ctx_set_literal_quirks(ctx, 0_c_int), 'literal quirks off')
+  ! low-l dense preconditioner block (CG_LMAX_PRECOND = 3): coadded noise at Nside 4 = sqrt of the summed siN^2 of the children
+  allocate(siN_low(12*4*4))
+  siN_low = sqrt(4.d0) * sum(siN) / npix                             ! smooth noise: every coarse pixel alike
+  nside_low = 4
+  low_p = [c_loc(siN_low), c_loc(siN_low)]
+  call cmdr_check(cmdr_precond_set_lowl(ctx, 0_c_int, 3_c_int, nside_low, low_p), 'set_lowl')
+  call cmdr_check(cmdr_precond_update_diag(ctx), 'update_precond with the low-l block')
+  call cmdr_check(cmdr_precond_set_lowl(ctx, 0_c_int, -1_c_int, nside_low, low_p), 'lowl off (first)')
+  call cmdr_check(cmdr_invM(ctx, x, ax), 'cr_invM, diagonal only')
+  call cmdr_check(cmdr_precond_set_lowl(ctx, 0_c_int, 3_c_int, nside_low, low_p), 'set_lowl again')
+  call cmdr_check(cmdr_precond_update_diag(ctx), 'update_precond with the low-l block')
+  call cmdr_check(cmdr_invM(ctx, x, ay), 'cr_invM with the low-l block')
+  ! applyLowlPrecond overwrites exactly the (L+1)^2 = 16 temperature entries with l <= 3 of component 0 (the block acts
+  ! on the INPUT vector, comm_cr_mod.f90:1064-1067; with a second diffuse component M^-1 is then no longer symmetric --
+  ! the reference enables the block for CMB-only sampling groups)
+  if (count(ay /= ax) /= 16) stop 'api_tour: the low-l block must change 16 entries'
+  if (any(ay /= ay)) stop 'api_tour: NaN from the low-l block'
+  call cmdr_check(cmdr_precond_set_lowl(ctx, 0_c_int, -1_c_int, nside_low, low_p), 'lowl off')
+  ! chain file: write component 0 of the sample, read it back (single precision on disk)
+  ierr = cmdr_chain_write_comp('api_tour_chain.h5'//c_null_char, 1_c_int, 'cmb'//c_null_char, sol(1:nalm), lmax, nmaps, &
+       & c_null_ptr, c_loc(sig), c_loc(Dl))
+  if (ierr == 0) then
+     call cmdr_check(cmdr_chain_read_comp('api_tour_chain.h5'//c_null_char, 1_c_int, 'cmb'//c_null_char, lmax, nmaps, &
+          & c_null_ptr, back, c_null_ptr), 'chain read')
+     if (maxval(abs(back - real(real(sol(1:nalm), c_float), c_double))) > 0.d0) stop 'api_tour: chain file round trip'
+  else
+     write(*,*) 'api_tour: libhdf5 not loadable, chain-file leg skipped'
+  end if
+  ! per-kernel timings incl. the matrix-unit adjoint (kinds 4, 5)
+  call cmdr_check(cmdr_profile_enable(ctx, 1_c_int), 'profile on')
+  call cmdr_check(cmdr_matmulA(ctx, x, ay), 'cr_matmulA, profiled')
+  call cmdr_check(cmdr_profile_read_ext(ctx, 6_c_int, pms, pcnt), 'profile read')
+  if (pcnt(4) /= 1 .or. pcnt(5) + pcnt(6) < 1) stop 'api_tour: profile counts'
 
   call cmdr_check(cmdr_ctx_destroy(ctx), 'cmdr_ctx_destroy')
   write(*,*) 'api_tour: OK'
