@@ -93,7 +93,7 @@ CMDR_HD void band_post_elem(const CompDev* __restrict__ comps, int ncomp, const 
                             int64_t part_map_stride, int64_t part_chunk_stride, int nchunk, int nbm,
                             const int* __restrict__ bm_stokes, const double* __restrict__ w /* [nbm][ncomp][lmax_g+1] */,
                             const double* __restrict__ cnorm, int lmax_g, double* __restrict__ yc, int accumulate,
-                            int m, int l) {
+                            int m, int l, const int* __restrict__ lwtab = nullptr) {
     // one thread = one (l, m): the chunk partials of a band map are read once and feed every component
     constexpr int kMaxComp = 8;
     double re[kMaxComp], im[kMaxComp];
@@ -112,6 +112,7 @@ CMDR_HD void band_post_elem(const CompDev* __restrict__ comps, int ncomp, const 
             const double* p = part + b * part_map_stride + 2 * t;
             double sr = 0.0, si = 0.0;
             for (int ch = 0; ch < nchunk; ++ch) {
+                if (lwtab && l < lwtab[m * nchunk + ch]) continue;   // never written by the adjoint: structurally zero
                 sr += p[ch * part_chunk_stride];
                 si += p[ch * part_chunk_stride + 1];
             }

@@ -575,7 +575,7 @@ void CrSystem::mix_adjoint(Group& G, bool rhs) {
     ShtPlan& P = *G.plan;
     const int64_t na = P.nalm();
     launch_part_to_alm(P.partials(), P.part_map_stride(), P.leg().tri_elems(), P.leg().nchunk, G.U.get(), na,
-                       P.leg().cnorm.get(), G.lmax, G.nT, stream_);
+                       P.leg().cnorm.get(), G.lmax, G.nT, stream_, P.leg().lw_chunk.get());
     if (G.npol)
         launch_part2_to_alm(P.partials2(), P.part2_pol_stride(), P.leg2().tri4(), P.leg2().nchunk,
                             G.U.get() + (int64_t)G.nT * na, G.U.get() + (int64_t)(G.nT + 1) * na, 2 * na,
@@ -790,7 +790,7 @@ void CrSystem::adjoint_groups_to_yc(bool from_maps) {
         span_end();
         launch_band_post(comps_dev_.get(), ncomp, lmax_max_, P.partials(), P.part_map_stride(), P.leg().tri_elems(),
                          P.leg().nchunk, G.nT, G.bm_stokes_dev.get(), G.w.get(), P.leg().cnorm.get(), G.lmax,
-                         yc_.get(), g > 0, stream_);
+                         yc_.get(), g > 0, stream_, P.leg().lw_chunk.get());
         if (G.npol)
             launch_band_post2(comps_dev_.get(), ncomp, lmax_max_, P.partials2(), P.part2_pol_stride(), P.leg2().tri4(),
                               P.leg2().nchunk, G.npol, G.w.get(), G.nT, P.leg2().cnorm.get(), G.lmax, yc_.get(),
@@ -1563,7 +1563,7 @@ void CrSystem::apply_pseudoinv(const double* x, double* y) {
         if (G.npol) P.adjoint2_to_partials(G.npol, G.nT, stream_);
         launch_band_post(comps_dev_.get(), ncomp, lmax_max_, P.partials(), P.part_map_stride(), P.leg().tri_elems(),
                          P.leg().nchunk, G.nT, G.bm_stokes_dev.get(), G.w_pout.get(), P.leg().cnorm.get(), G.lmax,
-                         yc_.get(), g > 0, stream_);                                     // alpha^2, U^+  :2303-2322
+                         yc_.get(), g > 0, stream_, P.leg().lw_chunk.get());             // alpha^2, U^+  :2303-2322
         if (G.npol)
             launch_band_post2(comps_dev_.get(), ncomp, lmax_max_, P.partials2(), P.part2_pol_stride(), P.leg2().tri4(),
                               P.leg2().nchunk, G.npol, G.w_pout.get(), G.nT, P.leg2().cnorm.get(), G.lmax, yc_.get(),

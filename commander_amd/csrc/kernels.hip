@@ -860,7 +860,7 @@ void launch_ring(int mode, const RingDev* rings, const int* cls, int ncls, int l
     if (const char* e = std::getenv("CMDR_RING_THREADS")) { const int v = std::atoi(e); if (v == 256 || v == 512 || v == 1024) nthr = v; }
     if (nthr > (1 << log2M) / 2) nthr = std::max(64, (1 << log2M) / 2);
     static int xbl = -1;                      // log2 of the pairs per block
-    if (xbl < 0) { xbl = 4; if (const char* e = std::getenv("CMDR_RING_XBL")) { const int v = std::atoi(e); if (v >= 0 && v <= 10) xbl = v; } }
+    if (xbl < 0) { xbl = 2; if (const char* e = std::getenv("CMDR_RING_XBL")) { const int v = std::atoi(e); if (v >= 0 && v <= 10) xbl = v; } }
     const int xb = 1 << xbl;
     const int per = ((ncls + 8 * xb - 1) / (8 * xb)) * xb;   // pairs per XCD group: whole blocks
     dim3 grid(8 * per * nmaps);
@@ -903,16 +903,16 @@ void launch_alm_to_stream(const double* alm, int64_t alm_stride, double* ast, co
 // partial columns -> Commander real-packed a_lm: alm = kappa'_m * cnorm * sum_chunks part ; kappa' = sqrt2 (m>0).
 __global__ void k_part_to_alm(const double* __restrict__ part, int64_t part_map_stride, int64_t part_chunk_stride,
                               int nchunk, double* __restrict__ alm, int64_t alm_stride,
-                              const double* __restrict__ cnorm, int lmax) {
+                              const double* __restrict__ cnorm, int lmax, const int* __restrict__ lwtab) {
     const int m = blockIdx.y, l = m + blockIdx.x * 256 + threadIdx.x;
     if (l > lmax) return;
     part_to_alm_elem(part + blockIdx.z * part_map_stride, part_chunk_stride, nchunk, alm + blockIdx.z * alm_stride,
-                     cnorm, lmax, m, l);
+                     cnorm, lmax, m, l, lwtab);
 }
 void launch_part_to_alm(const double* part, int64_t pms, int64_t pcs, int nchunk, double* alm, int64_t alm_stride,
-                        const double* cnorm, int lmax, int nmaps, hipStream_t s) {
+                        const double* cnorm, int lmax, int nmaps, hipStream_t s, const int* lwtab) {
     dim3 grid((lmax + 1 + 255) / 256, lmax + 1, nmaps);
-    hipLaunchKernelGGL(k_part_to_alm, grid, dim3(256), 0, s, part, pms, pcs, nchunk, alm, alm_stride, cnorm, lmax);
+    hipLaunchKernelGGL(k_part_to_alm, grid, dim3(256), 0, s, part, pms, pcs, nchunk, alm, alm_stride, cnorm, lmax, lwtab);
 }
 
 }  // namespace cmdr

@@ -31,8 +31,10 @@ void launch_ring_toeplitz_spec(const RingDev* rings, const int* cls, int ncls, i
                                int64_t npair_pad, cd* that, const cd* tw, int log2Mmax, hipStream_t s);
 void launch_alm_to_stream(const double* alm, int64_t alm_stride, double* ast, const double* cnorm, int lmax,
                           int nmaps, hipStream_t s);
+// lwtab (optional): [(lmax+1) * nchunk] first l written for (m, chunk) -- entries below it are structurally zero and
+// are not read (a quarter of the partial columns at Nside 1024 / lmax 2000)
 void launch_part_to_alm(const double* part, int64_t pms, int64_t pcs, int nchunk, double* alm, int64_t alm_stride,
-                        const double* cnorm, int lmax, int nmaps, hipStream_t s);
+                        const double* cnorm, int lmax, int nmaps, hipStream_t s, const int* lwtab = nullptr);
 
 // ---- spin-2 Legendre stage: npol polarisation pairs; pair ip uses phase maps kq0 + 2 ip (Q) and kq0 + 2 ip + 1 (U);
 // stream st[((t * npol) + ip) * 4 + {E'r,E'i,B'r,B'i}]; partials part[ip][chunk][4 * padded triangle]
@@ -55,7 +57,7 @@ void launch_band_prep(const CompDev* comps, int ncomp, const double* sx, const d
                       const double* extra = nullptr);
 void launch_band_post(const CompDev* comps, int ncomp, int lmax_max, const double* part, int64_t pms, int64_t pcs,
                       int nchunk, int nbm, const int* bm_stokes, const double* w, const double* cnorm, int lmax_g,
-                      double* yc, bool accumulate, hipStream_t s);
+                      double* yc, bool accumulate, hipStream_t s, const int* lwtab = nullptr);
 void launch_band_prep2(const CompDev* comps, int ncomp, const double* sx, const double* w, int nT, double* st, int npol,
                        const double* cnorm2, int lmax_g, hipStream_t s, const double* extra = nullptr);
 void launch_band_post2(const CompDev* comps, int ncomp, int lmax_max, const double* part2, int64_t pps, int64_t pcs,

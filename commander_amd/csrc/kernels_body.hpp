@@ -1070,10 +1070,12 @@ CMDR_HD void alm_to_stream_elem(const double* __restrict__ a, double* __restrict
 
 // adjoint partial columns -> packed a_lm: kappa'_m * cnorm * sum_chunks part ; kappa' = sqrt2 for m > 0.
 CMDR_HD void part_to_alm_elem(const double* __restrict__ p, int64_t part_chunk_stride, int nchunk,
-                              double* __restrict__ a, const double* __restrict__ cnorm, int lmax, int m, int l) {
+                              double* __restrict__ a, const double* __restrict__ cnorm, int lmax, int m, int l,
+                              const int* __restrict__ lwtab = nullptr) {
     const int64_t t = d_moffp(lmax, m) + (l - m);
     double re = 0.0, im = 0.0;
     for (int c = 0; c < nchunk; ++c) {
+        if (lwtab && l < lwtab[m * nchunk + c]) continue;     // never written: structurally zero
         re += p[c * part_chunk_stride + 2 * t];
         im += p[c * part_chunk_stride + 2 * t + 1];
     }

@@ -137,6 +137,8 @@ void LegendreTables::build(int lmax_, const std::vector<double>& x_, const std::
     make_tasks(R, tm);
     tasks.clear();
     for (int m = 0; m < nm; ++m) tasks.insert(tasks.end(), tm[m].begin(), tm[m].end());
+    lw_chunk.assign((size_t)nm * nchunk, lmax + 2);     // partial-column entries below it are never written (stay zero)
+    for (const WaveTask& t : tasks) lw_chunk[(size_t)t.m * nchunk + t.chunk] = t.lw;
     // longest first == smallest lw first (all columns end at lmax)
     std::stable_sort(tasks.begin(), tasks.end(), [](const WaveTask& a, const WaveTask& b) { return a.lw < b.lw; });
     while (tasks.size() % 4) { WaveTask t; t.m = 0; t.chunk = -1; t.lw = lmax + 1; t.lAend = lmax + 1; tasks.push_back(t); }

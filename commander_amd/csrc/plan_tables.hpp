@@ -34,6 +34,7 @@ struct LegendreTables {
     std::vector<double> seedc, seedp;   // mu_{ls}, mu_{ls-1}
     // adjoint kernel: R pairs per lane, one task per wavefront, 4 per workgroup, longest first
     std::vector<WaveTask> tasks;
+    std::vector<int> lw_chunk;           // [(lmax+1) * nchunk] first l the adjoint writes for (m, chunk); lmax+2: nothing
     int group = 4;
     bool synth_wg = false;               // tasks_s grouped: tasks_s[4i .. 4i+3] = 4 chunks of one m (chunk = -1: none)
     // synthesis kernel: Rs pairs per lane, same layout (its own list so R and Rs can be tuned independently)

@@ -19,6 +19,7 @@ void LegendreDev::upload(const LegendreTables& T) {
     alpha.upload(T.alpha);
     cnorm.upload(T.cnorm);
     tasks.upload(T.tasks);
+    lw_chunk.upload(T.lw_chunk);
 }
 
 LegArgs LegendreDev::args() const {
@@ -212,7 +213,7 @@ void ShtPlan::map2alm(const double* d_map, int64_t map_stride, double* d_alm, in
         rings(1, const_cast<double*>(d_map) + i0 * map_stride, map_stride, nullptr, weighted, nb, s);
         adjoint_to_partials(nb, false, s);
         launch_part_to_alm(part_.get(), part_map_stride(), leg_.tri_elems(), leg_.nchunk, d_alm + i0 * alm_stride,
-                           alm_stride, leg_.cnorm.get(), T_.lmax, nb, s);
+                           alm_stride, leg_.cnorm.get(), T_.lmax, nb, s, leg_.lw_chunk.get());
     }
 }
 
@@ -315,7 +316,7 @@ void ShtPlan::sandwich(const double* d_in, double* d_out, const double* const* d
     if (nT) {
         adjoint_to_partials(nTout, false, s);
         launch_part_to_alm(part_.get(), part_map_stride(), leg_.tri_elems(), leg_.nchunk, d_out, na, leg_.cnorm.get(),
-                           T_.lmax, nTout, s);
+                           T_.lmax, nTout, s, leg_.lw_chunk.get());
     }
     if (npol) {
         if (nPout < npol) {

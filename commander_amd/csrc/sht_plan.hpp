@@ -20,7 +20,7 @@ class LegendreDev {  // device mirror of LegendreTables
     int lmax = -1, npair_pad = 0, R = 1, Rs = 1, nchunk = 0, ntasks = 0, ntasks_s = 0;
     bool synth_wg = false;
     DevBuf<double> x, seedc, seedp, alpha, cnorm;
-    DevBuf<int> ls;
+    DevBuf<int> ls, lw_chunk;
     DevBuf<WaveTask> tasks, tasks_s;
     int64_t ph_elems() const { return (int64_t)(lmax + 1) * npair_pad * 4; }       // doubles per map
     int64_t tri_elems() const { return 2 * ntrip(lmax); }                          // doubles per map

@@ -229,11 +229,11 @@ void launch_alm_to_stream(const double* alm, int64_t alm_stride, double* ast, co
                 alm_to_stream_elem(alm + k * alm_stride, ast, nmaps, k, cnorm, lmax, m, l);
 }
 void launch_part_to_alm(const double* part, int64_t pms, int64_t pcs, int nchunk, double* alm, int64_t alm_stride,
-                        const double* cnorm, int lmax, int nmaps, hipStream_t) {
+                        const double* cnorm, int lmax, int nmaps, hipStream_t, const int* lwtab) {
     for (int k = 0; k < nmaps; ++k)
         for (int m = 0; m <= lmax; ++m)
             for (int l = m; l <= lmax; ++l)
-                part_to_alm_elem(part + k * pms, pcs, nchunk, alm + k * alm_stride, cnorm, lmax, m, l);
+                part_to_alm_elem(part + k * pms, pcs, nchunk, alm + k * alm_stride, cnorm, lmax, m, l, lwtab);
 }
 
 void launch_sqrtS(const CompDev* comps, int ncomp, int, const double* smat, int kind, const double* in,
@@ -263,10 +263,11 @@ void launch_pinv_prior(const CompDev* comps, int ncomp, int, const double* Q, in
 }
 void launch_band_post(const CompDev* comps, int ncomp, int lmax_max, const double* part, int64_t pms, int64_t pcs,
                       int nchunk, int nbm, const int* bm_stokes, const double* w, const double* cnorm, int lmax_g,
-                      double* yc, bool accumulate, hipStream_t) {
+                      double* yc, bool accumulate, hipStream_t, const int* lwtab) {
     for (int m = 0; m <= lmax_max; ++m)
         for (int l = m; l <= lmax_max; ++l)
-            band_post_elem(comps, ncomp, part, pms, pcs, nchunk, nbm, bm_stokes, w, cnorm, lmax_g, yc, accumulate ? 1 : 0, m, l);
+            band_post_elem(comps, ncomp, part, pms, pcs, nchunk, nbm, bm_stokes, w, cnorm, lmax_g, yc, accumulate ? 1 : 0, m, l,
+                           m <= lmax_g ? lwtab : nullptr);
 }
 void launch_band_prep2(const CompDev* comps, int ncomp, const double* sx, const double* w, int nT, double* st, int npol,
                        const double* cnorm2, int lmax_g, hipStream_t, const double* extra) {
