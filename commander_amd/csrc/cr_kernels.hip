@@ -143,7 +143,7 @@ __global__ void k_fill_gl(double* __restrict__ ph, const double* __restrict__ wn
                           int npair_pad, int lmax) {
     const int p = blockIdx.x * 256 + threadIdx.x, m = blockIdx.y;
     if (p >= npair_pad) return;
-    double* o = ph + ((int64_t)m * npair_pad + p) * 4;
+    double* o = ph + d_phidx(lmax + 1, p, m);
     o[0] = wn[p];
     o[1] = 0.0;
     o[2] = ws[p];

@@ -159,7 +159,7 @@ __global__ void __launch_bounds__(256) k_leg_synth_wg(LegArgs A, const WaveTask*
         const int p = base + r * 64;
 #pragma unroll
         for (int k = 0; k < NB; ++k) {
-            double* o = ph + (k0 + k) * ph_stride + ((int64_t)m * A.npair_pad + p) * 4;
+            double* o = ph + (k0 + k) * ph_stride + d_phidx(A.lmax + 1, p, m);
             o[0] = Er[r][k] + Or[r][k];
             o[1] = Ei[r][k] + Oi[r][k];
             o[2] = Er[r][k] - Or[r][k];
@@ -345,12 +345,13 @@ __global__ void __launch_bounds__(128) k_leg_adj_mx(LegArgs A, const WaveTask* _
     const bool on = mk < nb;
     double Be[2][16], Bo[2][16];
     {
-        const double* __restrict__ g0 = ph + (int64_t)(k0 + (on ? mk : 0)) * ph_stride + ((int64_t)m * A.npair_pad + pbase + kq) * 4 + reim;
+        const double* __restrict__ g0 = ph + (int64_t)(k0 + (on ? mk : 0)) * ph_stride + d_phidx(lmax + 1, pbase + kq, m) + reim;
+        const int64_t prow4 = 4 * (int64_t)(lmax + 1);
 #pragma unroll
         for (int r = 0; r < 2; ++r)
 #pragma unroll
             for (int q = 0; q < 16; ++q) {
-                const double* g = g0 + (r * 64 + 4 * q) * 4;
+                const double* g = g0 + (r * 64 + 4 * q) * prow4;
                 const double n = on ? g[0] : 0.0, s = on ? g[2] : 0.0;
                 Be[r][q] = n + s;
                 Bo[r][q] = n - s;
@@ -642,7 +643,7 @@ __global__ void __launch_bounds__(256) k_leg2_synth_np2(Leg2Args A, const WaveTa
             for (int q = 0; q < 2; ++q) {
                 const double kr = swap ? ar[r][p][2 * q + 1] : ar[r][p][2 * q], ki = swap ? ai[r][p][2 * q + 1] : ai[r][p][2 * q];
                 const double fr = swap ? ar[r][p][2 * q] : ar[r][p][2 * q + 1], fi = swap ? ai[r][p][2 * q] : ai[r][p][2 * q + 1];
-                double* o = ph + (kq + 2 * p + q) * ph_stride + ((int64_t)m * A.npair_pad + pr) * 4;
+                double* o = ph + (kq + 2 * p + q) * ph_stride + d_phidx(A.lmax + 1, pr, m);
                 o[0] = kr + fr;
                 o[1] = ki + fi;
                 o[2] = kr - fr;
@@ -796,7 +797,7 @@ void launch_part2_to_alm(const double* part, int64_t part_pol_stride, int64_t pc
 //   MODE 2: phases -> pixels * mul[pix] -> phases   (fused Y, N^-1, Y^T of the CR matvec; map never hits HBM)
 template <int MODE>
 __global__ void __launch_bounds__(1024) k_ring(const RingDev* __restrict__ rings, const int* __restrict__ cls,
-                                              double* __restrict__ ph, int64_t ph_stride, int64_t npair_pad,
+                                              double* __restrict__ ph, int64_t ph_stride, int64_t prow /* rows (m) per pair of the phase layout */,
                                               double* __restrict__ map, int64_t map_stride,
                                               const double* const* __restrict__ mul, int weighted,
                                               const cd* __restrict__ tw, int log2Mmax,
@@ -807,35 +808,40 @@ __global__ void __launch_bounds__(1024) k_ring(const RingDev* __restrict__ rings
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     cd* buf = reinterpret_cast<cd*>(smem);
     // Workgroups with equal blockIdx % 8 share an XCD (and its L2).  Deal the class's ring pairs to the 8 groups in
-    // blocks of 2^xbl neighbours (4 pairs x 32 B = one 128-B line of the phase array) and let each group walk pair-major,
-    // map-minor: the maps of one pair re-use the pair's chirp / rotation tables from L2, line-sharing neighbours stay
-    // on one XCD, and cheap (belt) and expensive (Bluestein, split) rings spread evenly over the XCDs.
+    // blocks of 2^xbl neighbours (4 pairs x 32 B = one 128-B line of the phase array) and let each group walk block-major,
+    // then map, then the pairs of the block: the workgroups that share the lines of a phase array (the same map, adjacent
+    // pairs) are dispatched back to back on one XCD, so the first one's misses fill L2 for the others -- the phase loads
+    // and stores are what this kernel spends its time on (65 KB between the 32-B entries of consecutive m of one pair;
+    // timing experiments) -- and cheap (belt) and expensive (cap) rings spread evenly over the XCDs.
     const int grp = blockIdx.x & 7, slot = blockIdx.x >> 3;
-    const int pl = slot / nmaps, imap = slot - pl * nmaps;
+    const int xb = 1 << xbl, blk = slot / (xb * nmaps), rem = slot - blk * xb * nmaps;
+    const int imap = rem >> xbl, pl = blk * xb + (rem & (xb - 1));
     const int idx = (((pl >> xbl) * 8 + grp) << xbl) + (pl & ((1 << xbl) - 1));
     if (pl >= per || idx >= ncls) return;
     const int pair = cls[idx];
     const RingDev d = rings[pair];
     FftCtx c{(int)threadIdx.x, (int)blockDim.x};
+    c.dbg = tw_off >> 24;
+    tw_off &= (1 << 24) - 1;
     if (tw_off) ring_tw_fill(buf + tw_off, tw, log2Mmax, c);   // visible after the first block barrier (before any FFT pass)
     cd* sc = d.split ? scratch + imap * scratch_map_stride + (int64_t)(d.split - 1) * scratch_line : nullptr;
-    ring_block<MODE>(buf, d, pair, ph + imap * ph_stride, npair_pad, map ? map + imap * map_stride : nullptr,
+    ring_block<MODE>(buf, d, pair, ph + imap * ph_stride, prow, map ? map + imap * map_stride : nullptr,
                      mul ? mul[imap] : nullptr, weighted ? d.wgt : 1.0, tw, log2Mmax, chirp, sc, c,
                      that ? that + imap * that_stride : nullptr);
 }
 
 __global__ void __launch_bounds__(1024) k_ring_toeplitz_spec(const RingDev* __restrict__ rings, const int* __restrict__ cls,
-                                                            const double* __restrict__ td, int64_t npair_pad,
+                                                            const double* __restrict__ td, int64_t prow,
                                                             cd* __restrict__ that, const cd* __restrict__ tw,
                                                             int log2Mmax) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int pair = cls[blockIdx.x];
     const RingDev d = rings[pair];
-    ring_toeplitz_spec(reinterpret_cast<cd*>(smem), d, td, npair_pad, pair, that, tw, log2Mmax,
+    ring_toeplitz_spec(reinterpret_cast<cd*>(smem), d, td, prow, pair, that, tw, log2Mmax,
                        FftCtx{(int)threadIdx.x, (int)blockDim.x});
 }
 void launch_ring_toeplitz_spec(const RingDev* rings, const int* cls, int ncls, int log2M, const double* td,
-                               int64_t npair_pad, cd* that, const cd* tw, int log2Mmax, hipStream_t s) {
+                               int64_t prow, cd* that, const cd* tw, int log2Mmax, hipStream_t s) {
     if (ncls == 0) return;
     static bool attr_set = false;
     if (!attr_set) {
@@ -845,16 +851,17 @@ void launch_ring_toeplitz_spec(const RingDev* rings, const int* cls, int ncls, i
     }
     const int nthr = std::max(64, std::min(512, (1 << log2M) / 2));
     hipLaunchKernelGGL(k_ring_toeplitz_spec, dim3(ncls), dim3(nthr), sizeof(cd) * (size_t)lds_elems(log2M), s, rings, cls, td,
-                       npair_pad, that, tw, log2Mmax);
+                       prow, that, tw, log2Mmax);
 }
 
 void launch_ring(int mode, const RingDev* rings, const int* cls, int ncls, int log2M, double* ph,
-                 int64_t ph_stride, int64_t npair_pad, double* map, int64_t map_stride, const double* const* mul,
+                 int64_t ph_stride, int64_t prow /* rows (m) per pair of the phase layout */, double* map, int64_t map_stride, const double* const* mul,
                  int weighted, const cd* tw, int log2Mmax, const cd* chirp, cd* scratch, int64_t scratch_map_stride,
                  int scratch_line, int nmaps, hipStream_t s, const cd* that, int64_t that_stride) {
     if (ncls == 0 || nmaps == 0) return;
     static const int use_ldstw = [] { const char* e = std::getenv("CMDR_RING_LDSTW"); return e ? std::atoi(e) : 1; }();
-    const int tw_off = use_ldstw ? lds_elems(log2M) : 0;      // two-level twiddle table behind the FFT image
+    static const int dbg_skip = [] { const char* e = std::getenv("CMDR_RING_DEBUG_SKIP"); return e ? std::atoi(e) : 0; }();
+    const int tw_off = (use_ldstw ? lds_elems(log2M) : 0) | (dbg_skip << 24);   // two-level twiddle table behind the FFT image
     const size_t lds = sizeof(cd) * (size_t)(lds_elems(log2M) + (use_ldstw ? ring_tw_elems(log2Mmax) : 0));
     int nthr = 512;   // measured: 512 > 256 threads per ring pair (more waves to cover LDS / global latency)
     if (const char* e = std::getenv("CMDR_RING_THREADS")) { const int v = std::atoi(e); if (v == 256 || v == 512 || v == 1024) nthr = v; }
@@ -872,7 +879,7 @@ void launch_ring(int mode, const RingDev* rings, const int* cls, int ncls, int l
                                       hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);                   \
             attr_set = true;                                                                                     \
         }                                                                                                        \
-        hipLaunchKernelGGL(k_ring<MM>, grid, dim3(nthr), lds, s, rings, cls, ph, ph_stride, npair_pad, map,      \
+        hipLaunchKernelGGL(k_ring<MM>, grid, dim3(nthr), lds, s, rings, cls, ph, ph_stride, prow, map,      \
                            map_stride, mul, weighted, tw, log2Mmax, chirp, scratch, scratch_map_stride,          \
                            scratch_line, ncls, nmaps, per, xbl, that, that_stride, tw_off);                      \
     } while (0)

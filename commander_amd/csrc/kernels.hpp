@@ -23,12 +23,12 @@ void launch_leg_adj(const LegArgs& A, const WaveTask* tasks, int ntasks, const d
                     hipStream_t s, const std::function<void(int)>& between = nullptr);
 // mode 0: phases->map, 1: map->phases, 2: phases -> *mul -> phases (in place)
 void launch_ring(int mode, const RingDev* rings, const int* cls, int ncls, int log2M, double* ph,
-                 int64_t ph_stride, int64_t npair_pad, double* map, int64_t map_stride, const double* const* mul,
+                 int64_t ph_stride, int64_t prow /* rows (m) per pair of the phase layout */, double* map, int64_t map_stride, const double* const* mul,
                  int weighted, const cd* tw, int log2Mmax, const cd* chirp, cd* scratch, int64_t scratch_map_stride,
                  int scratch_line, int nmaps, hipStream_t s, const cd* that = nullptr, int64_t that_stride = 0);
 // multiplier spectra of the Toeplitz pairs in cls (class log2M = their circulant size) from t_d in phase layout
 void launch_ring_toeplitz_spec(const RingDev* rings, const int* cls, int ncls, int log2M, const double* td,
-                               int64_t npair_pad, cd* that, const cd* tw, int log2Mmax, hipStream_t s);
+                               int64_t prow, cd* that, const cd* tw, int log2Mmax, hipStream_t s);
 void launch_alm_to_stream(const double* alm, int64_t alm_stride, double* ast, const double* cnorm, int lmax,
                           int nmaps, hipStream_t s);
 // lwtab (optional): [(lmax+1) * nchunk] first l written for (m, chunk) -- entries below it are structurally zero and

@@ -38,6 +38,12 @@ CMDR_HD int64_t d_packed_index(int lmax, int l, int m) {
     return 2 * ((int64_t)m * (lmax + 1) - (int64_t)m * (m - 1) / 2) - (lmax + 1) + 2 * (l - m);
 }
 
+// Phase arrays  F_m(ring pair) = (N.re, N.im, S.re, S.im), layout [map][pair][m][4]: the m of one ring pair are contiguous,
+// so the ring stage -- whose time goes into loading and storing exactly these entries -- streams 32 (m_max + 1) bytes per
+// pair fully coalesced.  The Legendre kernels (lane = pair) touch them once per task with a stride of one row per lane;
+// they are compute-bound and hide that.  prow = rows per pair (lmax + 1; 2 m_max + 1 rows in the Toeplitz setup array).
+CMDR_HD int64_t d_phidx(int64_t prow, int64_t pair, int m) { return (pair * prow + m) * 4; }
+
 struct LegArgs {
     int lmax;
     int npair_pad;
@@ -55,7 +61,7 @@ struct LegArgs {
 // The recursion (2 fp64 ops per l) is shared by the NB maps, each map adds 2 FMAs per l.
 //   ast : coefficient stream, complex, padded-triangle layout, maps interleaved: ast[((t*nbs)+k)*2 + {re,im}],
 //         already multiplied by cnorm etc.;  k0 = first map of this launch slice
-//   ph  : phase arrays [map][(lmax+1)][npair_pad][4] = (N.re, N.im, S.re, S.im)
+//   ph  : phase arrays [map][npair_pad][lmax+1][4] = (N.re, N.im, S.re, S.im)  (d_phidx)
 template <int R, int NB>
 CMDR_HD void leg_synth_lane(const LegArgs& A, const double* __restrict__ ast, int nbs, int k0,
                             double* __restrict__ ph, int64_t ph_stride, int m, int chunk, int lw, int lAend,
@@ -164,7 +170,7 @@ CMDR_HD void leg_synth_lane(const LegArgs& A, const double* __restrict__ ast, in
         const int p = base + r * 64;
 #pragma unroll
         for (int k = 0; k < NB; ++k) {
-            double* o = ph + (k0 + k) * ph_stride + ((int64_t)m * A.npair_pad + p) * 4;
+            double* o = ph + (k0 + k) * ph_stride + d_phidx(A.lmax + 1, p, m);
             o[0] = Er[r][k] + Or[r][k];
             o[1] = Ei[r][k] + Oi[r][k];
             o[2] = Er[r][k] - Or[r][k];
@@ -198,7 +204,7 @@ CMDR_HD void leg_adj_load(const LegArgs& A, const double* __restrict__ ph, int64
         S.mc[r] = S.mp[r] = 0.0;
 #pragma unroll
         for (int k = 0; k < NB; ++k) {
-            const double* g = ph + (k0 + k) * ph_stride + idx * 4;
+            const double* g = ph + (k0 + k) * ph_stride + d_phidx(A.lmax + 1, p, m);
             const double nr = g[0], ni = g[1], sr = g[2], si = g[3];
             S.Ger[r][k] = nr + sr;
             S.Gei[r][k] = ni + si;
@@ -357,7 +363,7 @@ CMDR_HD void leg2_synth_lane(const Leg2Args& A, const double* __restrict__ st, i
         for (int q = 0; q < 2; ++q) {
             const double kr = swap ? ar[r][2 * q + 1] : ar[r][2 * q], ki = swap ? ai[r][2 * q + 1] : ai[r][2 * q];
             const double fr = swap ? ar[r][2 * q] : ar[r][2 * q + 1], fi = swap ? ai[r][2 * q] : ai[r][2 * q + 1];
-            double* o = ph + (kq + q) * ph_stride + ((int64_t)m * A.npair_pad + p) * 4;
+            double* o = ph + (kq + q) * ph_stride + d_phidx(A.lmax + 1, p, m);
             o[0] = kr + fr;
             o[1] = ki + fi;
             o[2] = kr - fr;
@@ -380,9 +386,9 @@ CMDR_HD void leg2_adj_load(const Leg2Args& A, const double* __restrict__ ph, int
     const int base = chunk * 64 * R + lane;
 #pragma unroll
     for (int r = 0; r < R; ++r) {
-        const int64_t idx = (int64_t)m * A.npair_pad + base + r * 64;
-        const double* q = ph + kq * ph_stride + idx * 4;
-        const double* u = ph + (kq + 1) * ph_stride + idx * 4;
+        const int64_t idx = d_phidx(A.lmax + 1, base + r * 64, m);
+        const double* q = ph + kq * ph_stride + idx;
+        const double* u = ph + (kq + 1) * ph_stride + idx;
         // "keep" pairs with (N + S), "flip" with (N - S); for odd first-of-pair parity the roles swap
         const double qpr = q[0] + q[2], qpi = q[1] + q[3], qmr = q[0] - q[2], qmi = q[1] - q[3];
         const double upr = u[0] + u[2], upi = u[1] + u[3], umr = u[0] - u[2], umi = u[1] - u[3];
@@ -473,6 +479,7 @@ struct FftCtx {
     const cd* tw_hi = nullptr;
     const cd* tw_lo = nullptr;
     int tw_s = 0;
+    int dbg = 0;     // timing experiments only (CMDR_RING_DEBUG_SKIP): 1 no phase loads, 2 no synthesis FFT, 4 no analysis FFT, 8 no stores
 };
 CMDR_HD cd fft_tw(const cd* __restrict__ tw, const FftCtx& c, int k) {
     if (!c.tw_hi) return tw[k];
@@ -651,18 +658,18 @@ struct RingDev {  // device mirror of RingPairDesc
 //
 // Packed spectrum slot j of a ring pair from its phases (gather form, no atomics):
 //   Z_j = X^N_j + i X^S_j ,  X_j = rot_j [ sum_k s^k F_{j+kn} + sum_{k>=1} s^k conj F_{kn-j} ],  s = -1 (or +1)
-CMDR_HD cd ring_gather_slot(const double* __restrict__ ph, int64_t npair_pad, int pair, int n, int mmax, cd rot,
+CMDR_HD cd ring_gather_slot(const double* __restrict__ ph, int64_t prow, int pair, int n, int mmax, cd rot,
                             bool flip, int j) {
     double nr = 0.0, ni = 0.0, sr = 0.0, si = 0.0;
     double sg = 1.0;
     for (int m = j; m <= mmax; m += n) {  // direct aliases
-        const double* f = ph + ((int64_t)m * npair_pad + pair) * 4;
+        const double* f = ph + d_phidx(prow, pair, m);
         nr += sg * f[0]; ni += sg * f[1]; sr += sg * f[2]; si += sg * f[3];
         if (flip) sg = -sg;
     }
     sg = flip ? -1.0 : 1.0;
     for (int m = (j == 0 ? n : n - j); m <= mmax; m += n) {  // conjugate aliases (m > 0)
-        const double* f = ph + ((int64_t)m * npair_pad + pair) * 4;
+        const double* f = ph + d_phidx(prow, pair, m);
         nr += sg * f[0]; ni -= sg * f[1]; sr += sg * f[2]; si -= sg * f[3];
         if (flip) sg = -sg;
     }
@@ -675,7 +682,7 @@ CMDR_HD cd ring_gather_slot(const double* __restrict__ ph, int64_t npair_pad, in
 // independent (unrolled) global loads instead of a dependent gather per slot.
 //   BLUE: slot value is conj(Z_j w_j) at natural position (Bluestein input); else Z_j at the bit-reversed position.
 template <bool BLUE>
-CMDR_HD void ring_scatter(cd* buf, const RingDev& d, const double* __restrict__ ph, int64_t npair_pad, int pair,
+CMDR_HD void ring_scatter(cd* buf, const RingDev& d, const double* __restrict__ ph, int64_t prow, int pair,
                           const cd* __restrict__ rot, const cd* __restrict__ w, FftCtx c) {
     const int n = d.nphi, M = 1 << d.log2M, mmax = d.mmax_eff;
     const bool flip = d.phi0 != 0.0;
@@ -689,7 +696,7 @@ CMDR_HD void ring_scatter(cd* buf, const RingDev& d, const double* __restrict__ 
 #pragma unroll
         for (int u = 0; u < U; ++u) {
             const int m = m0 + u * c.nthr;
-            const double* q = ph + ((int64_t)(m <= mmax ? m : mmax) * npair_pad + pair) * 4;
+            const double* q = ph + d_phidx(prow, pair, m <= mmax ? m : mmax);
             f[u][0] = q[0]; f[u][1] = q[1]; f[u][2] = q[2]; f[u][3] = q[3];
         }
 #pragma unroll
@@ -783,7 +790,7 @@ struct PixelPost {           // (y_N, y_S) -> conj(mul_N y_N, mul_S y_S); no sou
     const double* __restrict__ b;
     CMDR_HD cd operator()(int k, cd z) const { return {z.x * a[k], b ? -(z.y * b[k]) : 0.0}; }
 };
-CMDR_HD void ring_synth_lds(cd* buf, const RingDev& d, const double* __restrict__ ph, int64_t npair_pad, int pair,
+CMDR_HD void ring_synth_lds(cd* buf, const RingDev& d, const double* __restrict__ ph, int64_t prow, int pair,
                             const cd* __restrict__ tw, int log2Mmax, const cd* __restrict__ chirp, FftCtx c,
                             bool fuse_mul = false, const double* __restrict__ mulN = nullptr,
                             const double* __restrict__ mulS = nullptr) {
@@ -792,13 +799,13 @@ CMDR_HD void ring_synth_lds(cd* buf, const RingDev& d, const double* __restrict_
     const cd* rot = chirp + d.chirp_off;   // rot_j, j < n
     const FftSub f = ring_fft_desc(d, chirp);
     if (n > 2 * d.mmax_eff) {
-        if (d.bluestein) ring_scatter<true>(buf, d, ph, npair_pad, pair, rot, f.w, c);
-        else ring_scatter<false>(buf, d, ph, npair_pad, pair, rot, nullptr, c);
+        if (d.bluestein) ring_scatter<true>(buf, d, ph, prow, pair, rot, f.w, c);
+        else ring_scatter<false>(buf, d, ph, prow, pair, rot, nullptr, c);
     } else {
         for (int j = c.tid; j < (d.bluestein ? M : n); j += c.nthr) {
             if (j < n) {
                 const cd r = flip ? rot[j] : cd{1.0, 0.0};
-                idft_put(buf, f, j, ring_gather_slot(ph, npair_pad, pair, n, d.mmax_eff, r, flip, j));
+                idft_put(buf, f, j, ring_gather_slot(ph, prow, pair, n, d.mmax_eff, r, flip, j));
             } else {
                 buf[lds_pad(j)] = {0.0, 0.0};
             }
@@ -813,7 +820,7 @@ CMDR_HD void ring_synth_lds(cd* buf, const RingDev& d, const double* __restrict_
 // adjoint Legendre stage: X^N_j = (Z_j + conj Z_{n-j})/2, X^S_j = (Z_j - conj Z_{n-j})/(2i);
 // G_{j+kn} = X_j e^{-i m phi0} = X_j s^k conj(rot_j).
 template <class Spec>
-CMDR_HD void ring_store_phases(const Spec& spec, const RingDev& d, double* __restrict__ ph, int64_t npair_pad,
+CMDR_HD void ring_store_phases(const Spec& spec, const RingDev& d, double* __restrict__ ph, int64_t prow,
                                int pair, const cd* __restrict__ chirp, FftCtx c) {
     const int n = d.nphi;
     const bool flip = d.phi0 != 0.0;
@@ -827,7 +834,7 @@ CMDR_HD void ring_store_phases(const Spec& spec, const RingDev& d, double* __res
         const cd e = flip ? cconj(rot[j]) : cd{1.0, 0.0};
         cd gn = cmul(xn, e), gs = cmul(xs, e);
         for (int m = j; m <= d.mmax_eff; m += n) {
-            double* o = ph + ((int64_t)m * npair_pad + pair) * 4;
+            double* o = ph + d_phidx(prow, pair, m);
             o[0] = gn.x; o[1] = gn.y; o[2] = gs.x; o[3] = gs.y;
             if (flip) { gn.x = -gn.x; gn.y = -gn.y; gs.x = -gs.x; gs.y = -gs.y; }
         }
@@ -868,12 +875,12 @@ struct SpecSplit {
     }
 };
 
-CMDR_HD cd ring_split_input(const double* __restrict__ ph, int64_t npair_pad, int pair, const RingDev& d,
+CMDR_HD cd ring_split_input(const double* __restrict__ ph, int64_t prow, int pair, const RingDev& d,
                             const cd* __restrict__ rot, bool flip, int k1, int j2) {
     const int n = d.nphi, h = n >> 1;
     const cd one = {1.0, 0.0};
-    const cd a = ring_gather_slot(ph, npair_pad, pair, n, d.mmax_eff, flip ? rot[j2] : one, flip, j2);
-    const cd b = ring_gather_slot(ph, npair_pad, pair, n, d.mmax_eff, flip ? rot[h + j2] : one, flip, h + j2);
+    const cd a = ring_gather_slot(ph, prow, pair, n, d.mmax_eff, flip ? rot[j2] : one, flip, j2);
+    const cd b = ring_gather_slot(ph, prow, pair, n, d.mmax_eff, flip ? rot[h + j2] : one, flip, h + j2);
     if (k1 == 0) return cadd(a, b);
     return cmul(csub(a, b), rot[2 * j2]);
 }
@@ -888,7 +895,7 @@ CMDR_HD cd ring_split_input(const double* __restrict__ ph, int64_t npair_pad, in
 // spectrum  tau(k) / M = (1/M) sum_d t_d e^{2 pi i d k / M}  (real), built once per multiplier map by
 // ring_toeplitz_spec from t_d (= the mode-1 transform of the multiplier map itself, run up to 2 mmax).
 // North and south ring share one complex FFT exactly as in the pixel form (real part north, imaginary part south).
-CMDR_HD void ring_toeplitz_load(cd* buf, int lg, int mmax, const double* __restrict__ ph, int64_t npair_pad, int pair,
+CMDR_HD void ring_toeplitz_load(cd* buf, int lg, int mmax, const double* __restrict__ ph, int64_t prow, int pair,
                                 FftCtx c) {
     const int M = 1 << lg;
     for (int j = mmax + 1 + c.tid; j < M - mmax; j += c.nthr) buf[lds_pad(d_bitrev(j, lg))] = {0.0, 0.0};
@@ -898,7 +905,7 @@ CMDR_HD void ring_toeplitz_load(cd* buf, int lg, int mmax, const double* __restr
 #pragma unroll
         for (int u = 0; u < U; ++u) {
             const int m = m0 + u * c.nthr;
-            const double* q = ph + ((int64_t)(m <= mmax ? m : mmax) * npair_pad + pair) * 4;
+            const double* q = ph + d_phidx(prow, pair, m <= mmax ? m : mmax);
             f[u][0] = q[0]; f[u][1] = q[1]; f[u][2] = q[2]; f[u][3] = q[3];
         }
 #pragma unroll
@@ -920,11 +927,11 @@ struct ToeplitzPost {
     }
 };
 // phases (in place) -> G = T F for one ring pair; that = this map's multiplier spectra
-CMDR_HD void ring_toeplitz_apply(cd* buf, const RingDev& d, double* __restrict__ ph, int64_t npair_pad, int pair,
+CMDR_HD void ring_toeplitz_apply(cd* buf, const RingDev& d, double* __restrict__ ph, int64_t prow, int pair,
                                  const cd* __restrict__ that, const cd* __restrict__ tw, int log2Mmax, FftCtx c) {
     const int lg = d.log2T, M = 1 << lg, mmax = d.mmax_eff;
     (void)M;
-    ring_toeplitz_load(buf, lg, mmax, ph, npair_pad, pair, c);
+    ring_toeplitz_load(buf, lg, mmax, ph, prow, pair, c);
     // x(k) = sum_j Z_j e^{+2 pi i jk/M}: (north, south) real signals; the multiplier spectrum rides on the last pass's
     // store, which leaves conj(tau(k) x(k)): the input form of the forward transform
     fft_dit_plus(buf, lg, tw, log2Mmax, c, ToeplitzPost{that + d.that_off});
@@ -932,17 +939,17 @@ CMDR_HD void ring_toeplitz_apply(cd* buf, const RingDev& d, double* __restrict__
     for (int j = c.tid; j <= mmax; j += c.nthr) {
         const cd a = cconj(buf[lds_pad(d_bitrev(j, lg))]);
         const cd b = buf[lds_pad(d_bitrev(j == 0 ? 0 : M - j, lg))];   // conj(Y_{M-j})
-        double* o = ph + ((int64_t)j * npair_pad + pair) * 4;
+        double* o = ph + d_phidx(prow, pair, j);
         o[0] = 0.5 * (a.x + b.x); o[1] = 0.5 * (a.y + b.y);           // G^N_j = (Y_j + conj Y_{M-j}) / 2
         o[2] = 0.5 * (a.y - b.y); o[3] = -0.5 * (a.x - b.x);          // G^S_j = (Y_j - conj Y_{M-j}) / (2i)
     }
 }
 
 // multiplier spectrum of one ring pair: td = phase-layout array holding t_d (north, south) for d <= 2 mmax
-CMDR_HD void ring_toeplitz_spec(cd* buf, const RingDev& d, const double* __restrict__ td, int64_t npair_pad, int pair,
+CMDR_HD void ring_toeplitz_spec(cd* buf, const RingDev& d, const double* __restrict__ td, int64_t prow, int pair,
                                 cd* __restrict__ that, const cd* __restrict__ tw, int log2Mmax, FftCtx c) {
     const int lg = d.log2T, M = 1 << lg;
-    ring_toeplitz_load(buf, lg, 2 * d.mmax_eff, td, npair_pad, pair, c);
+    ring_toeplitz_load(buf, lg, 2 * d.mmax_eff, td, prow, pair, c);
     fft_dit_plus(buf, lg, tw, log2Mmax, c);                       // tau^N(k) + i tau^S(k), both real
     const double inv = 1.0 / (double)M;
     cd* __restrict__ T = that + d.that_off;
@@ -991,12 +998,12 @@ CMDR_HD void ring_pixels(cd* buf, const FftSub& f, int npix, int k1, int kstep, 
 }
 
 template <int MODE>
-CMDR_HD void ring_block(cd* buf, const RingDev& d, int pair, double* __restrict__ php, int64_t npair_pad,
+CMDR_HD void ring_block(cd* buf, const RingDev& d, int pair, double* __restrict__ php, int64_t prow,
                         double* __restrict__ mp, const double* __restrict__ mu, double wg,
                         const cd* __restrict__ tw, int log2Mmax, const cd* __restrict__ chirp,
                         cd* __restrict__ scratch, FftCtx c, const cd* __restrict__ that = nullptr) {
     if (MODE == 2 && that && d.log2T) {
-        ring_toeplitz_apply(buf, d, php, npair_pad, pair, that, tw, log2Mmax, c);
+        ring_toeplitz_apply(buf, d, php, prow, pair, that, tw, log2Mmax, c);
         return;
     }
     const int n = d.nphi;
@@ -1005,17 +1012,19 @@ CMDR_HD void ring_block(cd* buf, const RingDev& d, int pair, double* __restrict_
         if (MODE == 2 && !d.bluestein) {
             // power-of-two ring of the fused pass: the pixel multiplier (and the conjugation the forward transform
             // wants) ride on the last synthesis pass's store; no separate pixel pass
-            ring_synth_lds(buf, d, php, npair_pad, pair, tw, log2Mmax, chirp, c, true, mu + d.startN,
-                           d.startS >= 0 ? mu + d.startS : nullptr);
-            dft_core(buf, f, tw, log2Mmax, c);
-            ring_store_phases(SpecDirect{buf, f}, d, php, npair_pad, pair, chirp, c);
+            if (!(c.dbg & 3))
+                ring_synth_lds(buf, d, php, prow, pair, tw, log2Mmax, chirp, c, true, mu + d.startN,
+                               d.startS >= 0 ? mu + d.startS : nullptr);
+            else if (!(c.dbg & 2)) fft_dit_plus(buf, f.log2M, tw, log2Mmax, c, PixelPost{mu + d.startN, d.startS >= 0 ? mu + d.startS : nullptr});
+            if (!(c.dbg & 4)) dft_core(buf, f, tw, log2Mmax, c);
+            if (!(c.dbg & 8)) ring_store_phases(SpecDirect{buf, f}, d, php, prow, pair, chirp, c);
             return;
         }
-        if (MODE == 0 || MODE == 2) ring_synth_lds(buf, d, php, npair_pad, pair, tw, log2Mmax, chirp, c);
+        if (MODE == 0 || MODE == 2) ring_synth_lds(buf, d, php, prow, pair, tw, log2Mmax, chirp, c);
         ring_pixels<MODE>(buf, f, n, 0, 1, d, mp, mu, wg, c);
         if (MODE == 0) return;
         dft_core(buf, f, tw, log2Mmax, c);
-        ring_store_phases(SpecDirect{buf, f}, d, php, npair_pad, pair, chirp, c);
+        ring_store_phases(SpecDirect{buf, f}, d, php, prow, pair, chirp, c);
         return;
     }
     const int h = n >> 1, M = 1 << d.log2M;
@@ -1024,7 +1033,7 @@ CMDR_HD void ring_block(cd* buf, const RingDev& d, int pair, double* __restrict_
     for (int k1 = 0; k1 < 2; ++k1) {
         if (MODE == 0 || MODE == 2) {
             for (int j = c.tid; j < (f.bluestein ? M : h); j += c.nthr) {
-                if (j < h) idft_put(buf, f, j, ring_split_input(php, npair_pad, pair, d, rot, flip, k1, j));
+                if (j < h) idft_put(buf, f, j, ring_split_input(php, prow, pair, d, rot, flip, k1, j));
                 else buf[lds_pad(j)] = {0.0, 0.0};
             }
             CMDR_BLOCK_SYNC();
@@ -1041,7 +1050,7 @@ CMDR_HD void ring_block(cd* buf, const RingDev& d, int pair, double* __restrict_
             CMDR_BLOCK_SYNC();
         }
     }
-    ring_store_phases(SpecSplit{buf, f, scratch, rot, n}, d, php, npair_pad, pair, chirp, c);
+    ring_store_phases(SpecSplit{buf, f, scratch, rot, n}, d, php, prow, pair, chirp, c);
 }
 
 // ---------------------------------------------------------------------------------------------------------

@@ -137,7 +137,7 @@ void ShtPlan::rings(int mode, double* d_map, int64_t map_stride, const double* c
     for (size_t c = 0; c < cls.size(); ++c) {
         if (!ncls[c]) continue;
         launch_ring(mode, rings_.get(), cls[c].get(), ncls[c], (int)c, ph_.get(), leg_.ph_elems(),
-                    leg_.npair_pad, d_map, map_stride, d_mul, weighted ? 1 : 0,
+                    T_.lmax + 1, d_map, map_stride, d_mul, weighted ? 1 : 0,
                     reinterpret_cast<const cd*>(tw_.get()), T_.ring.log2Mmax,
                     reinterpret_cast<const cd*>(chirp_.get()), reinterpret_cast<cd*>(ring_scratch_.get()),
                     (int64_t)T_.ring.nsplit * T_.ring.split_line, T_.ring.split_line, nmaps, s, tz ? that : nullptr,
@@ -158,12 +158,12 @@ void ShtPlan::toeplitz_build(const std::vector<const double*>& mul_host, DevBuf<
     for (size_t k = 0; k < mul_host.size(); ++k) {
         for (size_t c = 0; c < cls_tb_.size(); ++c)
             if (ncls_tb_[c])
-                launch_ring(1, rings_t2_.get(), cls_tb_[c].get(), ncls_tb_[c], (int)c, td.get(), 0, leg_.npair_pad,
+                launch_ring(1, rings_t2_.get(), cls_tb_[c].get(), ncls_tb_[c], (int)c, td.get(), 0, rows,
                             const_cast<double*>(mul_host[k]), 0, nullptr, 0, tw, T_.ring.log2Mmax,
                             reinterpret_cast<const cd*>(chirp_.get()), nullptr, 0, 0, 1, s);
         for (size_t c = 0; c < cls_ts_.size(); ++c)
             if (ncls_ts_[c])
-                launch_ring_toeplitz_spec(rings_.get(), cls_ts_[c].get(), ncls_ts_[c], (int)c, td.get(), leg_.npair_pad,
+                launch_ring_toeplitz_spec(rings_.get(), cls_ts_[c].get(), ncls_ts_[c], (int)c, td.get(), rows,
                                           out.get() + (int64_t)k * ne, tw, T_.ring.log2Mmax, s);
     }
     CMDR_HIP_CHECK(hipStreamSynchronize(s));   // td is released on return
@@ -179,7 +179,7 @@ void ShtPlan::rings_fused_range(int k0, int n, const double* const* d_mul, hipSt
     for (size_t c = 0; c < cls_.size(); ++c) {
         if (!ncls_[c]) continue;
         launch_ring(2, rings_.get(), cls_[c].get(), ncls_[c], (int)c, ph_.get() + (int64_t)k0 * leg_.ph_elems(),
-                    leg_.ph_elems(), leg_.npair_pad, nullptr, 0, d_mul + k0, 0,
+                    leg_.ph_elems(), T_.lmax + 1, nullptr, 0, d_mul + k0, 0,
                     reinterpret_cast<const cd*>(tw_.get()), T_.ring.log2Mmax,
                     reinterpret_cast<const cd*>(chirp_.get()),
                     reinterpret_cast<cd*>(ring_scratch_.get()) + (int64_t)k0 * sms, sms, T_.ring.split_line, n, s);

@@ -190,7 +190,7 @@ void launch_part2_to_alm(const double* part, int64_t part_pol_stride, int64_t pc
 }
 
 void launch_ring(int mode, const RingDev* rings, const int* cls, int ncls, int log2M, double* ph,
-                 int64_t ph_stride, int64_t npair_pad, double* map, int64_t map_stride, const double* const* mul,
+                 int64_t ph_stride, int64_t prow /* rows (m) per pair of the phase layout */, double* map, int64_t map_stride, const double* const* mul,
                  int weighted, const cd* tw, int log2Mmax, const cd* chirp, cd* scratch, int64_t scratch_map_stride,
                  int scratch_line, int nmaps, hipStream_t, const cd* that, int64_t that_stride) {
     std::vector<cd> bufv((size_t)lds_elems(log2M));
@@ -205,19 +205,19 @@ void launch_ring(int mode, const RingDev* rings, const int* cls, int ncls, int l
             const double* mu = mul ? mul[imap] : nullptr;
             const double wg = weighted ? d.wgt : 1.0;
             cd* sc = d.split ? scratch + imap * scratch_map_stride + (int64_t)(d.split - 1) * scratch_line : nullptr;
-            if (mode == 0) ring_block<0>(buf, d, pair, php, npair_pad, mp, mu, wg, tw, log2Mmax, chirp, sc, c);
-            else if (mode == 1) ring_block<1>(buf, d, pair, php, npair_pad, mp, mu, wg, tw, log2Mmax, chirp, sc, c);
-            else ring_block<2>(buf, d, pair, php, npair_pad, mp, mu, wg, tw, log2Mmax, chirp, sc, c,
+            if (mode == 0) ring_block<0>(buf, d, pair, php, prow, mp, mu, wg, tw, log2Mmax, chirp, sc, c);
+            else if (mode == 1) ring_block<1>(buf, d, pair, php, prow, mp, mu, wg, tw, log2Mmax, chirp, sc, c);
+            else ring_block<2>(buf, d, pair, php, prow, mp, mu, wg, tw, log2Mmax, chirp, sc, c,
                                that ? that + imap * that_stride : nullptr);
         }
 }
 
 void launch_ring_toeplitz_spec(const RingDev* rings, const int* cls, int ncls, int log2M, const double* td,
-                               int64_t npair_pad, cd* that, const cd* tw, int log2Mmax, hipStream_t) {
+                               int64_t prow, cd* that, const cd* tw, int log2Mmax, hipStream_t) {
     std::vector<cd> bufv((size_t)lds_elems(log2M));
     for (int ib = 0; ib < ncls; ++ib) {
         const int pair = cls[ib];
-        ring_toeplitz_spec(bufv.data(), rings[pair], td, npair_pad, pair, that, tw, log2Mmax, FftCtx{0, 1});
+        ring_toeplitz_spec(bufv.data(), rings[pair], td, prow, pair, that, tw, log2Mmax, FftCtx{0, 1});
     }
 }
 
@@ -294,7 +294,7 @@ void launch_precond_diag(const CompDev* comps, int ncomp, const double* P, int l
 void launch_fill_gl(double* ph, const double* wn, const double* ws, int npair_pad, int lmax, hipStream_t) {
     for (int m = 0; m <= lmax; ++m)
         for (int p = 0; p < npair_pad; ++p) {
-            double* o = ph + ((int64_t)m * npair_pad + p) * 4;
+            double* o = ph + d_phidx(lmax + 1, p, m);
             o[0] = wn[p]; o[1] = 0.0; o[2] = ws[p]; o[3] = 0.0;
         }
 }
