@@ -528,7 +528,8 @@ CMDR_HD cd rot_const(cd v, int jl) {   // v * exp(2 pi i jl / 2^(T+1)), jl < 2^T
 // post (last pass only): a pointwise step rides on the store that leaves the transform in natural order --
 // buf[i] = post(i, value) -- instead of costing its own LDS round trip and barrier
 struct NoPost {
-    CMDR_HD cd operator()(int, cd v) const { return v; }
+    CMDR_HD cd load(int) const { return {0.0, 0.0}; }
+    CMDR_HD cd apply(cd, cd v) const { return v; }
 };
 template <int K, class Post = NoPost>
 CMDR_HD void fft_dit_pass(cd* buf, int log2M, int hl, const cd* __restrict__ tw, int log2Mmax, FftCtx c,
@@ -543,7 +544,11 @@ CMDR_HD void fft_dit_pass(cd* buf, int log2M, int hl, const cd* __restrict__ tw,
         bt[K - 1] = fft_tw(tw, c, pos << (log2Mmax - (hl + K)));
 #pragma unroll
         for (int t = K - 1; t > 0; --t) bt[t - 1] = csqr(bt[t]);
-        cd v[N];
+        cd v[N], pre[N];
+        if (last) {   // the pointwise operands (global memory) are requested before the butterflies, used at the store
+#pragma unroll
+            for (int j = 0; j < N; ++j) pre[j] = post.load(i0 + (j << hl));
+        }
 #pragma unroll
         for (int j = 0; j < N; ++j) v[j] = buf[lds_pad(i0 + (j << hl))];
 #pragma unroll
@@ -560,7 +565,7 @@ CMDR_HD void fft_dit_pass(cd* buf, int log2M, int hl, const cd* __restrict__ tw,
         }
         if (last) {
 #pragma unroll
-            for (int j = 0; j < N; ++j) buf[lds_pad(i0 + (j << hl))] = post(i0 + (j << hl), v[j]);
+            for (int j = 0; j < N; ++j) buf[lds_pad(i0 + (j << hl))] = post.apply(pre[j], v[j]);
         } else {
 #pragma unroll
             for (int j = 0; j < N; ++j) buf[lds_pad(i0 + (j << hl))] = v[j];
@@ -788,7 +793,8 @@ CMDR_HD FftSub ring_fft_desc(const RingDev& d, const cd* __restrict__ chirp) {
 struct PixelPost {           // (y_N, y_S) -> conj(mul_N y_N, mul_S y_S); no southern ring: imaginary part 0
     const double* __restrict__ a;
     const double* __restrict__ b;
-    CMDR_HD cd operator()(int k, cd z) const { return {z.x * a[k], b ? -(z.y * b[k]) : 0.0}; }
+    CMDR_HD cd load(int k) const { return {a[k], b ? b[k] : 0.0}; }
+    CMDR_HD cd apply(cd m, cd z) const { return {z.x * m.x, -(z.y * m.y)}; }
 };
 CMDR_HD void ring_synth_lds(cd* buf, const RingDev& d, const double* __restrict__ ph, int64_t prow, int pair,
                             const cd* __restrict__ tw, int log2Mmax, const cd* __restrict__ chirp, FftCtx c,
@@ -921,10 +927,8 @@ CMDR_HD void ring_toeplitz_load(cd* buf, int lg, int mmax, const double* __restr
 
 struct ToeplitzPost {
     const cd* __restrict__ T;
-    CMDR_HD cd operator()(int k, cd z) const {
-        const cd t = T[k];
-        return {z.x * t.x, -(z.y * t.y)};
-    }
+    CMDR_HD cd load(int k) const { return T[k]; }
+    CMDR_HD cd apply(cd t, cd z) const { return {z.x * t.x, -(z.y * t.y)}; }
 };
 // phases (in place) -> G = T F for one ring pair; that = this map's multiplier spectra
 CMDR_HD void ring_toeplitz_apply(cd* buf, const RingDev& d, double* __restrict__ ph, int64_t prow, int pair,
