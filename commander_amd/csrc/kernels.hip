@@ -345,13 +345,12 @@ __global__ void __launch_bounds__(128) k_leg_adj_mx(LegArgs A, const WaveTask* _
     const bool on = mk < nb;
     double Be[2][16], Bo[2][16];
     {
-        const double* __restrict__ g0 = ph + (int64_t)(k0 + (on ? mk : 0)) * ph_stride + d_phidx(lmax + 1, pbase + kq, m) + reim;
-        const int64_t prow4 = 4 * (int64_t)(lmax + 1);
+        const double* __restrict__ g0 = ph + (int64_t)(k0 + (on ? mk : 0)) * ph_stride + reim;
 #pragma unroll
         for (int r = 0; r < 2; ++r)
 #pragma unroll
             for (int q = 0; q < 16; ++q) {
-                const double* g = g0 + (r * 64 + 4 * q) * prow4;
+                const double* g = g0 + d_phidx(lmax + 1, pbase + kq + r * 64 + 4 * q, m);
                 const double n = on ? g[0] : 0.0, s = on ? g[2] : 0.0;
                 Be[r][q] = n + s;
                 Bo[r][q] = n - s;

@@ -4,7 +4,7 @@ import os
 import subprocess
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-_SO = os.path.join(_HERE, "libcmdr_hip.so")
+_SO = os.environ.get("CMDR_LIB_PATH") or os.path.join(_HERE, "libcmdr_hip.so")   # CMDR_LIB_PATH: A/B builds (development)
 _LIB = None
 
 

@@ -99,3 +99,26 @@ def test_cfg4_matmulA_full_size_vs_oracle():
 def test_pseudoinv_with_toeplitz_rings_vs_oracle():
     from helpers import pinv_toeplitz_checks
     pinv_toeplitz_checks(None, nside=256, lmax=512)
+
+
+def test_ring_sharded_partial_matvecs_sum_to_the_full_one():
+    """What the 8 ranks of `bench.py --gpus 8` compute (ring pairs i = r mod 8, nine maps on 256 pairs each: the
+    matrix-unit adjoint with one chunk per m, the Toeplitz ring form on a shard), here one rank after the other on one
+    GPU: the partial vectors an all-reduce would sum add up to the single-GPU matvec."""
+    from commander_amd import synth, healpix
+    from commander_amd.cr import build_context
+    nside, P = 1024, 8
+    full = synth.make_problem("cfg3")
+    ctx = build_context(full)
+    x = np.random.default_rng(88).standard_normal(ctx.ncr)
+    y = ctx.cr_matmulA(x)
+    ctx.close()
+    acc = np.zeros_like(y)
+    for r in range(P):
+        rings = healpix.rank_rings(nside, r, P)
+        pix = healpix.local_pixels(nside, rings)
+        loc = synth.make_problem("cfg3", pixels=pix)
+        c = build_context(loc, rings_by_nside={nside: rings})
+        acc += c.cr_matmulA(x) - x          # each rank adds the unit prior term once
+        c.close()
+    assert rel(acc + x, y) < 1e-12
