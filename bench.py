@@ -240,7 +240,10 @@ def main():
     if world > 1:
         # band x ring-set hybrid: this rank owns lay["bands"] on ring set lay["ring_index"]
         if lay["ring_parts"] > 1:
-            rings = healpix.rank_rings(nside, lay["ring_index"], lay["ring_parts"])
+            # ring ownership: blocks of 64 adjacent pairs dealt back and forth (healpix.rank_rings: the lanes of a
+            # Legendre wave then hold neighbouring latitudes); CMDR_BENCH_RINGS=cyclic = Commander's own dealing
+            rings = healpix.rank_rings(nside, lay["ring_index"], lay["ring_parts"],
+                                       scheme=os.environ.get("CMDR_BENCH_RINGS", "block"))
             pixels = healpix.local_pixels(nside, rings)
         if lay["band_parts"] > 1:
             bands = lay["bands"]
@@ -440,6 +443,7 @@ def main():
                                    "amp-sample = cr_computeRHS + %d fixed PCG iterations, diagonal preconditioner"
                                    % (nband, nside, lmax, NITER),
                        "parallelism": par, "band_parts": lay["band_parts"], "ring_parts": lay["ring_parts"],
+                       "ring_ownership": (os.environ.get("CMDR_BENCH_RINGS", "block") if lay["ring_parts"] > 1 else None),
                        "ncr": ctx.ncr, "cg_iters_per_sec": args.steps * NITER / dt},
             "rccl_world_size": rccl_world, "collective": collective if dist is not None else None,
             "value_with_precond_refresh": (1.0 / dt_refresh) if dt_refresh else None,

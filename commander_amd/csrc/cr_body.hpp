@@ -56,6 +56,25 @@ CMDR_HD void sqrtS_elem(const CompDev& C, const double* __restrict__ smat, int k
 // Band stream entry: a~_bm(l,m) = cnorm * kappa_m * sum_c w[bm][c][l] * sx_{c, stokes(bm)}(l,m)
 //   w folds F_mean * b_l * mb_eff and both l-truncations (comm_cr_mod.f90:858-867,
 //   comm_diffuse_comp_mod.f90:2077-2089, comm_B_bl_mod.f90:108-127).
+// One real part (part 0 = re, 1 = im) of the coefficient-stream entry (l, m) of band map bm: the beam- and mixing-
+// weighted sum over the components, times the recursion normalisation.  Shared by k_band_prep (stream written to
+// memory) and the synthesis kernel's tile staging (stream never written: PrepDev).
+CMDR_HD double band_prep_part(const CompDev* __restrict__ comps, int ncomp, const double* __restrict__ sx,
+                              const double* __restrict__ w /* [ncomp][lmax_g+1] for this bm */, int stokes,
+                              const double* __restrict__ cnorm, int lmax_g, int m, int l, int part,
+                              const double* __restrict__ extra /* packed a_lm(lmax_g) added as is, or null */) {
+    if (l > lmax_g || (part && m == 0)) return 0.0;
+    double v = 0.0;
+    if (extra) v = extra[d_packed_index(lmax_g, l, m) + part];   // components with spatially varying mixing
+    for (int c = 0; c < ncomp; ++c) {
+        const CompDev C = comps[c];
+        if (l > C.lmax || stokes >= C.nmaps) continue;
+        const double wc = w[(int64_t)c * (lmax_g + 1) + l];
+        if (wc == 0.0) continue;
+        v += wc * sx[C.pos + (int64_t)stokes * C.nalm + d_packed_index(C.lmax, l, m) + part];
+    }
+    return v * (cnorm[d_moffp(lmax_g, m) + (l - m)] * (m == 0 ? 1.0 : 0.70710678118654752440));
+}
 CMDR_HD void band_prep_elem(const CompDev* __restrict__ comps, int ncomp, const double* __restrict__ sx,
                             const double* __restrict__ w /* [ncomp][lmax_g+1] for this bm */, int stokes,
                             double* __restrict__ ast_base, int nbs, int bm, const double* __restrict__ cnorm,
@@ -63,29 +82,20 @@ CMDR_HD void band_prep_elem(const CompDev* __restrict__ comps, int ncomp, const 
                             const double* __restrict__ extra = nullptr /* packed a_lm(lmax_g) added as is */) {
     const int64_t t = d_moffp(lmax_g, m) + (l - m);
     double* __restrict__ ast = ast_base + 2 * (t * nbs + bm) - 2 * t;  // maps interleaved: slot of (t, bm)
-    double re = 0.0, im = 0.0;
-    if (l <= lmax_g) {
-        if (extra) {   // band signal of the components with spatially varying mixing (already mixed and beam-convolved)
-            const int64_t i = d_packed_index(lmax_g, l, m);
-            re = extra[i];
-            if (m > 0) im = extra[i + 1];
-        }
-        for (int c = 0; c < ncomp; ++c) {
-            const CompDev C = comps[c];
-            if (l > C.lmax || stokes >= C.nmaps) continue;
-            const double wc = w[(int64_t)c * (lmax_g + 1) + l];
-            if (wc == 0.0) continue;
-            const int64_t i = C.pos + (int64_t)stokes * C.nalm + d_packed_index(C.lmax, l, m);
-            re += wc * sx[i];
-            if (m > 0) im += wc * sx[i + 1];
-        }
-        const double f = cnorm[t] * (m == 0 ? 1.0 : 0.70710678118654752440);
-        re *= f;
-        im *= f;
-    }
-    ast[2 * t] = re;
-    ast[2 * t + 1] = im;
+    ast[2 * t] = band_prep_part(comps, ncomp, sx, w, stokes, cnorm, lmax_g, m, l, 0, extra);
+    ast[2 * t + 1] = band_prep_part(comps, ncomp, sx, w, stokes, cnorm, lmax_g, m, l, 1, extra);
 }
+
+// Where the synthesis finds its coefficients when the stream is not materialised (launch_leg_synth, prep != null)
+struct PrepDev {
+    const CompDev* comps;
+    int ncomp;
+    const double* sx;        // S^1/2 x, stacked vector
+    const double* w;         // [nbm][ncomp][lmax+1]
+    const int* bm_stokes;    // [nbm]
+    const double* cnorm;     // padded-triangle normalisation of the plan
+    const double* extra;     // [nbm][(lmax+1)^2] or null
+};
 
 // Component entry of y_c: (+)= kappa'_m * sum_{bm in group} w[bm][c][l] cnorm[t] sum_chunks part[bm][chunk][t]
 //   (projectDiffuseBand, comm_diffuse_comp_mod.f90:2112-2167, and the truncation comm_cr_mod.f90:931-933).
@@ -335,4 +345,51 @@ CMDR_HD void precond_diag_elem(const CompDev* __restrict__ comps, int ncomp, con
     }
 }
 
+// ---- the PCG vector updates fused per (l, m) entry (solve_cr_eqn_by_CG, comm_cr_mod.f90:253-272); each routine handles
+// every slot of one (l, m) -- all components, Stokes blocks, re and im -- which is the granularity at which S^1/2 and
+// the diagonal preconditioner couple the stacked vector.  Used by k_cg_q / k_cg_xr / k_cg_d and the host emulation.
+template <class F>
+CMDR_HD void cg_for_slots(const CompDev* __restrict__ comps, int ncomp, int m, int l, F f) {
+    for (int c = 0; c < ncomp; ++c) {
+        const CompDev C = comps[c];
+        if (l > C.lmax) continue;
+        const int64_t i0 = C.pos + d_packed_index(C.lmax, l, m);
+        for (int a = 0; a < C.nmaps; ++a) {
+            f(i0 + a * C.nalm);
+            if (m > 0) f(i0 + a * C.nalm + 1);
+        }
+    }
+}
+// q = S^1/2 yc + d (the tail of cr_matmulA, :957-1008); returns this entry's share of d.q (:254)
+CMDR_HD double cg_q_elem(const CompDev* __restrict__ comps, int ncomp, const double* __restrict__ smat,
+                         const double* __restrict__ yc, const double* __restrict__ d, double* __restrict__ q, int m,
+                         int l) {
+    for (int c = 0; c < ncomp; ++c)
+        if (l <= comps[c].lmax) sqrtS_elem(comps[c], smat, 0, yc, d, q, m, l, false);
+    double acc = 0.0;
+    cg_for_slots(comps, ncomp, m, l, [&](int64_t i) { acc += d[i] * q[i]; });
+    return acc;
+}
+// x += alpha d ; r -= alpha q (:255-261) ; s = M^-1 r, diagonal type (:266) ; returns the share of r.s (:269)
+CMDR_HD double cg_xr_elem(const CompDev* __restrict__ comps, int ncomp, const double* __restrict__ P, int lmax_pre,
+                          int nmaps_pre, double alpha, double* __restrict__ x, double* r,
+                          const double* __restrict__ d, const double* __restrict__ q, double* s, int m, int l) {
+    cg_for_slots(comps, ncomp, m, l, [&](int64_t i) {
+        x[i] += alpha * d[i];
+        r[i] -= alpha * q[i];
+    });
+    precond_diag_elem(comps, ncomp, P, lmax_pre, nmaps_pre, r, s, m, l);
+    double acc = 0.0;
+    cg_for_slots(comps, ncomp, m, l, [&](int64_t i) { acc += r[i] * s[i]; });
+    return acc;
+}
+// d = s + beta d (:271-272) ; sx = S^1/2 d (the head of the next cr_matmulA, :792-836)
+CMDR_HD void cg_d_elem(const CompDev* __restrict__ comps, int ncomp, const double* __restrict__ smat, double beta,
+                       double* d, const double* __restrict__ s, double* __restrict__ sx, int m, int l) {
+    cg_for_slots(comps, ncomp, m, l, [&](int64_t i) { d[i] = s[i] + beta * d[i]; });
+    for (int c = 0; c < ncomp; ++c)
+        if (l <= comps[c].lmax) sqrtS_elem(comps[c], smat, 0, d, nullptr, sx, m, l, false);
+}
+
 }  // namespace cmdr
+

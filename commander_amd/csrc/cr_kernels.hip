@@ -243,6 +243,86 @@ void launch_dot(const double* a, const double* b, int64_t n, double* partial, do
 }
 int dot_partial_count() { return kDotBlocks; }
 
+// ---- fused PCG vector kernels (diagonal preconditioner, diffuse components only): 3 launches per iteration instead
+// of 10.  Fixed grid of kDotBlocks blocks striding over the (m, l - m) rectangle; the dot products leave kDotBlocks
+// partial sums that every block of the CONSUMING kernel folds itself, in one fixed order (same value in every block,
+// no atomics, no separate fold launch).
+__device__ inline double fold_partials(const double* __restrict__ partial) {
+    __shared__ double tot;
+    double acc = 0.0;
+    for (int i = threadIdx.x; i < kDotBlocks; i += 256) acc += partial[i];
+    const double r = block_sum_256(acc);
+    if (threadIdx.x == 0) tot = r;
+    __syncthreads();
+    return tot;
+}
+template <class F>
+__device__ inline void cg_stride(int lmax, F f) {
+    const int64_t n = (int64_t)(lmax + 1) * (lmax + 1);
+    for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < n; e += (int64_t)kDotBlocks * 256) {
+        const int m = (int)(e / (lmax + 1)), l = m + (int)(e - (int64_t)m * (lmax + 1));
+        if (l <= lmax) f(m, l);
+    }
+}
+__global__ void __launch_bounds__(256) k_cg_q(const CompDev* __restrict__ comps, int ncomp, int lmax,
+                                              const double* __restrict__ smat, const double* __restrict__ yc,
+                                              const double* __restrict__ d, double* __restrict__ q,
+                                              double* __restrict__ p_dq) {
+    double acc = 0.0;
+    cg_stride(lmax, [&](int m, int l) { acc += cg_q_elem(comps, ncomp, smat, yc, d, q, m, l); });
+    const double r = block_sum_256(acc);
+    if (threadIdx.x == 0) p_dq[blockIdx.x] = r;
+}
+__global__ void __launch_bounds__(256) k_cg_xr_precond(const CompDev* __restrict__ comps, int ncomp, int lmax,
+                                                       const double* __restrict__ P, int nmaps_pre,
+                                                       const double* __restrict__ p_dq,
+                                                       const double* __restrict__ p_rs_old, double* __restrict__ p_rs,
+                                                       double* __restrict__ x, double* r, const double* __restrict__ d,
+                                                       const double* __restrict__ q, double* s,
+                                                       double* __restrict__ scal) {
+    const double dq = fold_partials(p_dq);
+    const double alpha = fold_partials(p_rs_old) / dq;                                  // comm_cr_mod.f90:254
+    if (blockIdx.x == 0 && threadIdx.x == 0) scal[2] = dq;
+    double acc = 0.0;
+    cg_stride(lmax, [&](int m, int l) { acc += cg_xr_elem(comps, ncomp, P, lmax, nmaps_pre, alpha, x, r, d, q, s, m, l); });
+    const double t = block_sum_256(acc);
+    if (threadIdx.x == 0) p_rs[blockIdx.x] = t;
+}
+__global__ void __launch_bounds__(256) k_cg_d_sqrtS(const CompDev* __restrict__ comps, int ncomp, int lmax,
+                                                    const double* __restrict__ smat,
+                                                    const double* __restrict__ p_rs_old,
+                                                    const double* __restrict__ p_rs, double* d,
+                                                    const double* __restrict__ s, double* __restrict__ sx,
+                                                    double* __restrict__ scal) {
+    const double dold = fold_partials(p_rs_old), dnew = fold_partials(p_rs);
+    const double beta = dnew / dold;                                                    // :270-271
+    if (blockIdx.x == 0 && threadIdx.x == 0) { scal[0] = dnew; scal[1] = dold; }
+    cg_stride(lmax, [&](int m, int l) { cg_d_elem(comps, ncomp, smat, beta, d, s, sx, m, l); });
+}
+// p[0] = scal[slot], p[1..] = 0: a dot product computed by launch_dot enters the partial-sum protocol
+__global__ void k_cg_seed(const double* __restrict__ scal, int slot, double* __restrict__ p) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i < kDotBlocks) p[i] = i == 0 ? scal[slot] : 0.0;
+}
+void launch_cg_seed(const double* scal, int slot, double* p, hipStream_t s) {
+    hipLaunchKernelGGL(k_cg_seed, dim3(kDotBlocks / 256), dim3(256), 0, s, scal, slot, p);
+}
+void launch_cg_q(const CompDev* comps, int ncomp, int lmax, const double* smat, const double* yc, const double* d,
+                 double* q, double* p_dq, hipStream_t s) {
+    hipLaunchKernelGGL(k_cg_q, dim3(kDotBlocks), dim3(256), 0, s, comps, ncomp, lmax, smat, yc, d, q, p_dq);
+}
+void launch_cg_xr_precond(const CompDev* comps, int ncomp, int lmax, const double* P, int nmaps_pre, const double* p_dq,
+                          const double* p_rs_old, double* p_rs, double* x, double* r, const double* d, const double* q,
+                          double* sv, double* scal, hipStream_t s) {
+    hipLaunchKernelGGL(k_cg_xr_precond, dim3(kDotBlocks), dim3(256), 0, s, comps, ncomp, lmax, P, nmaps_pre, p_dq,
+                       p_rs_old, p_rs, x, r, d, q, sv, scal);
+}
+void launch_cg_d_sqrtS(const CompDev* comps, int ncomp, int lmax, const double* smat, const double* p_rs_old,
+                       const double* p_rs, double* d, const double* sv, double* sx, double* scal, hipStream_t s) {
+    hipLaunchKernelGGL(k_cg_d_sqrtS, dim3(kDotBlocks), dim3(256), 0, s, comps, ncomp, lmax, smat, p_rs_old, p_rs, d, sv, sx,
+                       scal);
+}
+
 // x += alpha d ; r -= alpha q ; alpha = scal[num] / scal[den]   (comm_cr_mod.f90:254-261)
 __global__ void k_cg_xr(double* __restrict__ x, double* __restrict__ r, const double* __restrict__ d,
                         const double* __restrict__ q, int64_t n, const double* __restrict__ scal, int num, int den) {

@@ -800,12 +800,17 @@ void CrSystem::adjoint_groups_to_yc(bool from_maps) {
     reduce(yc_.get(), ncr_);
 }
 
-void CrSystem::matmulA(const double* x, double* y) {
+void CrSystem::matmulA(const double* x, double* y) { matmulA_impl(x, y, false, true); }
+
+// sx_ready: sx_ already holds S^1/2 x (written by the fused PCG update of d).  finish = false: stop after the reduced
+// yc_ = sum_nu F^t B^t Y^t N^-1 Y B F sx; the caller forms S^1/2 yc + x itself (k_cg_q, fused with the d.q product).
+void CrSystem::matmulA_impl(const double* x, double* y, bool sx_ready, bool finish) {
     CMDR_REQUIRE(finalized_, "finalize first");
     const int ncomp = (int)comps_.size();
     span_begin(3);
     // sqrtS_x = S^1/2 x  (comm_cr_mod.f90:792-836)
-    launch_sqrtS(comps_dev_.get(), ncomp, lmax_max_, smat_.get(), 0, x, nullptr, sx_.get(), false, stream_);
+    if (!sx_ready)
+        launch_sqrtS(comps_dev_.get(), ncomp, lmax_max_, smat_.get(), 0, x, nullptr, sx_.get(), false, stream_);
     for (Compact& K : compacts_) {                                                   // pamp * P_cg(2)  :817-833
         if (K.active) launch_vec_scale(0, x + K.pos, K.sigma_dev.get(), nullptr, nullptr, sx_.get() + K.pos, K.nparam, stream_);
         CMDR_HIP_CHECK(hipMemsetAsync(yc_.get() + K.pos, 0, sizeof(double) * K.nparam, stream_));
@@ -815,8 +820,9 @@ void CrSystem::matmulA(const double* x, double* y) {
         const double* extra = nullptr;
         if (!G.mix.empty()) { mix_forward(G, sx_.get()); extra = G.E.get(); }            // varying mixing :2082-2084
         const double* wfwd = literal_quirks_ ? G.w_fwd.get() : G.w.get();
-        launch_band_prep(comps_dev_.get(), ncomp, sx_.get(), wfwd, G.bm_stokes_dev.get(), P.stream(),
-                         P.leg().cnorm.get(), G.lmax, G.nT, stream_, extra);
+        if (pipelined(G))   // the batches of the pipelined form read the stream
+            launch_band_prep(comps_dev_.get(), ncomp, sx_.get(), wfwd, G.bm_stokes_dev.get(), P.stream(),
+                             P.leg().cnorm.get(), G.lmax, G.nT, stream_, extra);
         if (G.npol)
             launch_band_prep2(comps_dev_.get(), ncomp, sx_.get(), wfwd, G.nT, P.stream2(), G.npol,
                               P.leg2().cnorm.get(), G.lmax, stream_, extra);
@@ -826,7 +832,7 @@ void CrSystem::matmulA(const double* x, double* y) {
             const int64_t np = P.npix_local();
             G.tmpmap.ensure((size_t)G.nbm * np);
             span_begin(0);
-            P.synth_from_stream(G.nT, stream_);
+            synth_T_of(G, sx_.get(), wfwd, extra);
             if (G.npol) P.synth2_from_stream(G.npol, G.nT, stream_);
             span_end();
             span_begin(1);
@@ -866,7 +872,7 @@ void CrSystem::matmulA(const double* x, double* y) {
             continue;
         }
         span_begin(0);
-        P.synth_from_stream(G.nT, stream_);                                          // Y        :891 (T: spin 0)
+        synth_T_of(G, sx_.get(), wfwd, extra);                                       // Y        :891 (T: spin 0)
         if (G.npol) P.synth2_from_stream(G.npol, G.nT, stream_);                     // (Q,U): spin 2, comm_map_mod.f90:446
         span_end();
         span_begin(1);
@@ -874,6 +880,7 @@ void CrSystem::matmulA(const double* x, double* y) {
         span_end();
     }
     adjoint_groups_to_yc(false);                                                     // Yt :915, projectBand :920-948
+    if (!finish) { span_end(); return; }
     // y = S^1/2 yc + x  (:957-1008)
     launch_sqrtS(comps_dev_.get(), ncomp, lmax_max_, smat_.get(), 0, yc_.get(), x, y, false, stream_);
     for (Compact& K : compacts_) {                                                   // :985-1003
@@ -897,6 +904,21 @@ void CrSystem::flip_active() {
 }
 
 // band signal maps of the components whose active flag is set, into G.tmpmap [nbm][npix_local]:
+// T maps of a plan: weighted component sum -> Legendre synthesis.  In the workgroup form the synthesis kernel forms
+// the coefficients while it stages its tiles (no stream written); otherwise k_band_prep writes the stream first.
+void CrSystem::synth_T_of(Group& G, const double* v, const double* w, const double* extra) {
+    ShtPlan& P = *G.plan;
+    const int ncomp = (int)comps_.size();
+    if (P.can_prep() && ncomp <= 8) {   // the kernel's term table holds 5 maps x 8 components
+        const PrepDev prep{comps_dev_.get(), ncomp, v, w, G.bm_stokes_dev.get(), P.leg().cnorm.get(), extra};
+        P.synth_from_prep(prep, G.nT, stream_);
+        return;
+    }
+    launch_band_prep(comps_dev_.get(), ncomp, v, w, G.bm_stokes_dev.get(), P.stream(), P.leg().cnorm.get(), G.lmax, G.nT,
+                     stream_, extra);
+    P.synth_from_stream(G.nT, stream_);
+}
+
 // Y sum_c getBand_c(alm) + pixel-space getBand of the compact ones; sx = amplitudes as they enter getBand
 void CrSystem::forward_maps(Group& G, const double* sx) {
     const int ncomp = (int)comps_.size();
@@ -904,13 +926,11 @@ void CrSystem::forward_maps(Group& G, const double* sx) {
     const int64_t np = P.npix_local();
     const double* extra = nullptr;
     if (!G.mix.empty()) { mix_forward(G, sx); extra = G.E.get(); }
-    launch_band_prep(comps_dev_.get(), ncomp, sx, G.w.get(), G.bm_stokes_dev.get(), P.stream(), P.leg().cnorm.get(),
-                     G.lmax, G.nT, stream_, extra);
     if (G.npol)
         launch_band_prep2(comps_dev_.get(), ncomp, sx, G.w.get(), G.nT, P.stream2(), G.npol, P.leg2().cnorm.get(), G.lmax,
                           stream_, extra);
     G.tmpmap.ensure((size_t)G.nbm * np);
-    P.synth_from_stream(G.nT, stream_);
+    synth_T_of(G, sx, G.w.get(), extra);
     if (G.npol) P.synth2_from_stream(G.npol, G.nT, stream_);
     P.rings(0, G.tmpmap.get(), np, nullptr, false, G.nbm, stream_);
     compact_forward(G, sx, G.tmpmap.get());
@@ -1551,12 +1571,10 @@ void CrSystem::apply_pseudoinv(const double* x, double* y) {
     for (int g = 0; g < (int)groups_.size(); ++g) {
         Group& G = groups_[g];
         ShtPlan& P = *G.plan;
-        launch_band_prep(comps_dev_.get(), ncomp, x, G.w_pin.get(), G.bm_stokes_dev.get(), P.stream(),
-                         P.leg().cnorm.get(), G.lmax, G.nT, stream_);                   // (U^+)^t   :2279-2291
         if (G.npol)
             launch_band_prep2(comps_dev_.get(), ncomp, x, G.w_pin.get(), G.nT, P.stream2(), G.npol,
                               P.leg2().cnorm.get(), G.lmax, stream_);
-        P.synth_from_stream(G.nT, stream_);                                              // WY        :2295
+        synth_T_of(G, x, G.w_pin.get(), nullptr);                                        // (U^+)^t :2279-2291, WY :2295
         if (G.npol) P.synth2_from_stream(G.npol, G.nT, stream_);
         P.rings(2, nullptr, 0, G.mulP_ptrs.get(), false, G.nbm, stream_, G.thatP.get());  // N         :2297
         P.adjoint_to_partials(G.nT, false, stream_);                                     // YtW       :2299
@@ -1624,6 +1642,26 @@ SolveResult CrSystem::solve(const double* b, double* x, int crit, double tol, in
     R.delta0 = h[3];
     const double lim = by_chisq ? tol : tol * h[3];                                     // :220-226
     double chisq = by_chisq ? chisq_of(x) : 0.0;
+    // Fused vector updates (3 launches per iteration: k_cg_q, k_cg_xr_precond, k_cg_d_sqrtS) when every entry of the
+    // stacked vector is a diffuse a_lm under the diagonal preconditioner; else the general sequence below.
+    const char* fuse_env = std::getenv("CMDR_CG_FUSED");                             // read per solve (test hook)
+    const bool fuse_on = !fuse_env || std::atoi(fuse_env) != 0;
+    bool lowl_on = false;
+    for (const LowL& W : lowl_) lowl_on = lowl_on || W.ready;
+    const bool fused = fuse_on && precond_type_ == 0 && compacts_.empty() && !lowl_on;
+    const int npart = dot_partial_count();
+    double* p_dq = nullptr;
+    double* p_rs[2] = {nullptr, nullptr};
+    bool sx_ready = false;
+    if (fused) {
+        cg_partials_.ensure((size_t)3 * npart);
+        p_dq = cg_partials_.get();
+        p_rs[0] = p_dq + npart;
+        p_rs[1] = p_dq + 2 * npart;
+        launch_cg_seed(scal, 0, p_rs[0], stream_);                                      // delta_new of :206
+        launch_sqrtS(comps_dev_.get(), ncomp, lmax_max_, smat_.get(), 0, d_.get(), nullptr, sx_.get(), false, stream_);
+        sx_ready = true;
+    }
     int i = 1;
     for (; i <= maxiter; ++i) {                                                         // :230
         if (i % check_freq == 0 && !fixed_iter) {                                       // :236-247
@@ -1631,10 +1669,22 @@ SolveResult CrSystem::solve(const double* b, double* x, int crit, double tol, in
             double val = h[0];
             if (by_chisq) {
                 const double prev = chisq;
-                chisq = chisq_of(x);
+                chisq = chisq_of(x);                                                    // uses sx_ for S^1/2 x
+                sx_ready = false;
                 val = std::fabs((prev - chisq) / chisq);
             }
             if (val < lim && (i >= miniter || h[0] <= 1e-30 * h[3])) break;
+        }
+        if (fused) {
+            matmulA_impl(d_.get(), nullptr, sx_ready, false);                           // :253, up to the reduced yc_
+            launch_cg_q(comps_dev_.get(), ncomp, lmax_max_, smat_.get(), yc_.get(), d_.get(), q_.get(), p_dq, stream_);
+            launch_cg_xr_precond(comps_dev_.get(), ncomp, lmax_max_, P_.get(), nmaps_pre_, p_dq, p_rs[(i - 1) & 1],
+                                 p_rs[i & 1], x, r_.get(), d_.get(), q_.get(), s_.get(), scal, stream_);   // :254-269
+            launch_cg_d_sqrtS(comps_dev_.get(), ncomp, lmax_max_, smat_.get(), p_rs[(i - 1) & 1], p_rs[i & 1], d_.get(),
+                              s_.get(), sx_.get(), scal, stream_);                      // :270-272 + head of the next A d
+            sx_ready = true;
+            R.niter = i;
+            continue;
         }
         matmulA(d_.get(), q_.get());                                                    // :253
         launch_dot(d_.get(), q_.get(), n, dot_partial_.get(), scal, 2, false, stream_); // :254

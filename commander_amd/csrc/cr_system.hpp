@@ -210,6 +210,8 @@ class CrSystem {
     DevBuf<double> qucov_tmp_, qucov_tmp2_;
     void rebuild_weights();
     void flip_active();
+    void matmulA_impl(const double* x, double* y, bool sx_ready, bool finish);
+    void synth_T_of(Group& G, const double* v, const double* w, const double* extra);
     void forward_maps(Group& G, const double* sx);
     double chisq_of(const double* x);
     std::vector<const double*> last_resid_;
@@ -253,6 +255,7 @@ class CrSystem {
     DevBuf<double> smat_;
     DevBuf<double> sx_, yc_, r_, d_, q_, s_, tmp_;
     DevBuf<double> dot_partial_, scal_;
+    DevBuf<double> cg_partials_;        // fused PCG kernels: [d.q | r.s even | r.s odd] x dot_partial_count()
     // diagonal preconditioner
     int lmax_pre_ = -1, nmaps_pre_ = 0;
     std::vector<double> M0_;                // [nmaps_pre][npre][npre][ntri(lmax_pre)]

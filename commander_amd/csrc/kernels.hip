@@ -40,10 +40,11 @@ __global__ void __launch_bounds__(256) k_leg_synth(LegArgs A, const WaveTask* __
 // staged through a double-buffered LDS tile of kTileL l values and read back as LDS broadcasts (uniform VGPR
 // operands): the scalar-cache miss bandwidth (~1.5 B/clk/CU, measured) that bounds k_leg_synth no longer enters.
 constexpr int kTileL = 32;
-template <int R, int NB>
-__global__ void __launch_bounds__(256) k_leg_synth_wg(LegArgs A, const WaveTask* __restrict__ tasks, int ntasks,
+// PREP: the coefficient stream is not read from memory but formed while the tile is staged (k_band_prep folded in)
+template <int R, int NB, bool PREP>
+__global__ void __launch_bounds__(256, 3) k_leg_synth_wg(LegArgs A, const WaveTask* __restrict__ tasks, int ntasks,
                                                       const double* __restrict__ ast, int nbs, int k0, int rep,
-                                                      double* __restrict__ ph, int64_t ph_stride) {
+                                                      double* __restrict__ ph, int64_t ph_stride, PrepDev P) {
     constexpr int ROW = 2 * NB + 2;                     // doubles per l: NB x (re, im), alpha_{l+1}, pad
     constexpr int NE = kTileL * ROW;                    // doubles per tile
     constexpr int NLD = (NE + 255) / 256;               // global loads per thread and tile
@@ -83,6 +84,27 @@ __global__ void __launch_bounds__(256) k_leg_synth_wg(LegArgs A, const WaveTask*
 #pragma unroll
         for (int k = 0; k < NB; ++k) Er[r][k] = Ei[r][k] = Or[r][k] = Oi[r][k] = 0.0;
     }
+    // PREP: per (map of this batch, component) where the component's (l = 0, m) entry sits in sx (the packed index is
+    // linear in l within one m), where its weight row starts, and up to which l it contributes
+    struct PrepTerm { long long sxo, wo; int lmaxc, pad; };
+    __shared__ PrepTerm terms[PREP ? 5 * 8 : 1];
+    const int sl = m == 0 ? 1 : 2;
+    const int64_t na = (int64_t)(lmax + 1) * (lmax + 1);
+    const int64_t gbase = d_packed_index(lmax, 0, m);
+    if (PREP) {
+        if ((int)threadIdx.x < NB * P.ncomp) {
+            const int k = threadIdx.x / P.ncomp, c = threadIdx.x - k * P.ncomp, bm = k0 + k;
+            const CompDev C = P.comps[c];
+            const int st = P.bm_stokes[bm];
+            PrepTerm T;
+            T.lmaxc = st < C.nmaps ? C.lmax : -1;
+            T.sxo = C.pos + (int64_t)st * C.nalm + d_packed_index(C.lmax, 0, m);
+            T.wo = ((int64_t)bm * P.ncomp + c) * (lmax + 1);
+            T.pad = 0;
+            terms[threadIdx.x] = T;
+        }
+        __syncthreads();
+    }
     // tile element e -> (row = l - lb, col): col < 2 NB: stream double, col == 2 NB: alpha_{l+1}
     auto fetch = [&](int lb, double* v) {
 #pragma unroll
@@ -92,8 +114,27 @@ __global__ void __launch_bounds__(256) k_leg_synth_wg(LegArgs A, const WaveTask*
             const int l = lb + row;
             double val = 0.0;
             if (e < NE && l <= lmax + 1) {
-                if (col < 2 * NB) val = as[ls2 * l + col];
-                else if (col == 2 * NB) val = al[l + 1];
+                if (col < 2 * NB) {
+                    if (PREP) {   // band_prep_part with the per-(map, component) constants from the LDS table
+                        const int k = col >> 1, part = col & 1;
+                        if (l <= lmax && !(part && m == 0)) {
+                            double v = 0.0;
+                            if (P.extra) v = P.extra[(int64_t)(k0 + k) * na + gbase + sl * l + part];
+                            for (int c = 0; c < P.ncomp; ++c) {
+                                const PrepTerm T = terms[k * P.ncomp + c];
+                                if (l > T.lmaxc) continue;
+                                const double wc = P.w[T.wo + l];
+                                const double t = P.sx[T.sxo + sl * l + part];
+                                if (wc != 0.0) v += wc * t;
+                            }
+                            val = v * (P.cnorm[mo - m + l] * (m == 0 ? 1.0 : 0.70710678118654752440));
+                        }
+                    } else {
+                        val = as[ls2 * l + col];
+                    }
+                } else if (col == 2 * NB) {
+                    val = al[l + 1];
+                }
             }
             v[i] = val;
         }
@@ -313,6 +354,12 @@ __device__ __forceinline__ void mx_recur(const double* __restrict__ al, int l0, 
     }
 }
 
+// NR sub-blocks of 64 ring pairs per wave, 2 waves per task: NR = 2 -> tasks of 256 pairs (plans with R = 4),
+// NR = 1 -> 128 pairs (R = 2: ring-sharded ranks with few pairs, where one task per m would leave the longest column,
+// m = 0, as the critical path of the launch).  The sub-blocks of a 256-pair task are dealt 0,3 | 1,2 to the two waves
+// (polar + equatorial against the two middle ones) and each wave skips the 32-l groups that lie below every start of
+// a sub-block, so the (m, ring) cut is honoured per 64 pairs, not per task.
+template <int NR>
 __global__ void __launch_bounds__(128) k_leg_adj_mx(LegArgs A, const WaveTask* __restrict__ tasks, int ntasks,
                                                     const double* __restrict__ ph, int64_t ph_stride, int k0, int nb,
                                                     double* __restrict__ part, int64_t part_map_stride,
@@ -328,29 +375,38 @@ __global__ void __launch_bounds__(128) k_leg_adj_mx(LegArgs A, const WaveTask* _
     const int lw = __builtin_amdgcn_readfirstlane(T.lw);
     const int lAend = __builtin_amdgcn_readfirstlane(T.lAend);
     const int lmax = A.lmax;
-    const int pbase = chunk * 256 + wid * 128;
-    double x[2], mc[2], mp[2], sc[2], sp[2];
-    int ls[2];
+    int pb[NR];                  // first pair of this wave's sub-blocks
 #pragma unroll
-    for (int r = 0; r < 2; ++r) {
-        const int p = pbase + r * 64 + lane;
+    for (int r = 0; r < NR; ++r) {
+        const int sub = NR == 1 ? wid : (wid == 0 ? 3 * r : 1 + r);
+        pb[r] = chunk * (128 * NR) + sub * 64;
+    }
+    double x[NR], mc[NR], mp[NR], sc[NR], sp[NR];
+    int ls[NR], lwr[NR];
+#pragma unroll
+    for (int r = 0; r < NR; ++r) {
+        const int p = pb[r] + lane;
         const int64_t idx = (int64_t)m * A.npair_pad + p;
         x[r] = A.x[p];
         ls[r] = A.ls[idx];
         sc[r] = A.seedc[idx];
         sp[r] = A.seedp[idx];
         mc[r] = mp[r] = 0.0;
+        int v = ls[r];
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) v = min(v, __shfl_xor(v, o));
+        lwr[r] = __builtin_amdgcn_readfirstlane(v);
     }
     const int kq = lane >> 4, col = lane & 15, mk = col >> 1, reim = col & 1;
     const bool on = mk < nb;
-    double Be[2][16], Bo[2][16];
+    double Be[NR][16], Bo[NR][16];
     {
         const double* __restrict__ g0 = ph + (int64_t)(k0 + (on ? mk : 0)) * ph_stride + reim;
 #pragma unroll
-        for (int r = 0; r < 2; ++r)
+        for (int r = 0; r < NR; ++r)
 #pragma unroll
             for (int q = 0; q < 16; ++q) {
-                const double* g = g0 + d_phidx(lmax + 1, pbase + kq + r * 64 + 4 * q, m);
+                const double* g = g0 + d_phidx(lmax + 1, pb[r] + kq + 4 * q, m);
                 const double n = on ? g[0] : 0.0, s = on ? g[2] : 0.0;
                 Be[r][q] = n + s;
                 Bo[r][q] = n - s;
@@ -365,7 +421,8 @@ __global__ void __launch_bounds__(128) k_leg_adj_mx(LegArgs A, const WaveTask* _
     for (int l0 = lw; l0 <= lmax; l0 += kMxL) {
         mx_d4 De0 = {0.0, 0.0, 0.0, 0.0}, De1 = De0, Do0 = De0, Do1 = De0;
 #pragma unroll
-        for (int r = 0; r < 2; ++r) {
+        for (int r = 0; r < NR; ++r) {
+            if (l0 + kMxL <= lwr[r]) continue;            // no pair of this sub-block has started yet (wave-uniform)
             if (l0 < lAend) mx_recur<true>(al, l0, x[r], mc[r], mp[r], sc[r], sp[r], ls[r], Tw + lane);
             else            mx_recur<false>(al, l0, x[r], mc[r], mp[r], sc[r], sp[r], ls[r], Tw + lane);
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -425,10 +482,13 @@ int leg_max_batch(int R) { return leg_batch(R, false); }
 
 template <int R, int NB>
 static void synth_RN(const LegArgs& A, const WaveTask* tasks, int ntasks, const double* ast, int nbs, int k0, int rep,
-                     double* ph, int64_t ph_stride, hipStream_t s) {
-    if (A.wg && NB <= 5)
-        hipLaunchKernelGGL((k_leg_synth_wg<R, (NB <= 5 ? NB : 5)>), dim3((ntasks / 4) * rep), dim3(256), 0,
-                           s, A, tasks, ntasks, ast, nbs, k0, rep, ph, ph_stride);
+                     double* ph, int64_t ph_stride, hipStream_t s, const PrepDev* prep) {
+    if (A.wg && NB <= 5 && prep)
+        hipLaunchKernelGGL((k_leg_synth_wg<R, (NB <= 5 ? NB : 5), true>), dim3((ntasks / 4) * rep), dim3(256), 0,
+                           s, A, tasks, ntasks, ast, nbs, k0, rep, ph, ph_stride, *prep);
+    else if (A.wg && NB <= 5)
+        hipLaunchKernelGGL((k_leg_synth_wg<R, (NB <= 5 ? NB : 5), false>), dim3((ntasks / 4) * rep), dim3(256), 0,
+                           s, A, tasks, ntasks, ast, nbs, k0, rep, ph, ph_stride, PrepDev{});
     else
         hipLaunchKernelGGL((k_leg_synth<R, NB>), dim3((ntasks / 4) * rep), dim3(256), 0, s, A, tasks, ntasks, ast, nbs,
                            k0, rep, ph, ph_stride);
@@ -448,12 +508,16 @@ static void for_batches(int nmaps, int nbmax, F f) {
         ib += rep;
     }
 }
+bool leg_synth_can_prep(const LegArgs& A) {
+    static const bool on = [] { const char* e = std::getenv("CMDR_SYNTH_PREP"); return !e || std::atoi(e) != 0; }();
+    return on && A.wg;
+}
 void launch_leg_synth(const LegArgs& A, const WaveTask* tasks, int ntasks, const double* ast, double* ph,
-                      int64_t ph_stride, int nmaps, hipStream_t s, int nbs) {
+                      int64_t ph_stride, int nmaps, hipStream_t s, int nbs, const PrepDev* prep) {
     if (ntasks == 0 || nmaps == 0) return;
     if (nbs < 0) nbs = nmaps;
     for_batches(nmaps, A.wg ? std::min(leg_batch(A.R, false, true), 5) : leg_batch(A.R, false), [&](int nb, int k0, int rep) {
-#define CMDR_S(RR, NN) case NN: synth_RN<RR, NN>(A, tasks, ntasks, ast, nbs, k0, rep, ph, ph_stride, s); break;
+#define CMDR_S(RR, NN) case NN: synth_RN<RR, NN>(A, tasks, ntasks, ast, nbs, k0, rep, ph, ph_stride, s, prep); break;
         if (A.R == 1) {
             switch (nb) { CMDR_S(1, 1) CMDR_S(1, 2) CMDR_S(1, 3) CMDR_S(1, 4) CMDR_S(1, 5) CMDR_S(1, 6) CMDR_S(1, 7)
                           CMDR_S(1, 8) CMDR_S(1, 9) }
@@ -486,14 +550,19 @@ void launch_leg_adj(const LegArgs& A, const WaveTask* tasks, int ntasks, const d
     }
     // matrix-unit form for batches of up to 8 maps (plans with 256-pair chunks); the rest through the VALU kernel
     static const int mx_min = [] { const char* e = std::getenv("CMDR_ADJ_MX"); return e ? std::atoi(e) : 6; }();
-    int kdone = 0;
-    if (A.R == 4 && mx_min > 0)
-        while (nmaps - kdone >= mx_min) {
-            const int nb = std::min(8, nmaps - kdone);
-            hipLaunchKernelGGL(k_leg_adj_mx, dim3(ntasks), dim3(128), 0, s, A, tasks, ntasks, ph, ph_stride, kdone, nb, part,
-                               pms, pcs);
-            kdone += nb;
-        }
+    int kdone = 0, nmx = 0;
+    if ((A.R == 4 || A.R == 2) && mx_min > 0)
+        for (int left = nmaps; left >= mx_min; left -= std::min(8, left)) nmx += std::min(8, left);
+    while (kdone < nmx) {
+        const int nb = std::min(8, nmx - kdone);
+        if (A.R == 4)
+            hipLaunchKernelGGL(k_leg_adj_mx<2>, dim3(ntasks), dim3(128), 0, s, A, tasks, ntasks, ph, ph_stride, kdone, nb,
+                               part, pms, pcs);
+        else
+            hipLaunchKernelGGL(k_leg_adj_mx<1>, dim3(ntasks), dim3(128), 0, s, A, tasks, ntasks, ph, ph_stride, kdone, nb,
+                               part, pms, pcs);
+        kdone += nb;
+    }
     if (between) between(kdone);
     if (kdone == nmaps) return;
     ph += (int64_t)kdone * ph_stride;

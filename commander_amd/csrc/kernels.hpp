@@ -14,8 +14,11 @@ namespace cmdr {
 // coefficient stream: maps interleaved, ast[((t * nmaps) + k) * 2 + {re, im}]
 int leg_max_batch(int R);
 // nbs: maps interleaved in the stream buffer (default nmaps); a sub-range of maps is addressed by shifting ast / ph
+// prep != null (only when leg_synth_can_prep(A)): the coefficients are formed from the stacked vector while the kernel
+// stages its tiles (k_band_prep folded in) and ast is not read
 void launch_leg_synth(const LegArgs& A, const WaveTask* tasks, int ntasks, const double* ast, double* ph,
-                      int64_t ph_stride, int nmaps, hipStream_t s, int nbs = -1);
+                      int64_t ph_stride, int nmaps, hipStream_t s, int nbs = -1, const PrepDev* prep = nullptr);
+bool leg_synth_can_prep(const LegArgs& A);
 // between(nmx): called once after the matrix-unit launches (nmx maps went through k_leg_adj_mx; 0 = none) and before
 // the VALU launches of the remaining maps (profiling hook; may be empty)
 void launch_leg_adj(const LegArgs& A, const WaveTask* tasks, int ntasks, const double* ph, int64_t ph_stride,
@@ -76,6 +79,15 @@ void launch_pix(int mode, const double* a, const double* b, const double* c, dou
 int dot_partial_count();
 void launch_dot(const double* a, const double* b, int64_t n, double* partial, double* scal, int slot, bool shift,
                 hipStream_t s);
+// fused PCG vector kernels (diagonal preconditioner, diffuse components only): p_* = dot_partial_count() partial sums
+void launch_cg_seed(const double* scal, int slot, double* p, hipStream_t s);
+void launch_cg_q(const CompDev* comps, int ncomp, int lmax, const double* smat, const double* yc, const double* d,
+                 double* q, double* p_dq, hipStream_t s);
+void launch_cg_xr_precond(const CompDev* comps, int ncomp, int lmax, const double* P, int nmaps_pre, const double* p_dq,
+                          const double* p_rs_old, double* p_rs, double* x, double* r, const double* d, const double* q,
+                          double* sv, double* scal, hipStream_t s);
+void launch_cg_d_sqrtS(const CompDev* comps, int ncomp, int lmax, const double* smat, const double* p_rs_old,
+                       const double* p_rs, double* d, const double* sv, double* sx, double* scal, hipStream_t s);
 void launch_cg_xr(double* x, double* r, const double* d, const double* q, int64_t n, const double* scal, int num,
                   int den, hipStream_t s);
 void launch_cg_d(double* d, const double* sv, int64_t n, const double* scal, int num, int den, hipStream_t s);

@@ -177,6 +177,9 @@ void LegendreTables::build(int lmax_, const std::vector<double>& x_, const std::
         std::stable_sort(tasks_s.begin(), tasks_s.end(), [](const WaveTask& a, const WaveTask& b) { return a.lw < b.lw; });
         while (tasks_s.size() % 4) { WaveTask t; t.m = 0; t.chunk = -1; t.lw = lmax + 1; t.lAend = lmax + 1; tasks_s.push_back(t); }
     }
+    if (std::getenv("CMDR_DEBUG_PLAN"))
+        std::fprintf(stderr, "[cmdr] synthesis plan: Rs=%d, %zu tasks, %s form\n", Rs, tasks_s.size(),
+                     synth_wg ? "workgroup (LDS tiles; coefficients can be formed in the staging)" : "wave");
 }
 
 // --------------------------------------------------------------------------------------------- spin-2 tables
@@ -515,11 +518,12 @@ void ShtTables::build(int nside_, int lmax_, const std::vector<int>& rings_in, c
         sth[p] = r.sth;
     }
     const int np = (int)rings.size();
-    // Adjoint: 4 ring pairs per lane amortise the cross-lane reduction (also on small ring-sharded ranks: the batches
-    // of a launch are fused, so even one chunk per m fills the GPU).  Synthesis: 2 pairs per lane (higher occupancy;
-    // its coefficients come through LDS in the workgroup form, which needs the chunks of an m in groups of 4 -- 1 pair
-    // per lane where 2 would leave fewer than 4 chunks, e.g. 256-pair shards).  Measured with tools/cr_time.py and
-    // tools/cr_time_rank.py; tunable through CMDR_LEG_R / CMDR_LEG_RS.
+    // Adjoint: 4 ring pairs per lane (tasks of 256 pairs: the matrix-unit kernel keeps their phases in registers, the
+    // VALU kernel amortises its cross-lane reduction) -- also on ring-sharded ranks with 256 or 512 pairs: 128-pair
+    // tasks (R = 2, twice as many and half as long) measured 10 % slower there (cr_time_rank.py).  Synthesis: 2
+    // pairs per lane (higher occupancy; its coefficients come through LDS in the workgroup form, which needs the
+    // chunks of an m in groups of 4 -- 1 pair per lane where 2 would leave fewer than 4 chunks, e.g. 256-pair shards).
+    // Measured with tools/cr_time.py and tools/cr_time_rank.py; tunable through CMDR_LEG_R / CMDR_LEG_RS.
     int R = 4, Rs = 2;
     while (R > 1 && np < 64 * R) R >>= 1;
     while (Rs > 1 && (np < 64 * Rs || ((np + 64 * R - 1) / (64 * R) * R / Rs) % 4 != 0)) Rs >>= 1;

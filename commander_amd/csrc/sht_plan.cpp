@@ -129,6 +129,13 @@ void ShtPlan::synth_from_stream(int nmaps, hipStream_t s) {
                      s);
 }
 
+bool ShtPlan::can_prep() const { return leg_synth_can_prep(leg_.args_synth()); }
+void ShtPlan::synth_from_prep(const PrepDev& prep, int nmaps, hipStream_t s) {
+    CMDR_REQUIRE(can_prep(), "this plan's synthesis reads its coefficients from the stream");
+    launch_leg_synth(leg_.args_synth(), leg_.tasks_s.get(), leg_.ntasks_s, ast_.get(), ph_.get(), leg_.ph_elems(), nmaps,
+                     s, -1, &prep);
+}
+
 void ShtPlan::rings(int mode, double* d_map, int64_t map_stride, const double* const* d_mul, bool weighted,
                     int nmaps, hipStream_t s, const cd* that) {
     const bool tz = mode == 2 && that && T_.ring.that_elems;      // classes follow the LDS image each pair then needs

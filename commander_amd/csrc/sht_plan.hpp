@@ -78,6 +78,8 @@ class ShtPlan {
     double* partials() { return part_.get(); }             // [max_maps][nchunk][tri_elems]
     int64_t part_map_stride() const { return (int64_t)leg_.nchunk * leg_.tri_elems(); }
     void synth_from_stream(int nmaps, hipStream_t s);                                // stream -> phases
+    bool can_prep() const;                             // the synthesis can form its coefficients itself (workgroup form)
+    void synth_from_prep(const PrepDev& prep, int nmaps, hipStream_t s);             // stacked vector -> phases
     // that (mode 2 only): multiplier spectra from toeplitz_build() for the same d_mul maps -> cap rings take the
     // Toeplitz form (kernels_body.hpp) instead of two Bluestein transforms per direction
     void rings(int mode, double* d_map, int64_t map_stride, const double* const* d_mul, bool weighted, int nmaps,

@@ -40,9 +40,27 @@ def pix_phi(nside):
     return phi
 
 
-def rank_rings(nside, rank, nranks):
-    """Northern ring numbers owned by ``rank`` (comm_map_mod.f90:197: i = 1+myid, 2*nside, nprocs)."""
-    return np.arange(1 + rank, 2 * nside + 1, nranks, dtype=np.int32)
+def rank_rings(nside, rank, nranks, scheme="cyclic", block=64):
+    """Northern ring numbers owned by ``rank`` (the southern mirrors are implied).
+
+    ``cyclic``: Commander's own dealing (comm_map_mod.f90:197: i = 1+myid, 2*nside, nprocs).
+    ``block``:  blocks of ``block`` adjacent ring pairs dealt boustrophedon (0..N-1, N-1..0, ...) -- the GPU-friendly
+    ownership: the 64 lanes of a Legendre wave then hold neighbouring latitudes, whose recursions start at nearly the
+    same l (cyclic dealing spreads a wave over a quarter of the hemisphere: 78 % instead of 96 % useful lane steps
+    at Nside 1024 / 8 ranks).  The back-and-forth order balances pixels exactly in the polar caps (ring length grows
+    linearly) and the Legendre work closely.  Any union of ring pairs is a valid shard for the library."""
+    if scheme == "cyclic":
+        return np.arange(1 + rank, 2 * nside + 1, nranks, dtype=np.int32)
+    assert scheme == "block", scheme
+    nr, B = 2 * nside, int(block)
+    while B > 1 and nr // B < 2 * nranks:
+        B //= 2
+    out = []
+    for b in range((nr + B - 1) // B):
+        pos = b % (2 * nranks)
+        if (pos if pos < nranks else 2 * nranks - 1 - pos) == rank:
+            out.append(np.arange(b * B + 1, min((b + 1) * B, nr) + 1, dtype=np.int32))
+    return np.concatenate(out) if out else np.zeros(0, dtype=np.int32)
 
 
 def local_pixels(nside, rings):

@@ -430,3 +430,59 @@ def pinv_toeplitz_checks(_lib=None, nside=256, lmax=512, tol=1e-10):
     got = ctx.cr_invM(x)
     assert rel(got, S.invM(x)) < tol
     assert np.array_equal(ctx.cr_invM(x), got)
+
+
+def fused_staging_checks(_lib=None, nside=128, lmax=24, tol=1e-12):
+    """256 ring pairs: the synthesis runs in its workgroup form, where the coefficient stream is never written -- the
+    kernel's tile staging forms beam x mixing x component sums itself (PrepDev), incl. the varying-mixing 'extra' term
+    and components with different lmax; matvec, RHS and the pseudo-inverse preconditioner against the oracle."""
+    from commander_amd import synth, healpix
+    from commander_amd.cr import build_context
+    spec = synth.make_problem("cfg2", nside=nside, lmax=lmax, comp_lmax=[lmax, lmax - 7])
+    z = healpix.pix_z(nside)
+    spec["comps"][1]["F_map"] = {ib: ((b["nu"] / 30.0) ** (-3.1 + 0.1 * z))[:, None]
+                                 for ib, b in enumerate(spec["bands"])}
+    S = oracle_system(spec)
+    ctx = build_context(spec, _lib=_lib)
+    x = np.random.default_rng(33).standard_normal(ctx.ncr)
+    assert rel(ctx.cr_matmulA(x), S.matmulA(x)) < tol
+    resid, xi, eta = synth.draw_inputs(spec)
+    assert rel(ctx.cr_computeRHS("sample", resid, xi, eta), S.computeRHS(resid, "sample", xi, eta)) < tol
+    ctx.initPrecond("pseudoinv")
+    ctx.update_precond()
+    S.init_precond_pseudoinv()
+    S.update_precond_pseudoinv()
+    assert rel(ctx.cr_invM(x), S.invM(x)) < 10 * tol
+
+
+def fused_pcg_checks(_lib, pol, monkeypatch, nside=16, lmax=32):
+    """solve_cr_eqn_by_CG with the three fused vector kernels per iteration (S^1/2 yc + d with d.q; x, r, M^-1 r with
+    r.s; d with the next S^1/2 d) against the one-kernel-per-line sequence (CMDR_CG_FUSED=0) and the oracle, with
+    different lmax per component and the chisq criterion (whose evaluation overwrites the S^1/2 buffer)."""
+    from commander_amd import synth
+    from commander_amd.cr import build_context
+    spec = synth.make_problem("cfg2", nside=nside, lmax=lmax, pol=pol, comp_lmax=[lmax, lmax - 8])
+    S = oracle_system(spec)
+    ctx = build_context(spec, _lib=_lib)
+    ctx.initPrecond()
+    ctx.update_precond()
+    S.init_precond_diag()
+    S.update_precond_diag()
+    resid, xi, eta = synth.draw_inputs(spec)
+    b = ctx.cr_computeRHS("sample", resid, xi, eta)
+    out = {}
+    for mode in ("1", "0"):
+        monkeypatch.setenv("CMDR_CG_FUSED", mode)
+        out[mode] = [ctx.solve_cr_eqn_by_CG(b, "fixed_iter", 1e-8, 5, 12, 1),
+                     ctx.solve_cr_eqn_by_CG(b, "residual", 1e-10, 5, 600, 3),
+                     ctx.solve_cr_eqn_by_CG(b, "chisq", 1e-3, 2, 60, 2)]
+    f, g = out["1"][0], out["0"][0]                                # fixed_iter: same arithmetic up to the dot-product order
+    assert f[1] == g[1] == 12 and f[2] == g[2] and rel(f[0], g[0]) < 1e-9, (f[1:], g[1:], rel(f[0], g[0]))
+    assert abs(f[3][0] - g[3][0]) <= 1e-7 * abs(g[3][0])           # delta_new
+    # stopping rules: the two sequences sum their dot products in different orders, so after many iterations the
+    # iterates differ at the level the stopping rule leaves (delta_new / delta_0 < 1e-10 -> ~1e-5 in the solution)
+    for k, freq, lim in ((1, 3, 1e-4), (2, 2, 1e-6)):
+        f, g = out["1"][k], out["0"][k]
+        assert abs(f[1] - g[1]) <= freq and f[2] == g[2] == 0 and rel(f[0], g[0]) < lim, (k, f[1:], g[1:], rel(f[0], g[0]))
+    xo, no, so = S.solve(b, "fixed_iter", 1e-8, 5, 12, 1)
+    assert out["1"][0][1] == no and rel(out["1"][0][0], xo) < 1e-10

@@ -20,9 +20,24 @@ static void synth_RN(const LegArgs& A, const WaveTask* tasks, int ntasks, const 
             leg_synth_lane<R, NB>(A, ast, nbs, k0, ph, ph_stride, tasks[t].m, tasks[t].chunk, tasks[t].lw,
                                   tasks[t].lAend, lane);
 }
+bool leg_synth_can_prep(const LegArgs& A) { return A.wg != 0; }
 void launch_leg_synth(const LegArgs& A, const WaveTask* tasks, int ntasks, const double* ast, double* ph,
-                      int64_t ph_stride, int nmaps, hipStream_t, int nbs) {
+                      int64_t ph_stride, int nmaps, hipStream_t, int nbs, const PrepDev* prep) {
     if (nbs < 0) nbs = nmaps;
+    std::vector<double> formed;
+    if (prep) {   // what the kernel's tile staging computes, element by element
+        const int lmax = A.lmax;
+        formed.assign((size_t)2 * nbs * d_moffp(lmax, lmax + 1), 0.0);
+        for (int bm = 0; bm < nmaps; ++bm)
+            for (int m = 0; m <= lmax; ++m)
+                for (int l = m; l <= lmax + 1; ++l)
+                    for (int part = 0; part < 2; ++part)
+                        formed[2 * ((d_moffp(lmax, m) + (l - m)) * nbs + bm) + part] = band_prep_part(
+                            prep->comps, prep->ncomp, prep->sx, prep->w + (int64_t)bm * prep->ncomp * (lmax + 1),
+                            prep->bm_stokes[bm], prep->cnorm, lmax, m, l, part,
+                            prep->extra ? prep->extra + (int64_t)bm * (lmax + 1) * (lmax + 1) : nullptr);
+        ast = formed.data();
+    }
     const int nbmax = leg_max_batch(A.R);
     for (int k0 = 0; k0 < nmaps; k0 += nbmax) {
         const int nb = std::min(nbmax, nmaps - k0);
@@ -321,6 +336,42 @@ void launch_dot(const double* a, const double* b, int64_t n, double*, double* sc
     for (int64_t i = 0; i < n; ++i) s += a[i] * b[i];
     if (shift) scal[slot + 1] = scal[slot];
     scal[slot] = s;
+}
+// fused PCG vector kernels: the partial-sum protocol with the whole sum in entry 0
+static double fold_partials(const double* p) {
+    double t = 0.0;
+    for (int i = 0; i < dot_partial_count(); ++i) t += p[i];
+    return t;
+}
+static void put_partial(double* p, double v) {
+    std::fill(p, p + dot_partial_count(), 0.0);
+    p[0] = v;
+}
+void launch_cg_seed(const double* scal, int slot, double* p, hipStream_t) { put_partial(p, scal[slot]); }
+void launch_cg_q(const CompDev* comps, int ncomp, int lmax, const double* smat, const double* yc, const double* d,
+                 double* q, double* p_dq, hipStream_t) {
+    double acc = 0.0;
+    for (int m = 0; m <= lmax; ++m)
+        for (int l = m; l <= lmax; ++l) acc += cg_q_elem(comps, ncomp, smat, yc, d, q, m, l);
+    put_partial(p_dq, acc);
+}
+void launch_cg_xr_precond(const CompDev* comps, int ncomp, int lmax, const double* P, int nmaps_pre, const double* p_dq,
+                          const double* p_rs_old, double* p_rs, double* x, double* r, const double* d, const double* q,
+                          double* sv, double* scal, hipStream_t) {
+    const double dq = fold_partials(p_dq), alpha = fold_partials(p_rs_old) / dq;
+    scal[2] = dq;
+    double acc = 0.0;
+    for (int m = 0; m <= lmax; ++m)
+        for (int l = m; l <= lmax; ++l) acc += cg_xr_elem(comps, ncomp, P, lmax, nmaps_pre, alpha, x, r, d, q, sv, m, l);
+    put_partial(p_rs, acc);
+}
+void launch_cg_d_sqrtS(const CompDev* comps, int ncomp, int lmax, const double* smat, const double* p_rs_old,
+                       const double* p_rs, double* d, const double* sv, double* sx, double* scal, hipStream_t) {
+    const double dold = fold_partials(p_rs_old), dnew = fold_partials(p_rs);
+    scal[0] = dnew;
+    scal[1] = dold;
+    for (int m = 0; m <= lmax; ++m)
+        for (int l = m; l <= lmax; ++l) cg_d_elem(comps, ncomp, smat, dnew / dold, d, sv, sx, m, l);
 }
 void launch_cg_xr(double* x, double* r, const double* d, const double* q, int64_t n, const double* scal, int num,
                   int den, hipStream_t) {

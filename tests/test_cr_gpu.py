@@ -365,3 +365,14 @@ def test_lowl_preconditioner_gpu():
 def test_literal_quirks_switch_gpu():
     from helpers import literal_quirks_checks
     literal_quirks_checks(None, nside=32, lmax=64)
+
+
+def test_coefficients_formed_in_the_synthesis_staging_gpu():
+    from helpers import fused_staging_checks
+    fused_staging_checks(None, tol=1e-11)
+
+
+@pytest.mark.parametrize("pol", [False, True])
+def test_fused_pcg_updates_equal_the_general_sequence_gpu(pol, monkeypatch):
+    from helpers import fused_pcg_checks
+    fused_pcg_checks(None, pol, monkeypatch, nside=32, lmax=64)

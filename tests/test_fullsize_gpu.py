@@ -101,10 +101,12 @@ def test_pseudoinv_with_toeplitz_rings_vs_oracle():
     pinv_toeplitz_checks(None, nside=256, lmax=512)
 
 
-def test_ring_sharded_partial_matvecs_sum_to_the_full_one():
-    """What the 8 ranks of `bench.py --gpus 8` compute (ring pairs i = r mod 8, nine maps on 256 pairs each: the
-    matrix-unit adjoint with one chunk per m, the Toeplitz ring form on a shard), here one rank after the other on one
-    GPU: the partial vectors an all-reduce would sum add up to the single-GPU matvec."""
+@pytest.mark.parametrize("scheme", ["block", "cyclic"])
+def test_ring_sharded_partial_matvecs_sum_to_the_full_one(scheme):
+    """What the 8 ranks of `bench.py --gpus 8` compute (blocks of 64 ring pairs dealt back and forth -- or Commander's
+    cyclic dealing, i = r mod 8 --, nine maps on 256 pairs each: the matrix-unit adjoint with one chunk per m and its
+    per-64-pair skip, the Toeplitz ring form on a shard), here one rank after the other on one GPU: the partial
+    vectors an all-reduce would sum add up to the single-GPU matvec."""
     from commander_amd import synth, healpix
     from commander_amd.cr import build_context
     nside, P = 1024, 8
@@ -115,7 +117,7 @@ def test_ring_sharded_partial_matvecs_sum_to_the_full_one():
     ctx.close()
     acc = np.zeros_like(y)
     for r in range(P):
-        rings = healpix.rank_rings(nside, r, P)
+        rings = healpix.rank_rings(nside, r, P, scheme=scheme)
         pix = healpix.local_pixels(nside, rings)
         loc = synth.make_problem("cfg3", pixels=pix)
         c = build_context(loc, rings_by_nside={nside: rings})

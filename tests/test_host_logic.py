@@ -90,8 +90,10 @@ def test_emul_inactive_component_and_no_prior(EL):
     assert rel(ctx2.cr_matmulA(x), S2.matmulA(x)) < 1e-12
 
 
-def test_emul_ring_sharded_partial_sums(EL):
-    """Ring-pair sharding with replicated a_lm: the per-rank partial matvecs sum to the full one."""
+@pytest.mark.parametrize("scheme", ["cyclic", "block"])
+def test_emul_ring_sharded_partial_sums(EL, scheme):
+    """Ring-pair sharding with replicated a_lm: the per-rank partial matvecs sum to the full one, for
+    Commander's cyclic ring dealing and for the block dealing bench.py uses."""
     from commander_amd import synth, healpix
     from commander_amd.cr import build_context
     nside, lmax, P = 16, 32, 3
@@ -101,7 +103,7 @@ def test_emul_ring_sharded_partial_sums(EL):
     y = ctx.cr_matmulA(x)
     acc = np.zeros_like(y)
     for r in range(P):
-        rings = healpix.rank_rings(nside, r, P)
+        rings = healpix.rank_rings(nside, r, P, scheme=scheme)
         pix = healpix.local_pixels(nside, rings)
         loc = synth.make_problem("cfg2", nside=nside, lmax=lmax, pixels=pix)
         c = build_context(loc, rings_by_nside={nside: rings}, _lib=EL)
@@ -467,3 +469,38 @@ def test_emul_literal_quirks_switch(EL):
 def test_emul_pseudoinv_with_toeplitz_rings(EL):
     from helpers import pinv_toeplitz_checks
     pinv_toeplitz_checks(EL)
+
+
+def test_emul_coefficients_formed_in_the_synthesis_staging(EL):
+    from helpers import fused_staging_checks
+    fused_staging_checks(EL)
+
+
+@pytest.mark.parametrize("pol", [False, True])
+def test_emul_fused_pcg_updates_equal_the_general_sequence(EL, pol, monkeypatch):
+    from helpers import fused_pcg_checks
+    fused_pcg_checks(EL, pol, monkeypatch)
+
+
+@pytest.mark.parametrize("R,Rs", [(4, 2), (4, 1), (2, 1), (1, 1)])
+def test_emul_sht_pairs_per_lane(R, Rs, EL, oracle_lib, monkeypatch):
+    """The plan picks the ring pairs per lane from the shard size (4 / 2 for the adjoint, 2 / 1 for the synthesis);
+    every combination the kernels are compiled for gives the same transform (256 pairs: all four are valid)."""
+    from commander_amd.sht import ShtPlan
+    import commander_amd.sht as shtmod
+    monkeypatch.setenv("CMDR_LEG_R", str(R))
+    monkeypatch.setenv("CMDR_LEG_RS", str(Rs))
+    nside, lmax = 128, 40
+    rng = np.random.default_rng(R * 10 + Rs)
+    old = shtmod.lib
+    shtmod.lib = lambda: EL
+    try:
+        plan = ShtPlan(nside, lmax, max_maps=3)
+        a = rng.standard_normal(((lmax + 1) ** 2, 3))
+        m = rng.standard_normal((12 * nside * nside, 3))
+        y, yt = plan.Y(a), plan.Yt(m)
+    finally:
+        shtmod.lib = old
+    for k in range(3):
+        assert rel(y[:, k], oracle_lib.Y(nside, lmax, a[:, k])) < 1e-12
+        assert rel(yt[:, k], oracle_lib.Yt(nside, lmax, m[:, k])) < 1e-12

@@ -16,11 +16,12 @@ if len(sys.argv) > 3:                       # "BxR": band groups x ring sets; ti
 else:
     bp, rp = shard.plan_shards(nband, world)
 lay = max((shard.rank_layout(nband, world, r, bp, rp) for r in range(world)), key=lambda l: len(l["bands"]))
-rings = healpix.rank_rings(nside, lay["ring_index"], rp) if rp > 1 else None
+scheme = os.environ.get("CMDR_BENCH_RINGS", "block")
+rings = healpix.rank_rings(nside, lay["ring_index"], rp, scheme=scheme) if rp > 1 else None
 pix = healpix.local_pixels(nside, rings) if rings is not None else None
 spec = synth.make_problem(cfg, pixels=pix, bands=lay["bands"] if bp > 1 else None)
 ctx = build_context(spec, rings_by_nside={nside: rings} if rings is not None else None)
-print("layout: %d band groups x %d ring sets; this rank: %d bands" % (bp, rp, len(lay["bands"])), flush=True)
+print("layout: %d band groups x %d ring sets (%s ring ownership); this rank: %d bands" % (bp, rp, scheme, len(lay["bands"])), flush=True)
 ctx.initPrecond(); ctx.update_precond()
 x, y, b = ctx.dev(ctx.ncr, np.random.default_rng(0).standard_normal(ctx.ncr)), ctx.dev(ctx.ncr), ctx.dev(ctx.ncr)
 ctx.L.cmdr_profile_enable(ctx._h, 1)
@@ -34,7 +35,7 @@ for _ in range(n):
     ctx.cr_invM_dev(y, b)
 ctx.L.cmdr_memcpy_d2h(np.zeros(1).ctypes.data_as(ctypes.c_void_p), y.ptr, 8)
 dt = (time.time() - t0) / n
-ms = (ctypes.c_double * 4)(); cnt = (ctypes.c_longlong * 4)()
-ctx.L.cmdr_profile_read(ctx._h, ms, cnt)
-print("world=%d rank share: matvec+invM %.3f ms | per launch ms: synth %.3f ring %.3f adj %.3f matvec %.3f" % (
-    (world, dt * 1e3) + tuple(ms[k] / max(cnt[k], 1) for k in range(4))), flush=True)
+ms = (ctypes.c_double * 6)(); cnt = (ctypes.c_longlong * 6)()
+ctx.L.cmdr_profile_read_ext(ctx._h, 6, ms, cnt)
+print("world=%d rank share: matvec+invM %.3f ms | per launch ms: synth %.3f ring %.3f adj %.3f (matrix-unit %.3f + VALU %.3f) matvec %.3f" % (
+    (world, dt * 1e3) + tuple(ms[k] / max(cnt[k], 1) for k in (0, 1, 2, 4, 5, 3))), flush=True)
