@@ -248,6 +248,19 @@ CMDR_HD void alm_copy_elem(const double* __restrict__ src, int lmax_s, double* _
     }
 }
 
+// One column of a batched a_lm copy (launch_alm_copy_batch): the arguments of alm_copy_elem.  The columns of one
+// launch must write distinct destinations.
+struct AlmCopyDesc {
+    const double* src;
+    double* dst;
+    const double* fl;
+    int lmax_s, lmax_d, accumulate, lcut;
+};
+constexpr int kAlmCopyBatch = 16;
+struct AlmCopyBatch {
+    AlmCopyDesc d[kAlmCopyBatch];
+};
+
 // Prior part and scatter of the pseudo-inverse preconditioner (applyDiffPrecond_pseudoinv,
 // comm_diffuse_comp_mod.f90:2328-2372): out_c = z_c + sum_c' Q[stokes][c][c'][l] x_c' for active components
 // (Q = B B^t, B = prior columns of pinv(U)); inactive components keep x.

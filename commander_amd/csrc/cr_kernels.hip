@@ -112,6 +112,25 @@ void launch_alm_copy(const double* src, int lmax_s, double* dst, int lmax_d, con
     hipLaunchKernelGGL(k_alm_copy, grid, dim3(256), 0, s, src, lmax_s, dst, lmax_d, fl, accumulate ? 1 : 0, lcut);
 }
 
+// several columns in one launch (blockIdx.z): the staging copies of the varying-mixing batches, one per band
+__global__ void k_alm_copy_batch(AlmCopyBatch B) {
+    const AlmCopyDesc D = B.d[blockIdx.z];
+    const int m = blockIdx.y, l = m + blockIdx.x * 256 + threadIdx.x;
+    if (m > D.lmax_d || l > D.lmax_d) return;
+    alm_copy_elem(D.src, D.lmax_s, D.dst, D.lmax_d, D.fl, D.accumulate, D.lcut, m, l);
+}
+void launch_alm_copy_batch(const AlmCopyDesc* d, int n, hipStream_t s) {
+    for (int i0 = 0; i0 < n; i0 += kAlmCopyBatch) {
+        const int nb = std::min(kAlmCopyBatch, n - i0);
+        AlmCopyBatch B;
+        int lm = 0;
+        for (int i = 0; i < nb; ++i) { B.d[i] = d[i0 + i]; lm = std::max(lm, d[i0 + i].lmax_d); }
+        for (int i = nb; i < kAlmCopyBatch; ++i) B.d[i] = d[i0];
+        dim3 grid((lm + 1 + 255) / 256, lm + 1, nb);
+        hipLaunchKernelGGL(k_alm_copy_batch, grid, dim3(256), 0, s, B);
+    }
+}
+
 __global__ void k_pinv_prior(const CompDev* __restrict__ comps, int ncomp, const double* __restrict__ Q, int lmax_pre,
                              int nmaps_pre, const double* __restrict__ x, const double* __restrict__ z,
                              double* __restrict__ out) {

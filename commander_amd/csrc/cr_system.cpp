@@ -545,26 +545,30 @@ void CrSystem::mix_forward(Group& G, const double* sx) {
     for (MixBatch& B : G.mix) {
         const int nT = (int)B.T.size(), nP = (int)B.P.size();
         int k = 0;
+        std::vector<AlmCopyDesc> cp;     // the staging copies of a batch go out as one launch
         auto col_in = [&](const MixCol& m, int stokes) {
             const CompDev& C = comps_[m.comp].d;
-            launch_alm_copy(sx + C.pos + (int64_t)stokes * C.nalm, C.lmax, G.mix_in.get() + (int64_t)k * na, G.lmax, nullptr,
-                            false, stream_);
+            cp.push_back({sx + C.pos + (int64_t)stokes * C.nalm, G.mix_in.get() + (int64_t)k * na, nullptr, C.lmax, G.lmax,
+                          0, 1 << 30});
             ++k;
         };
         // every column of a batch starts from the same component a_lm: with sharing it is staged (and synthesised) once
         const bool share = mix_share();
         for (const MixCol& m : B.T) { col_in(m, 0); if (share) break; }
         for (const MixCol& m : B.P) { col_in(m, 1); col_in(m, 2); if (share) break; }
+        launch_alm_copy_batch(cp.data(), (int)cp.size(), stream_);
         P.sandwich(G.mix_in.get(), G.mix_out.get(), B.mul_ptrs.get(), nT, nP, stream_, share, false);
         reduce_rings(G.mix_out.get(), (int64_t)(nT + 2 * nP) * na);
         k = 0;
-        auto col_out = [&](int bm) {
-            launch_alm_copy(G.mix_out.get() + (int64_t)k * na, G.lmax, G.E.get() + (int64_t)bm * na, G.lmax,
-                            G.bl.get() + (int64_t)bm * (G.lmax + 1), true, stream_);
+        cp.clear();
+        auto col_out = [&](int bm) {     // one component's columns: every band map of the batch is a different E[bm]
+            cp.push_back({G.mix_out.get() + (int64_t)k * na, G.E.get() + (int64_t)bm * na,
+                          G.bl.get() + (int64_t)bm * (G.lmax + 1), G.lmax, G.lmax, 1, 1 << 30});
             ++k;
         };
         for (const MixCol& m : B.T) col_out(m.bm);
         for (const MixCol& m : B.P) { col_out(m.bm); col_out(m.bm + 1); }
+        launch_alm_copy_batch(cp.data(), (int)cp.size(), stream_);
     }
 }
 
@@ -584,14 +588,16 @@ void CrSystem::mix_adjoint(Group& G, bool rhs) {
     for (MixBatch& B : G.mix) {
         const int nT = (int)B.T.size(), nP = (int)B.P.size();
         int k = 0;
+        std::vector<AlmCopyDesc> cp;
         auto col_in = [&](int bm, int comp) {
-            launch_alm_copy(G.U.get() + (int64_t)bm * na, G.lmax, G.mix_in.get() + (int64_t)k * na, G.lmax,
-                            G.bl.get() + (int64_t)bm * (G.lmax + 1), false, stream_,
-                            rhs ? comps_[comp].d.lmax : (1 << 30));
+            cp.push_back({G.U.get() + (int64_t)bm * na, G.mix_in.get() + (int64_t)k * na,
+                          G.bl.get() + (int64_t)bm * (G.lmax + 1), G.lmax, G.lmax, 0,
+                          rhs ? comps_[comp].d.lmax : (1 << 30)});
             ++k;
         };
         for (const MixCol& m : B.T) col_in(m.bm, m.comp);
         for (const MixCol& m : B.P) { col_in(m.bm, m.comp); col_in(m.bm + 1, m.comp); }
+        launch_alm_copy_batch(cp.data(), (int)cp.size(), stream_);
         // ... and every output is added to the same component block: with sharing the phases are summed and one adjoint runs
         const bool share = mix_share();
         P.sandwich(G.mix_in.get(), G.mix_out.get(), B.mul_ptrs.get(), nT, nP, stream_, false, share);

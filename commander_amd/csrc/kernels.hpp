@@ -68,6 +68,7 @@ void launch_band_post2(const CompDev* comps, int ncomp, int lmax_max, const doub
                        hipStream_t s);
 void launch_precond_diag(const CompDev* comps, int ncomp, const double* P, int lmax_pre, int nmaps_pre,
                          const double* in, double* out, hipStream_t s);
+void launch_alm_copy_batch(const AlmCopyDesc* d, int n, hipStream_t s);   // columns with distinct destinations
 void launch_alm_copy(const double* src, int lmax_s, double* dst, int lmax_d, const double* fl, bool accumulate,
                      hipStream_t s, int lcut = 1 << 30);
 void launch_pinv_prior(const CompDev* comps, int ncomp, int lmax_max, const double* Q, int lmax_pre, int nmaps_pre,

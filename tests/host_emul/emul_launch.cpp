@@ -266,6 +266,12 @@ void launch_band_prep(const CompDev* comps, int ncomp, const double* sx, const d
                 band_prep_elem(comps, ncomp, sx, w + (int64_t)bm * ncomp * (lmax_g + 1), bm_stokes[bm], ast, nbm, bm,
                                cnorm, lmax_g, m, l, extra ? extra + bm * na : nullptr);
 }
+void launch_alm_copy_batch(const AlmCopyDesc* d, int n, hipStream_t) {
+    for (int i = 0; i < n; ++i)
+        for (int m = 0; m <= d[i].lmax_d; ++m)
+            for (int l = m; l <= d[i].lmax_d; ++l)
+                alm_copy_elem(d[i].src, d[i].lmax_s, d[i].dst, d[i].lmax_d, d[i].fl, d[i].accumulate, d[i].lcut, m, l);
+}
 void launch_alm_copy(const double* src, int lmax_s, double* dst, int lmax_d, const double* fl, bool accumulate,
                      hipStream_t, int lcut) {
     for (int m = 0; m <= lmax_d; ++m)
