@@ -275,12 +275,16 @@ __device__ inline double fold_partials(const double* __restrict__ partial) {
     __syncthreads();
     return tot;
 }
+// Block b walks the row pairs (m, lmax - m) with m = b, b + kDotBlocks, ...: a pair holds lmax + 2 entries whatever m,
+// so the blocks are balanced without an index division; consecutive threads take consecutive l of one row (the (re, im)
+// slots of consecutive l are adjacent in the packed layout: coalesced).
 template <class F>
 __device__ inline void cg_stride(int lmax, F f) {
-    const int64_t n = (int64_t)(lmax + 1) * (lmax + 1);
-    for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < n; e += (int64_t)kDotBlocks * 256) {
-        const int m = (int)(e / (lmax + 1)), l = m + (int)(e - (int64_t)m * (lmax + 1));
-        if (l <= lmax) f(m, l);
+    for (int m = blockIdx.x; 2 * m <= lmax; m += kDotBlocks) {
+        for (int l = m + threadIdx.x; l <= lmax; l += 256) f(m, l);
+        const int m2 = lmax - m;
+        if (m2 != m)
+            for (int l = m2 + threadIdx.x; l <= lmax; l += 256) f(m2, l);
     }
 }
 __global__ void __launch_bounds__(256) k_cg_q(const CompDev* __restrict__ comps, int ncomp, int lmax,
