@@ -408,12 +408,14 @@ def main():
         # (2 FMA recursion + 2 FMA accumulate per (ring pair, l, m)); a launch = the Legendre stage of `nk` maps.
         npair_loc = (len(rings) if rings is not None else 2 * nside)
         use_mx = int(cnt[4]) > 0
-        nk = min(nbm, 8) if use_mx else nbm
+        # nine maps: the ninth rides along in the same launch on the VALU (k_leg_adj_mx<.., X9>; CMDR_ADJ_X9=0: own launch)
+        x9 = use_mx and nbm == 9 and os.environ.get("CMDR_ADJ_X9", "1") != "0"
+        nk = (9 if x9 else min(nbm, 8)) if use_mx else nbm
         t_dom = avg(4) if use_mx else avg(5)
         f_alg = 8.0 * npair_loc * (lmax + 1) * (lmax + 2) / 2.0 * nk
         f_pruned = 8.0 * steps_pruned * nk                      # only (m, ring) inside libsharp's mlim cut are run
         if use_mx:    # executed: per (ring pair, l) one recursion step (mul + FMA = 3 flop) + 16 columns x 2 flop on the MFMA
-            f_exec = (3.0 + 32.0) * steps_pruned
+            f_exec = (3.0 + 32.0 + (4.0 if x9 else 0.0)) * steps_pruned    # + 2 FMA per step for the map riding along
         else:
             nb_adj = 3.0 if nbm >= 3 else float(nbm)            # maps sharing one recursion in k_leg_adj<4,3>
             f_exec = (2.0 * 2.0 * nbm + 3.0 * nbm / nb_adj) * steps_pruned
@@ -456,14 +458,14 @@ def main():
                           if use_mx else ("k_leg_adj (Legendre adjoint, VALU: phases -> a_lm, %d maps per span)" % nk),
                 "achieved": ach, "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": ach / FP64_PEAK_TFLOPS,
                 "note": "achieved = SURVEY 8d algorithmic flops (8 per (ring pair, l, m) and map, unpruned) / launch time, as "
-                        "the contract defines it; the kernel runs fewer: the (m, ring) cut removes 22 % of the steps and 8 maps "
-                        "share one recursion, so frac can exceed 1.  frac_executed counts what the kernel really executes.",
+                        "the contract defines it; the kernel runs fewer: the (m, ring) cut removes 22 % of the steps and all maps "
+                        "of a launch share one recursion, so frac can exceed 1.  frac_executed counts what the kernel really executes.",
                 "traffic": traffic, "avg_launch_ms": t_dom, "launches": int(cnt[4] if use_mx else cnt[5]),
                 "flop_per_launch": {"algorithmic_8d": f_alg, "mlim_pruned": f_pruned, "executed": f_exec},
                 "frac_mlim_pruned": f_pruned / (t_dom * 1e-3) / 1e12 / FP64_PEAK_TFLOPS if t_dom else None,
                 "frac_executed": f_exec / (t_dom * 1e-3) / 1e12 / FP64_PEAK_TFLOPS if t_dom else None,
                 "secondary": {
-                    "k_leg_adj_valu_leftover": {"bound": "fp64 valu", "avg_span_ms": avg(5) if use_mx else None,
+                    "k_leg_adj_valu_leftover": {"bound": "fp64 valu", "avg_span_ms": avg(5) if use_mx and nbm > nk else None,
                                                 "maps": nbm - nk if use_mx else 0},
                     "k_leg_synth": {"bound": "fp64 valu", "avg_span_ms": t_syn,
                                     "frac_algorithmic_8d": f_alg9 / (t_syn * 1e-3) / 1e12 / FP64_PEAK_TFLOPS if t_syn else None,

@@ -359,12 +359,18 @@ __device__ __forceinline__ void mx_recur(const double* __restrict__ al, int l0, 
 // m = 0, as the critical path of the launch).  The sub-blocks of a 256-pair task are dealt 0,3 | 1,2 to the two waves
 // (polar + equatorial against the two middle ones) and each wave skips the 32-l groups that lie below every start of
 // a sub-block, so the (m, ring) cut is honoured per 64 pairs, not per task.
-template <int NR>
+// X9: a ninth map (slot k0 + 8) rides along on the VALU: while the A operands of a 64-pair block are in registers
+// (lane = (l row, pair of a quad)), four FMAs per MFMA step multiply them with that map's N+S / N-S phases, read back
+// from a wave-private LDS table as broadcasts; the sum over the four pair lanes of a row closes with two cross-lane
+// steps per 32-l group.  One map more for ~1/8 more work on the shared fp64 datapath instead of a VALU launch of its own
+// with its own recursion and wave-wide reductions.
+template <int NR, bool X9>
 __global__ void __launch_bounds__(128) k_leg_adj_mx(LegArgs A, const WaveTask* __restrict__ tasks, int ntasks,
                                                     const double* __restrict__ ph, int64_t ph_stride, int k0, int nb,
                                                     double* __restrict__ part, int64_t part_map_stride,
                                                     int64_t part_chunk_stride) {
     __shared__ __attribute__((aligned(16))) double tile[2][kMxL * kMxPitch];
+    __shared__ __attribute__((aligned(16))) double g9s[X9 ? 2 : 1][X9 ? 64 * 4 : 2];
     const int wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int lane = threadIdx.x & 63;
     if ((int)blockIdx.x >= ntasks) return;
@@ -418,11 +424,23 @@ __global__ void __launch_bounds__(128) k_leg_adj_mx(LegArgs A, const WaveTask* _
     double* __restrict__ Tw = tile[wid];
     const double* __restrict__ To = tile[1 - wid];
     const int arow = (lane & 15) * 2 * kMxPitch + kq;
+    const double* __restrict__ ph9 = ph + (int64_t)(k0 + 8) * ph_stride;     // X9 only
+    double* __restrict__ out9 = part + chunk * part_chunk_stride + 2 * (mo - m) + (int64_t)(k0 + 8) * part_map_stride;
+    double* __restrict__ G9 = g9s[X9 ? wid : 0];
     for (int l0 = lw; l0 <= lmax; l0 += kMxL) {
         mx_d4 De0 = {0.0, 0.0, 0.0, 0.0}, De1 = De0, Do0 = De0, Do1 = De0;
+        double xer = 0.0, xei = 0.0, xor_ = 0.0, xoi = 0.0;   // ninth map: even / odd rows, re / im; lane = (row, kq)
 #pragma unroll
         for (int r = 0; r < NR; ++r) {
             if (l0 + kMxL <= lwr[r]) continue;            // no pair of this sub-block has started yet (wave-uniform)
+            if (X9) {   // this block's ninth-map phases, lane = pair: (N+S).re, (N+S).im, (N-S).re, (N-S).im
+                const double* g = ph9 + d_phidx(lmax + 1, pb[r] + lane, m);
+                const double nr = g[0], ni = g[1], sr = g[2], si = g[3];
+                G9[4 * lane] = nr + sr;
+                G9[4 * lane + 1] = ni + si;
+                G9[4 * lane + 2] = nr - sr;
+                G9[4 * lane + 3] = ni - si;
+            }
             if (l0 < lAend) mx_recur<true>(al, l0, x[r], mc[r], mp[r], sc[r], sp[r], ls[r], Tw + lane);
             else            mx_recur<false>(al, l0, x[r], mc[r], mp[r], sc[r], sp[r], ls[r], Tw + lane);
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -436,6 +454,14 @@ __global__ void __launch_bounds__(128) k_leg_adj_mx(LegArgs A, const WaveTask* _
                 Do0 = __builtin_amdgcn_mfma_f64_16x16x4f64(ao0, Bo[r][q], Do0, 0, 0, 0);
                 De1 = __builtin_amdgcn_mfma_f64_16x16x4f64(ae1, Be[r][q + 1], De1, 0, 0, 0);
                 Do1 = __builtin_amdgcn_mfma_f64_16x16x4f64(ao1, Bo[r][q + 1], Do1, 0, 0, 0);
+                if (X9) {
+                    const double* ga = G9 + 4 * (4 * q + kq);
+                    const double* gb = ga + 16;
+                    xer += ae0 * ga[0] + ae1 * gb[0];
+                    xei += ae0 * ga[1] + ae1 * gb[1];
+                    xor_ += ao0 * ga[2] + ao1 * gb[2];
+                    xoi += ao0 * ga[3] + ao1 * gb[3];
+                }
             }
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
             __builtin_amdgcn_wave_barrier();
@@ -448,6 +474,22 @@ __global__ void __launch_bounds__(128) k_leg_adj_mx(LegArgs A, const WaveTask* _
         mx_d4 keep = wid == 0 ? De0 : Do0;
 #pragma unroll
         for (int v = 0; v < 4; ++v) Tw[v * 64 + lane] = give[v];
+        double k9r = 0.0, k9i = 0.0;
+        if (X9) {   // rows summed over the four pair lanes (kq); then the same hand-over as the matrix-unit rows
+#pragma unroll
+            for (int o = 16; o <= 32; o <<= 1) {
+                xer += __shfl_xor(xer, o);
+                xei += __shfl_xor(xei, o);
+                xor_ += __shfl_xor(xor_, o);
+                xoi += __shfl_xor(xoi, o);
+            }
+            k9r = wid == 0 ? xer : xor_;
+            k9i = wid == 0 ? xei : xoi;
+            if (lane < 16) {
+                Tw[256 + lane] = wid == 0 ? xor_ : xer;
+                Tw[272 + lane] = wid == 0 ? xoi : xei;
+            }
+        }
         __syncthreads();
 #pragma unroll
         for (int v = 0; v < 4; ++v) keep[v] += To[v * 64 + lane];
@@ -456,6 +498,13 @@ __global__ void __launch_bounds__(128) k_leg_adj_mx(LegArgs A, const WaveTask* _
             for (int v = 0; v < 4; ++v) {
                 const int l = l0 + 2 * (kq + 4 * v) + wid;
                 if (l <= lmax) outp[2 * l] = keep[v];
+            }
+        }
+        if (X9 && lane < 16) {
+            const int l = l0 + 2 * lane + wid;
+            if (l <= lmax) {
+                out9[2 * l] = k9r + To[256 + lane];
+                out9[2 * l + 1] = k9i + To[272 + lane];
             }
         }
         __syncthreads();
@@ -553,15 +602,16 @@ void launch_leg_adj(const LegArgs& A, const WaveTask* tasks, int ntasks, const d
     int kdone = 0, nmx = 0;
     if ((A.R == 4 || A.R == 2) && mx_min > 0)
         for (int left = nmaps; left >= mx_min; left -= std::min(8, left)) nmx += std::min(8, left);
+    static const bool x9_on = [] { const char* e = std::getenv("CMDR_ADJ_X9"); return !e || std::atoi(e) != 0; }();
     while (kdone < nmx) {
         const int nb = std::min(8, nmx - kdone);
-        if (A.R == 4)
-            hipLaunchKernelGGL(k_leg_adj_mx<2>, dim3(ntasks), dim3(128), 0, s, A, tasks, ntasks, ph, ph_stride, kdone, nb,
-                               part, pms, pcs);
-        else
-            hipLaunchKernelGGL(k_leg_adj_mx<1>, dim3(ntasks), dim3(128), 0, s, A, tasks, ntasks, ph, ph_stride, kdone, nb,
-                               part, pms, pcs);
-        kdone += nb;
+        const bool x9 = x9_on && nb == 8 && nmaps - (kdone + 8) == 1;    // a single map left over rides along
+#define CMDR_MX(NRR, XX) hipLaunchKernelGGL((k_leg_adj_mx<NRR, XX>), dim3(ntasks), dim3(128), 0, s, A, tasks, ntasks, ph, \
+                                            ph_stride, kdone, nb, part, pms, pcs)
+        if (A.R == 4) { if (x9) CMDR_MX(2, true); else CMDR_MX(2, false); }
+        else          { if (x9) CMDR_MX(1, true); else CMDR_MX(1, false); }
+#undef CMDR_MX
+        kdone += nb + (x9 ? 1 : 0);
     }
     if (between) between(kdone);
     if (kdone == nmaps) return;
