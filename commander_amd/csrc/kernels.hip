@@ -457,10 +457,14 @@ __global__ void __launch_bounds__(128) k_leg_adj_mx(LegArgs A, const WaveTask* _
                 if (X9) {
                     const double* ga = G9 + 4 * (4 * q + kq);
                     const double* gb = ga + 16;
-                    xer += ae0 * ga[0] + ae1 * gb[0];
-                    xei += ae0 * ga[1] + ae1 * gb[1];
-                    xor_ += ao0 * ga[2] + ao1 * gb[2];
-                    xoi += ao0 * ga[3] + ao1 * gb[3];
+                    xer = fma(ae0, ga[0], xer);
+                    xei = fma(ae0, ga[1], xei);
+                    xor_ = fma(ao0, ga[2], xor_);
+                    xoi = fma(ao0, ga[3], xoi);
+                    xer = fma(ae1, gb[0], xer);
+                    xei = fma(ae1, gb[1], xei);
+                    xor_ = fma(ao1, gb[2], xor_);
+                    xoi = fma(ao1, gb[3], xoi);
                 }
             }
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
