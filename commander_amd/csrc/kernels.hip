@@ -359,18 +359,24 @@ __device__ __forceinline__ void mx_recur(const double* __restrict__ al, int l0, 
 // m = 0, as the critical path of the launch).  The sub-blocks of a 256-pair task are dealt 0,3 | 1,2 to the two waves
 // (polar + equatorial against the two middle ones) and each wave skips the 32-l groups that lie below every start of
 // a sub-block, so the (m, ring) cut is honoured per 64 pairs, not per task.
+// acc += a * g(lane Q of this lane's 16-lane row): gfx90a+ let fp64 VALU ops take src0 through the DPP row broadcast,
+// so the operand that is shared by the 16 l-rows of one pair costs no instruction and no LDS read of its own.
+template <int Q>
+__device__ __forceinline__ void fmac_row_bcast(double& acc, double g, double a) {
+    asm("v_fmac_f64_dpp %0, %1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf" : "+v"(acc) : "v"(g), "v"(a), "n"(Q));
+}
 // X9: a ninth map (slot k0 + 8) rides along on the VALU: while the A operands of a 64-pair block are in registers
-// (lane = (l row, pair of a quad)), four FMAs per MFMA step multiply them with that map's N+S / N-S phases, read back
-// from a wave-private LDS table as broadcasts; the sum over the four pair lanes of a row closes with two cross-lane
-// steps per 32-l group.  One map more for ~1/8 more work on the shared fp64 datapath instead of a VALU launch of its own
-// with its own recursion and wave-wide reductions.
+// (lane = (l row, pair kq of quad q)), four FMAs per MFMA step multiply them with that map's N+S / N-S phases.  Those
+// sit in 8 registers per block, lane (row q', kq) holding pair 4 q' + kq, so that step q needs lane q of every 16-lane
+// row: the DPP row broadcast of v_fmac_f64 delivers it inside the FMA.  The sum over the four pair lanes of a row
+// closes with two cross-lane steps per 32-l group.  One map more for 1/8 more work on the shared fp64 datapath instead
+// of a VALU launch of its own with its own recursion and wave-wide reductions.
 template <int NR, bool X9>
 __global__ void __launch_bounds__(128) k_leg_adj_mx(LegArgs A, const WaveTask* __restrict__ tasks, int ntasks,
                                                     const double* __restrict__ ph, int64_t ph_stride, int k0, int nb,
                                                     double* __restrict__ part, int64_t part_map_stride,
                                                     int64_t part_chunk_stride) {
     __shared__ __attribute__((aligned(16))) double tile[2][kMxL * kMxPitch];
-    __shared__ __attribute__((aligned(16))) double g9s[X9 ? 2 : 1][X9 ? 64 * 4 : 2];
     const int wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int lane = threadIdx.x & 63;
     if ((int)blockIdx.x >= ntasks) return;
@@ -426,47 +432,50 @@ __global__ void __launch_bounds__(128) k_leg_adj_mx(LegArgs A, const WaveTask* _
     const int arow = (lane & 15) * 2 * kMxPitch + kq;
     const double* __restrict__ ph9 = ph + (int64_t)(k0 + 8) * ph_stride;     // X9 only
     double* __restrict__ out9 = part + chunk * part_chunk_stride + 2 * (mo - m) + (int64_t)(k0 + 8) * part_map_stride;
-    double* __restrict__ G9 = g9s[X9 ? wid : 0];
+    double g9[NR][4];            // X9: (N+S).re, (N+S).im, (N-S).re, (N-S).im of pair 4 (lane & 15) + (lane >> 4)
+#pragma unroll
+    for (int r = 0; r < NR; ++r) {
+        g9[r][0] = g9[r][1] = g9[r][2] = g9[r][3] = 0.0;
+        if (X9) {
+            const double* g = ph9 + d_phidx(lmax + 1, pb[r] + 4 * (lane & 15) + kq, m);
+            g9[r][0] = g[0] + g[2];
+            g9[r][1] = g[1] + g[3];
+            g9[r][2] = g[0] - g[2];
+            g9[r][3] = g[1] - g[3];
+        }
+    }
     for (int l0 = lw; l0 <= lmax; l0 += kMxL) {
         mx_d4 De0 = {0.0, 0.0, 0.0, 0.0}, De1 = De0, Do0 = De0, Do1 = De0;
         double xer = 0.0, xei = 0.0, xor_ = 0.0, xoi = 0.0;   // ninth map: even / odd rows, re / im; lane = (row, kq)
 #pragma unroll
         for (int r = 0; r < NR; ++r) {
             if (l0 + kMxL <= lwr[r]) continue;            // no pair of this sub-block has started yet (wave-uniform)
-            if (X9) {   // this block's ninth-map phases, lane = pair: (N+S).re, (N+S).im, (N-S).re, (N-S).im
-                const double* g = ph9 + d_phidx(lmax + 1, pb[r] + lane, m);
-                const double nr = g[0], ni = g[1], sr = g[2], si = g[3];
-                G9[4 * lane] = nr + sr;
-                G9[4 * lane + 1] = ni + si;
-                G9[4 * lane + 2] = nr - sr;
-                G9[4 * lane + 3] = ni - si;
-            }
             if (l0 < lAend) mx_recur<true>(al, l0, x[r], mc[r], mp[r], sc[r], sp[r], ls[r], Tw + lane);
             else            mx_recur<false>(al, l0, x[r], mc[r], mp[r], sc[r], sp[r], ls[r], Tw + lane);
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
             __builtin_amdgcn_wave_barrier();
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-#pragma unroll
-            for (int q = 0; q < 16; q += 2) {
-                const double ae0 = Tw[arow + 4 * q], ao0 = Tw[arow + kMxPitch + 4 * q];
-                const double ae1 = Tw[arow + 4 * q + 4], ao1 = Tw[arow + kMxPitch + 4 * q + 4];
-                De0 = __builtin_amdgcn_mfma_f64_16x16x4f64(ae0, Be[r][q], De0, 0, 0, 0);
-                Do0 = __builtin_amdgcn_mfma_f64_16x16x4f64(ao0, Bo[r][q], Do0, 0, 0, 0);
-                De1 = __builtin_amdgcn_mfma_f64_16x16x4f64(ae1, Be[r][q + 1], De1, 0, 0, 0);
-                Do1 = __builtin_amdgcn_mfma_f64_16x16x4f64(ao1, Bo[r][q + 1], Do1, 0, 0, 0);
-                if (X9) {
-                    const double* ga = G9 + 4 * (4 * q + kq);
-                    const double* gb = ga + 16;
-                    xer = fma(ae0, ga[0], xer);
-                    xei = fma(ae0, ga[1], xei);
-                    xor_ = fma(ao0, ga[2], xor_);
-                    xoi = fma(ao0, ga[3], xoi);
-                    xer = fma(ae1, gb[0], xer);
-                    xei = fma(ae1, gb[1], xei);
-                    xor_ = fma(ao1, gb[2], xor_);
-                    xoi = fma(ao1, gb[3], xoi);
-                }
+#define CMDR_MX_Q(q)                                                                                       \
+            {                                                                                              \
+                const double ae0 = Tw[arow + 4 * (q)], ao0 = Tw[arow + kMxPitch + 4 * (q)];                \
+                const double ae1 = Tw[arow + 4 * (q) + 4], ao1 = Tw[arow + kMxPitch + 4 * (q) + 4];        \
+                De0 = __builtin_amdgcn_mfma_f64_16x16x4f64(ae0, Be[r][(q)], De0, 0, 0, 0);                 \
+                Do0 = __builtin_amdgcn_mfma_f64_16x16x4f64(ao0, Bo[r][(q)], Do0, 0, 0, 0);                 \
+                De1 = __builtin_amdgcn_mfma_f64_16x16x4f64(ae1, Be[r][(q) + 1], De1, 0, 0, 0);             \
+                Do1 = __builtin_amdgcn_mfma_f64_16x16x4f64(ao1, Bo[r][(q) + 1], Do1, 0, 0, 0);             \
+                if (X9) {                                                                                  \
+                    fmac_row_bcast<(q)>(xer, g9[r][0], ae0);                                               \
+                    fmac_row_bcast<(q)>(xei, g9[r][1], ae0);                                               \
+                    fmac_row_bcast<(q)>(xor_, g9[r][2], ao0);                                              \
+                    fmac_row_bcast<(q)>(xoi, g9[r][3], ao0);                                               \
+                    fmac_row_bcast<(q) + 1>(xer, g9[r][0], ae1);                                           \
+                    fmac_row_bcast<(q) + 1>(xei, g9[r][1], ae1);                                           \
+                    fmac_row_bcast<(q) + 1>(xor_, g9[r][2], ao1);                                          \
+                    fmac_row_bcast<(q) + 1>(xoi, g9[r][3], ao1);                                           \
+                }                                                                                          \
             }
+            CMDR_MX_Q(0) CMDR_MX_Q(2) CMDR_MX_Q(4) CMDR_MX_Q(6) CMDR_MX_Q(8) CMDR_MX_Q(10) CMDR_MX_Q(12) CMDR_MX_Q(14)
+#undef CMDR_MX_Q
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
             __builtin_amdgcn_wave_barrier();
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");

@@ -40,7 +40,7 @@ out = {"command": "rocprofv3 --pmc FETCH_SIZE (and, separately, --pmc WRITE_SIZE
                                "adjoint_9maps": span("cmdr::k_leg_adj<4", nspan_adj) + span("cmdr::k_leg_adj_mx", nspan_adj)}}
 ls = out["legendre_span_bytes"]
 ls["mean"] = 0.5 * (ls["synth_9maps"] + ls["adjoint_9maps"])
-mx = kern.get("cmdr::k_leg_adj_mx")
+mx = next((v for k, v in kern.items() if k.startswith("cmdr::k_leg_adj_mx")), None)   # template arguments vary
 if mx:   # the dominant kernel of round 2: one launch = the Legendre adjoint of 8 maps on the matrix unit
     out["adjoint_launch_bytes"] = {"kernel": "cmdr::k_leg_adj_mx",
                                    "mean": (mx["FETCH_SIZE_KB_per_dispatch"] + mx["WRITE_SIZE_KB_per_dispatch"]) * 1024.0,
