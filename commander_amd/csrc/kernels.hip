@@ -40,8 +40,49 @@ __global__ void __launch_bounds__(256) k_leg_synth(LegArgs A, const WaveTask* __
 // staged through a double-buffered LDS tile of kTileL l values and read back as LDS broadcasts (uniform VGPR
 // operands): the scalar-cache miss bandwidth (~1.5 B/clk/CU, measured) that bounds k_leg_synth no longer enters.
 constexpr int kTileL = 32;
+// acc += a * g(lane Q of this lane's 16-lane row): gfx90a+ let fp64 VALU ops take src0 through the DPP row broadcast,
+// so the operand that is shared by the 16 l-rows of one pair costs no instruction and no LDS read of its own.
+template <int Q>
+__device__ __forceinline__ void fmac_row_bcast(double& acc, double g, double a) {
+    asm("v_fmac_f64_dpp %0, %1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf" : "+v"(acc) : "v"(g), "v"(a), "n"(Q));
+}
+
+// One l of the synthesis for R ring pairs per lane and NB maps, coefficients through DPP row broadcasts: C[c] holds, in
+// lane j of every 16-lane row, column c of tile row lb16 + j (a~ re / im of map c / 2), so step J takes lane J of the
+// row inside the FMA; alpha_{l+1} comes through the scalar unit.  Same operations in the same order as the LDS-broadcast loop.
+template <int R, int NB, bool INJECT, int J>
+__device__ __forceinline__ void synth_steps16(const double (&C)[2 * NB], const double* __restrict__ alp /* alpha_{lb16+1+j} */,
+                                              int lb16, const double (&x)[R], double (&mc)[R],
+                                              double (&mp)[R], const double (&sc)[R], const double (&sp)[R],
+                                              const int (&ls)[R], double (&Er)[R][NB], double (&Ei)[R][NB],
+                                              double (&Or)[R][NB], double (&Oi)[R][NB]) {
+    if constexpr (J < 16) {
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            if (INJECT) if (ls[r] == lb16 + J) { mc[r] = sc[r]; mp[r] = sp[r]; }   // phase A: lanes still switch on
+#pragma unroll
+            for (int k = 0; k < NB; ++k) {
+                if constexpr ((J & 1) == 0) {
+                    fmac_row_bcast<J>(Er[r][k], C[2 * k], mc[r]);
+                    fmac_row_bcast<J>(Ei[r][k], C[2 * k + 1], mc[r]);
+                } else {
+                    fmac_row_bcast<J>(Or[r][k], C[2 * k], mc[r]);
+                    fmac_row_bcast<J>(Oi[r][k], C[2 * k + 1], mc[r]);
+                }
+            }
+            const double ax = alp[J] * x[r];                   // alpha_{l+1} through the scalar unit
+            const double tt = ax * mc[r] - mp[r];
+            mp[r] = mc[r];
+            mc[r] = tt;
+        }
+        synth_steps16<R, NB, INJECT, J + 1>(C, alp, lb16, x, mc, mp, sc, sp, ls, Er, Ei, Or, Oi);
+    }
+}
+
 // PREP: the coefficient stream is not read from memory but formed while the tile is staged (k_band_prep folded in)
-template <int R, int NB, bool PREP>
+// DPPC: the tile is consumed 16 l at a time through DPP row broadcasts (synth_steps16) instead of one LDS broadcast read
+// per coefficient and l
+template <int R, int NB, bool PREP, bool DPPC>
 __global__ void __launch_bounds__(256, 3) k_leg_synth_wg(LegArgs A, const WaveTask* __restrict__ tasks, int ntasks,
                                                       const double* __restrict__ ast, int nbs, int k0, int rep,
                                                       double* __restrict__ ph, int64_t ph_stride, PrepDev P) {
@@ -153,6 +194,34 @@ __global__ void __launch_bounds__(256, 3) k_leg_synth_wg(LegArgs A, const WaveTa
         const int lb = lw0 + t * kTileL;
         if (t + 1 < ntile) fetch(lb + kTileL, pre);       // in flight while this tile is consumed
         if (chunk < 0 || lb + kTileL <= lw) continue;     // this wave has not started yet (wave-uniform)
+        if (DPPC) {
+            // 16-l blocks; a block that starts below lw runs with mu = 0 until the seeds are injected, rows beyond
+            // lmax + 1 hold zero coefficients (fetch), so neither end needs a bound
+            // (two loops one after the other, like phases A and B below: both bodies inside one loop would make the
+            // register allocator copy the 4 R NB accumulators between them on every pass)
+            int hb = 0;
+#pragma unroll 1
+            for (; hb < kTileL && lb + hb < lAend; hb += 16) {
+                const int lb16 = lb + hb;
+                if (lb16 + 16 <= lw || lb16 > lmax) continue;
+                double C[2 * NB];
+                const double* __restrict__ crow = cur + (hb + (lane & 15)) * ROW;
+#pragma unroll
+                for (int c = 0; c < 2 * NB; ++c) C[c] = crow[c];
+                synth_steps16<R, NB, true, 0>(C, al + lb16 + 1, lb16, x, mc, mp, sc, sp, ls, Er, Ei, Or, Oi);
+            }
+#pragma unroll 1
+            for (; hb < kTileL; hb += 16) {
+                const int lb16 = lb + hb;
+                if (lb16 + 16 <= lw || lb16 > lmax) continue;
+                double C[2 * NB];
+                const double* __restrict__ crow = cur + (hb + (lane & 15)) * ROW;
+#pragma unroll
+                for (int c = 0; c < 2 * NB; ++c) C[c] = crow[c];
+                synth_steps16<R, NB, false, 0>(C, al + lb16 + 1, lb16, x, mc, mp, sc, sp, ls, Er, Ei, Or, Oi);
+            }
+            continue;
+        }
         const int lend = min(lb + kTileL, lmax + 1);
         int l = max(lb, lw);
         for (; l < lend && l < lAend; l += 2) {           // Phase A: lanes switch on at their own ls
@@ -359,12 +428,6 @@ __device__ __forceinline__ void mx_recur(const double* __restrict__ al, int l0, 
 // m = 0, as the critical path of the launch).  The sub-blocks of a 256-pair task are dealt 0,3 | 1,2 to the two waves
 // (polar + equatorial against the two middle ones) and each wave skips the 32-l groups that lie below every start of
 // a sub-block, so the (m, ring) cut is honoured per 64 pairs, not per task.
-// acc += a * g(lane Q of this lane's 16-lane row): gfx90a+ let fp64 VALU ops take src0 through the DPP row broadcast,
-// so the operand that is shared by the 16 l-rows of one pair costs no instruction and no LDS read of its own.
-template <int Q>
-__device__ __forceinline__ void fmac_row_bcast(double& acc, double g, double a) {
-    asm("v_fmac_f64_dpp %0, %1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf" : "+v"(acc) : "v"(g), "v"(a), "n"(Q));
-}
 // X9: a ninth map (slot k0 + 8) rides along on the VALU: while the A operands of a 64-pair block are in registers
 // (lane = (l row, pair kq of quad q)), four FMAs per MFMA step multiply them with that map's N+S / N-S phases.  Those
 // sit in 8 registers per block, lane (row q', kq) holding pair 4 q' + kq, so that step q needs lane q of every 16-lane
@@ -545,15 +608,18 @@ int leg_max_batch(int R) { return leg_batch(R, false); }
 template <int R, int NB>
 static void synth_RN(const LegArgs& A, const WaveTask* tasks, int ntasks, const double* ast, int nbs, int k0, int rep,
                      double* ph, int64_t ph_stride, hipStream_t s, const PrepDev* prep) {
-    if (A.wg && NB <= 5 && prep)
-        hipLaunchKernelGGL((k_leg_synth_wg<R, (NB <= 5 ? NB : 5), true>), dim3((ntasks / 4) * rep), dim3(256), 0,
-                           s, A, tasks, ntasks, ast, nbs, k0, rep, ph, ph_stride, *prep);
-    else if (A.wg && NB <= 5)
-        hipLaunchKernelGGL((k_leg_synth_wg<R, (NB <= 5 ? NB : 5), false>), dim3((ntasks / 4) * rep), dim3(256), 0,
-                           s, A, tasks, ntasks, ast, nbs, k0, rep, ph, ph_stride, PrepDev{});
-    else
-        hipLaunchKernelGGL((k_leg_synth<R, NB>), dim3((ntasks / 4) * rep), dim3(256), 0, s, A, tasks, ntasks, ast, nbs,
-                           k0, rep, ph, ph_stride);
+    static const bool dppc = [] { const char* e = std::getenv("CMDR_SYNTH_DPP"); return !e || std::atoi(e) != 0; }();
+    constexpr int NBW = NB <= 5 ? NB : 5;
+    const dim3 grid((ntasks / 4) * rep);
+#define CMDR_WG(PP, DD) hipLaunchKernelGGL((k_leg_synth_wg<R, NBW, PP, DD>), grid, dim3(256), 0, s, A, tasks, ntasks, ast, nbs, \
+                                           k0, rep, ph, ph_stride, prep ? *prep : PrepDev{})
+    if (A.wg && NB <= 5) {
+        if (prep) { if (dppc) CMDR_WG(true, true); else CMDR_WG(true, false); }
+        else      { if (dppc) CMDR_WG(false, true); else CMDR_WG(false, false); }
+    } else {
+        hipLaunchKernelGGL((k_leg_synth<R, NB>), grid, dim3(256), 0, s, A, tasks, ntasks, ast, nbs, k0, rep, ph, ph_stride);
+    }
+#undef CMDR_WG
 }
 // balanced split of nmaps into batches of at most nbmax maps, e.g. 9 -> 3+3+3, 8 -> 3+3+2; consecutive batches of
 // equal size share one launch: calls f(nb, k0, rep)
