@@ -1,16 +1,16 @@
 """How the ranks of one chain split the amplitude-sampling matvec: A = 1 + S^1/2 sum_bands sum_rings (...)
 S^1/2 is a double sum, so ranks may own a subset of the bands, a subset of the ring pairs, or both (hybrid).  Pure ring
 sharding balances perfectly but shrinks the per-rank Legendre problem (256 ring pairs at Nside 1024 on 8 GPUs run at
-58 % of the single-GPU efficiency, measured with tools/cr_time_rank.py); pure band sharding keeps the kernels large
+63 % of the single-GPU efficiency, measured with tools/cr_time_rank.py); pure band sharding keeps the kernels large
 but balances badly (9 bands on 8 GPUs).  ``plan_shards`` picks the factorisation world = band_parts x ring_parts with
 the smallest estimated time."""
 
 # measured on MI355X at the cfg3 geometry with the round-2 kernels (tools/cr_time_rank.py; one rank's
-# matvec + invM: 8.85 ms alone, 4.96 / 2.92 / 1.91 ms as 1 of 2 / 4 / 8 ring sets with block ring ownership): compute
+# matvec + invM: 7.65 ms alone, 4.27 / 2.55 / 1.51 ms as 1 of 2 / 4 / 8 ring sets with block ring ownership): compute
 # efficiency of one rank's share under ring_parts-way ring sharding, and the penalty of holding fewer bands (smaller
 # map batches per launch: below 6 maps the adjoint leaves the matrix-unit kernel; measured before the last kernel
-# round as 2 x 2: 3.55 ms, 2 x 4: 2.20 ms, 4 x 2: 2.25 ms)
-RING_EFF = {1: 1.0, 2: 0.89, 4: 0.76, 8: 0.58}
+# round as 2 x 2: 3.55 ms, 4 x 2: 2.25 ms; 2 x 4 with the final kernels: 2.04 ms)
+RING_EFF = {1: 1.0, 2: 0.90, 4: 0.75, 8: 0.63}
 
 
 def _eff(r):
