@@ -86,7 +86,7 @@ template <int R, int NB, bool PREP, bool DPPC>
 __global__ void __launch_bounds__(256, 3) k_leg_synth_wg(LegArgs A, const WaveTask* __restrict__ tasks, int ntasks,
                                                       const double* __restrict__ ast, int nbs, int k0, int rep,
                                                       double* __restrict__ ph, int64_t ph_stride, PrepDev P) {
-    constexpr int ROW = 2 * NB + 2;                     // doubles per l: NB x (re, im), alpha_{l+1}, pad
+    constexpr int ROW = DPPC ? 2 * NB : 2 * NB + 2;     // doubles per l: NB x (re, im) [, alpha_{l+1}, pad: LDS form only]
     constexpr int NE = kTileL * ROW;                    // doubles per tile
     constexpr int NLD = (NE + 255) / 256;               // global loads per thread and tile
     __shared__ __attribute__((aligned(16))) double tile[2][NE];
@@ -146,8 +146,48 @@ __global__ void __launch_bounds__(256, 3) k_leg_synth_wg(LegArgs A, const WaveTa
         }
         __syncthreads();
     }
+    // One diffuse component and no varying-mixing term (the headline case): everything about a thread's tile elements
+    // but l is fixed, so the three addresses are formed once
+    const bool prep1 = PREP && P.ncomp == 1 && !P.extra;
+    const double* pw[NLD];
+    const double* psx[NLD];
+    int plm[NLD], prow[NLD];
+#pragma unroll
+    for (int i = 0; i < NLD; ++i) {
+        const int e = (int)threadIdx.x + 256 * i;
+        const int row = e / ROW, col = e - row * ROW;
+        prow[i] = row;
+        pw[i] = psx[i] = nullptr;
+        plm[i] = -1;
+        if (PREP && prep1 && e < NE && col < 2 * NB) {
+            const PrepTerm T = terms[col >> 1];
+            pw[i] = P.w + T.wo;
+            psx[i] = P.sx + T.sxo + (col & 1);
+            plm[i] = ((col & 1) && m == 0) ? -1 : min(T.lmaxc, lmax);
+        }
+    }
+    const double* __restrict__ pcn = PREP ? P.cnorm + (mo - m) : nullptr;
+    const double kap = m == 0 ? 1.0 : 0.70710678118654752440;
     // tile element e -> (row = l - lb, col): col < 2 NB: stream double, col == 2 NB: alpha_{l+1}
     auto fetch = [&](int lb, double* v) {
+        if (PREP && prep1) {
+#pragma unroll
+            for (int i = 0; i < NLD; ++i) {
+                const int l = lb + prow[i];
+                double val = 0.0;
+                if (l <= plm[i]) {
+                    const double wc = pw[i][l], t = psx[i][sl * l];
+                    double a = 0.0;
+                    if (wc != 0.0) a += wc * t;
+                    val = a * (pcn[l] * kap);
+                } else if (!DPPC && (int)threadIdx.x + 256 * i < NE && (int)threadIdx.x + 256 * i - prow[i] * ROW == 2 * NB &&
+                           l <= lmax + 1) {
+                    val = al[l + 1];
+                }
+                v[i] = val;
+            }
+            return;
+        }
 #pragma unroll
         for (int i = 0; i < NLD; ++i) {
             const int e = (int)threadIdx.x + 256 * i;
@@ -168,12 +208,12 @@ __global__ void __launch_bounds__(256, 3) k_leg_synth_wg(LegArgs A, const WaveTa
                                 const double t = P.sx[T.sxo + sl * l + part];
                                 if (wc != 0.0) v += wc * t;
                             }
-                            val = v * (P.cnorm[mo - m + l] * (m == 0 ? 1.0 : 0.70710678118654752440));
+                            val = v * (P.cnorm[mo - m + l] * kap);
                         }
                     } else {
                         val = as[ls2 * l + col];
                     }
-                } else if (col == 2 * NB) {
+                } else if (!DPPC && col == 2 * NB) {
                     val = al[l + 1];
                 }
             }
