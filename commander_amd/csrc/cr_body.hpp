@@ -404,5 +404,58 @@ CMDR_HD void cg_d_elem(const CompDev* __restrict__ comps, int ncomp, const doubl
         if (l <= comps[c].lmax) sqrtS_elem(comps[c], smat, 0, d, nullptr, sx, m, l, false);
 }
 
-}  // namespace cmdr
+// ---- the same three updates for ONE diffuse component with ONE map (the T-only headline): identical arithmetic, the
+// loops over components and Stokes blocks (runtime trip counts, small arrays indexed at run time) gone.
+CMDR_HD bool cg_single(const CompDev* __restrict__ comps, int ncomp) { return ncomp == 1 && comps[0].nmaps == 1; }
+// sqrtS_slot for nmaps = 1, kind 0, pass_inactive = false: out = fac * in (+ add where the component has a prior)
+CMDR_HD double cg_sqrtS1(const CompDev& C, const double* __restrict__ smat, int l, double v) {
+    if (!C.active) return 0.0;
+    if (C.lmax_cl < 0) return v;
+    if (l > C.lmax_cl) return 0.0;
+    double s = 0.0;
+    s += smat[C.smat_off + l] * v;
+    return s;
+}
+CMDR_HD double cg_q_elem1(const CompDev& C, const double* __restrict__ smat, const double* __restrict__ yc,
+                          const double* __restrict__ d, double* __restrict__ q, int m, int l) {
+    const int64_t i0 = C.pos + d_packed_index(C.lmax, l, m);
+    const bool addon = C.active && C.lmax_cl >= 0;
+    double acc = 0.0;
+    for (int sl = 0; sl < (m > 0 ? 2 : 1); ++sl) {
+        const double dv = d[i0 + sl];
+        const double o = cg_sqrtS1(C, smat, l, yc[i0 + sl]) + (addon ? dv : 0.0);
+        q[i0 + sl] = o;
+        acc += dv * o;
+    }
+    return acc;
+}
+CMDR_HD double cg_xr_elem1(const CompDev& C, const double* __restrict__ P, int lmax_pre, double alpha,
+                           double* __restrict__ x, double* __restrict__ r, const double* __restrict__ d,
+                           const double* __restrict__ q, double* __restrict__ s, int m, int l) {
+    const int64_t i0 = C.pos + d_packed_index(C.lmax, l, m);
+    const double p = P[d_moff(lmax_pre, m) + (l - m)];
+    double acc = 0.0;
+    for (int sl = 0; sl < (m > 0 ? 2 : 1); ++sl) {
+        const int64_t i = i0 + sl;
+        x[i] += alpha * d[i];
+        double rn = r[i];
+        rn -= alpha * q[i];
+        r[i] = rn;
+        double sv = 0.0;
+        sv += p * rn;
+        s[i] = sv;
+        acc += rn * sv;
+    }
+    return acc;
+}
+CMDR_HD void cg_d_elem1(const CompDev& C, const double* __restrict__ smat, double beta, double* __restrict__ d,
+                        const double* __restrict__ s, double* __restrict__ sx, int m, int l) {
+    const int64_t i0 = C.pos + d_packed_index(C.lmax, l, m);
+    for (int sl = 0; sl < (m > 0 ? 2 : 1); ++sl) {
+        const double dn = s[i0 + sl] + beta * d[i0 + sl];
+        d[i0 + sl] = dn;
+        sx[i0 + sl] = cg_sqrtS1(C, smat, l, dn);
+    }
+}
 
+}  // namespace cmdr

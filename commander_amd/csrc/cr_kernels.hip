@@ -292,7 +292,12 @@ __global__ void __launch_bounds__(256) k_cg_q(const CompDev* __restrict__ comps,
                                               const double* __restrict__ d, double* __restrict__ q,
                                               double* __restrict__ p_dq) {
     double acc = 0.0;
-    cg_stride(lmax, [&](int m, int l) { acc += cg_q_elem(comps, ncomp, smat, yc, d, q, m, l); });
+    if (cg_single(comps, ncomp)) {
+        const CompDev C = comps[0];
+        cg_stride(lmax, [&](int m, int l) { acc += cg_q_elem1(C, smat, yc, d, q, m, l); });
+    } else {
+        cg_stride(lmax, [&](int m, int l) { acc += cg_q_elem(comps, ncomp, smat, yc, d, q, m, l); });
+    }
     const double r = block_sum_256(acc);
     if (threadIdx.x == 0) p_dq[blockIdx.x] = r;
 }
@@ -307,7 +312,12 @@ __global__ void __launch_bounds__(256) k_cg_xr_precond(const CompDev* __restrict
     const double alpha = fold_partials(p_rs_old) / dq;                                  // comm_cr_mod.f90:254
     if (blockIdx.x == 0 && threadIdx.x == 0) scal[2] = dq;
     double acc = 0.0;
-    cg_stride(lmax, [&](int m, int l) { acc += cg_xr_elem(comps, ncomp, P, lmax, nmaps_pre, alpha, x, r, d, q, s, m, l); });
+    if (cg_single(comps, ncomp) && nmaps_pre == 1) {
+        const CompDev C = comps[0];
+        cg_stride(lmax, [&](int m, int l) { acc += cg_xr_elem1(C, P, lmax, alpha, x, r, d, q, s, m, l); });
+    } else {
+        cg_stride(lmax, [&](int m, int l) { acc += cg_xr_elem(comps, ncomp, P, lmax, nmaps_pre, alpha, x, r, d, q, s, m, l); });
+    }
     const double t = block_sum_256(acc);
     if (threadIdx.x == 0) p_rs[blockIdx.x] = t;
 }
@@ -320,7 +330,12 @@ __global__ void __launch_bounds__(256) k_cg_d_sqrtS(const CompDev* __restrict__ 
     const double dold = fold_partials(p_rs_old), dnew = fold_partials(p_rs);
     const double beta = dnew / dold;                                                    // :270-271
     if (blockIdx.x == 0 && threadIdx.x == 0) { scal[0] = dnew; scal[1] = dold; }
-    cg_stride(lmax, [&](int m, int l) { cg_d_elem(comps, ncomp, smat, beta, d, s, sx, m, l); });
+    if (cg_single(comps, ncomp)) {
+        const CompDev C = comps[0];
+        cg_stride(lmax, [&](int m, int l) { cg_d_elem1(C, smat, beta, d, s, sx, m, l); });
+    } else {
+        cg_stride(lmax, [&](int m, int l) { cg_d_elem(comps, ncomp, smat, beta, d, s, sx, m, l); });
+    }
 }
 // p[0] = scal[slot], p[1..] = 0: a dot product computed by launch_dot enters the partial-sum protocol
 __global__ void k_cg_seed(const double* __restrict__ scal, int slot, double* __restrict__ p) {

@@ -42,6 +42,9 @@ __global__ void __launch_bounds__(256) k_leg_synth(LegArgs A, const WaveTask* __
 constexpr int kTileL = 32;
 // acc += a * g(lane Q of this lane's 16-lane row): gfx90a+ let fp64 VALU ops take src0 through the DPP row broadcast,
 // so the operand that is shared by the 16 l-rows of one pair costs no instruction and no LDS read of its own.
+// (Hazard note: a VGPR written by a VALU instruction must not be read through DPP by one of the next two instructions;
+// the hazard recogniser cannot see inside inline asm.  Both users pass registers filled by LDS / global loads long
+// before -- the parity tests at full size are the check that a future compiler does not slip a copy in between.)
 template <int Q>
 __device__ __forceinline__ void fmac_row_bcast(double& acc, double g, double a) {
     asm("v_fmac_f64_dpp %0, %1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf" : "+v"(acc) : "v"(g), "v"(a), "n"(Q));

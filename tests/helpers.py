@@ -455,13 +455,15 @@ def fused_staging_checks(_lib=None, nside=128, lmax=24, tol=1e-12):
     assert rel(ctx.cr_invM(x), S.invM(x)) < 10 * tol
 
 
-def fused_pcg_checks(_lib, pol, monkeypatch, nside=16, lmax=32):
+def fused_pcg_checks(_lib, pol, monkeypatch, nside=16, lmax=32, cfg="cfg2"):
     """solve_cr_eqn_by_CG with the three fused vector kernels per iteration (S^1/2 yc + d with d.q; x, r, M^-1 r with
     r.s; d with the next S^1/2 d) against the one-kernel-per-line sequence (CMDR_CG_FUSED=0) and the oracle, with
     different lmax per component and the chisq criterion (whose evaluation overwrites the S^1/2 buffer)."""
     from commander_amd import synth
     from commander_amd.cr import build_context
-    spec = synth.make_problem("cfg2", nside=nside, lmax=lmax, pol=pol, comp_lmax=[lmax, lmax - 8])
+    # cfg3 = nine bands, one T-only component: the kernels' single-component form; cfg2: the general one
+    spec = synth.make_problem(cfg, nside=nside, lmax=lmax, pol=pol,
+                              comp_lmax=[lmax, lmax - 8] if cfg == "cfg2" else None)
     S = oracle_system(spec)
     ctx = build_context(spec, _lib=_lib)
     ctx.initPrecond()

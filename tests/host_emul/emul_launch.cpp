@@ -358,7 +358,8 @@ void launch_cg_q(const CompDev* comps, int ncomp, int lmax, const double* smat, 
                  double* q, double* p_dq, hipStream_t) {
     double acc = 0.0;
     for (int m = 0; m <= lmax; ++m)
-        for (int l = m; l <= lmax; ++l) acc += cg_q_elem(comps, ncomp, smat, yc, d, q, m, l);
+        for (int l = m; l <= lmax; ++l)
+            acc += cg_single(comps, ncomp) ? cg_q_elem1(comps[0], smat, yc, d, q, m, l) : cg_q_elem(comps, ncomp, smat, yc, d, q, m, l);
     put_partial(p_dq, acc);
 }
 void launch_cg_xr_precond(const CompDev* comps, int ncomp, int lmax, const double* P, int nmaps_pre, const double* p_dq,
@@ -368,7 +369,9 @@ void launch_cg_xr_precond(const CompDev* comps, int ncomp, int lmax, const doubl
     scal[2] = dq;
     double acc = 0.0;
     for (int m = 0; m <= lmax; ++m)
-        for (int l = m; l <= lmax; ++l) acc += cg_xr_elem(comps, ncomp, P, lmax, nmaps_pre, alpha, x, r, d, q, sv, m, l);
+        for (int l = m; l <= lmax; ++l)
+            acc += cg_single(comps, ncomp) && nmaps_pre == 1 ? cg_xr_elem1(comps[0], P, lmax, alpha, x, r, d, q, sv, m, l)
+                                                             : cg_xr_elem(comps, ncomp, P, lmax, nmaps_pre, alpha, x, r, d, q, sv, m, l);
     put_partial(p_rs, acc);
 }
 void launch_cg_d_sqrtS(const CompDev* comps, int ncomp, int lmax, const double* smat, const double* p_rs_old,
@@ -377,7 +380,10 @@ void launch_cg_d_sqrtS(const CompDev* comps, int ncomp, int lmax, const double* 
     scal[0] = dnew;
     scal[1] = dold;
     for (int m = 0; m <= lmax; ++m)
-        for (int l = m; l <= lmax; ++l) cg_d_elem(comps, ncomp, smat, dnew / dold, d, sv, sx, m, l);
+        for (int l = m; l <= lmax; ++l) {
+            if (cg_single(comps, ncomp)) cg_d_elem1(comps[0], smat, dnew / dold, d, sv, sx, m, l);
+            else cg_d_elem(comps, ncomp, smat, dnew / dold, d, sv, sx, m, l);
+        }
 }
 void launch_cg_xr(double* x, double* r, const double* d, const double* q, int64_t n, const double* scal, int num,
                   int den, hipStream_t) {

@@ -372,7 +372,7 @@ def test_coefficients_formed_in_the_synthesis_staging_gpu():
     fused_staging_checks(None, tol=1e-11)
 
 
-@pytest.mark.parametrize("pol", [False, True])
-def test_fused_pcg_updates_equal_the_general_sequence_gpu(pol, monkeypatch):
+@pytest.mark.parametrize("cfg,pol", [("cfg2", False), ("cfg2", True), ("cfg3", False)])
+def test_fused_pcg_updates_equal_the_general_sequence_gpu(cfg, pol, monkeypatch):
     from helpers import fused_pcg_checks
-    fused_pcg_checks(None, pol, monkeypatch, nside=32, lmax=64)
+    fused_pcg_checks(None, pol, monkeypatch, nside=32, lmax=64, cfg=cfg)

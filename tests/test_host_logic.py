@@ -476,10 +476,10 @@ def test_emul_coefficients_formed_in_the_synthesis_staging(EL):
     fused_staging_checks(EL)
 
 
-@pytest.mark.parametrize("pol", [False, True])
-def test_emul_fused_pcg_updates_equal_the_general_sequence(EL, pol, monkeypatch):
+@pytest.mark.parametrize("cfg,pol", [("cfg2", False), ("cfg2", True), ("cfg3", False)])
+def test_emul_fused_pcg_updates_equal_the_general_sequence(EL, cfg, pol, monkeypatch):
     from helpers import fused_pcg_checks
-    fused_pcg_checks(EL, pol, monkeypatch)
+    fused_pcg_checks(EL, pol, monkeypatch, cfg=cfg)
 
 
 @pytest.mark.parametrize("R,Rs", [(4, 2), (4, 1), (2, 1), (1, 1)])
