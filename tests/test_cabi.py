@@ -50,3 +50,20 @@ def test_product_never_imports_oracle():
             assert not re.search(r"^\s*(from|import)\s+oracle\b", txt, flags=re.M), path
             if not path.endswith(".py"):
                 assert "sht_oracle" not in txt and "oracle/" not in txt.replace("tests/host_emul", ""), path
+
+
+def test_hand_written_dpp_fmas_keep_their_hazard_distance():
+    """The synthesis and the ninth-map accumulation of the adjoint use v_fmac_f64_dpp through inline asm, which the
+    compiler's hazard recogniser cannot pad: tools/check_dpp_hazards.py compiles kernels.hip to assembly and checks
+    that no DPP operand was written by a VALU instruction within the two instructions before it."""
+    import os
+    import subprocess
+    import sys
+    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    if not os.path.exists(hipcc):
+        pytest.skip("hipcc not available")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "tools", "check_dpp_hazards.py")], capture_output=True, text=True,
+                       timeout=900)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert " 0 hazards" in r.stdout and not r.stdout.startswith("0 DPP"), r.stdout
