@@ -20,7 +20,10 @@ def _eff(r):
 
 
 def _band_penalty(nb):
-    return 1.0 if nb >= 9 else (1.25 if nb >= 5 else (1.28 if nb >= 3 else (1.35 if nb == 2 else 1.4)))
+    # cost per band relative to a rank that holds all nine: 5 bands on 1/4 of the rings take 2.04 ms where 9 take 2.55
+    # (1.44 per band: below 6 maps the adjoint leaves the matrix-unit kernel, the synthesis runs one batch of 5); fewer
+    # bands were last measured with the first-half kernels (3 bands on 1/2 of the rings: 2.25 ms) and are scaled likewise
+    return 1.0 if nb >= 9 else (1.44 if nb >= 5 else (1.4 if nb >= 3 else (1.5 if nb == 2 else 1.55)))
 
 
 def plan_shards(nband, world):
