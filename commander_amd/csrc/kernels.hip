@@ -630,6 +630,120 @@ __global__ void __launch_bounds__(128) k_leg_adj_mx(LegArgs A, const WaveTask* _
     }
 }
 
+// ---- adjoint of 1..7 maps without the matrix unit: the same task shape, recursion and LDS transposition as k_leg_adj_mx,
+// and for EVERY map the accumulation k_leg_adj_mx<.., X9> uses for its ninth: lane = (l row, pair kq of quad q), the
+// map's N+S / N-S phases in 4 registers per 64-pair block with lane (row q', kq) holding pair 4 q' + kq, four
+// v_fmac_f64_dpp row_newbcast:q per map and step.  2 + 2 NB fp64 operations per (ring pair, l) -- what the synthesis
+// needs -- against ~4.8 per map in k_leg_adj (wave-wide reductions) and a fixed 8-map price in k_leg_adj_mx.  The four
+// pair lanes of a row are folded with two half / row swaps per map (swap_halves, swap_rows), which also packs a map's
+// four sums into one register: row 0 = even-l re, 1 = odd-l re, 2 = even-l im, 3 = odd-l im.
+template <int NR, int NB>
+__global__ void __launch_bounds__(128) k_leg_adj_dx(LegArgs A, const WaveTask* __restrict__ tasks, int ntasks,
+                                                    const double* __restrict__ ph, int64_t ph_stride, int k0,
+                                                    double* __restrict__ part, int64_t part_map_stride,
+                                                    int64_t part_chunk_stride) {
+    __shared__ __attribute__((aligned(16))) double tile[2][kMxL * kMxPitch];
+    const int wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    if ((int)blockIdx.x >= ntasks) return;
+    const WaveTask T = tasks[blockIdx.x];
+    if (T.chunk < 0) return;
+    const int m = __builtin_amdgcn_readfirstlane(T.m);
+    const int chunk = __builtin_amdgcn_readfirstlane(T.chunk);
+    const int lw = __builtin_amdgcn_readfirstlane(T.lw);
+    const int lAend = __builtin_amdgcn_readfirstlane(T.lAend);
+    const int lmax = A.lmax;
+    const int kq = lane >> 4, row = lane & 15;
+    int pb[NR];
+#pragma unroll
+    for (int r = 0; r < NR; ++r) {
+        const int sub = NR == 1 ? wid : (wid == 0 ? 3 * r : 1 + r);
+        pb[r] = chunk * (128 * NR) + sub * 64;
+    }
+    double x[NR], mc[NR], mp[NR], sc[NR], sp[NR];
+    int ls[NR], lwr[NR];
+    double g[NR][NB][4];
+#pragma unroll
+    for (int r = 0; r < NR; ++r) {
+        const int p = pb[r] + lane;
+        const int64_t idx = (int64_t)m * A.npair_pad + p;
+        x[r] = A.x[p];
+        ls[r] = A.ls[idx];
+        sc[r] = A.seedc[idx];
+        sp[r] = A.seedp[idx];
+        mc[r] = mp[r] = 0.0;
+        int v = ls[r];
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) v = min(v, __shfl_xor(v, o));
+        lwr[r] = __builtin_amdgcn_readfirstlane(v);
+#pragma unroll
+        for (int k = 0; k < NB; ++k) {
+            const double* gp = ph + (int64_t)(k0 + k) * ph_stride + d_phidx(lmax + 1, pb[r] + 4 * row + kq, m);
+            g[r][k][0] = gp[0] + gp[2];
+            g[r][k][1] = gp[1] + gp[3];
+            g[r][k][2] = gp[0] - gp[2];
+            g[r][k][3] = gp[1] - gp[3];
+        }
+    }
+    const int64_t mo = d_moffp(lmax, m);
+    const double* __restrict__ al = A.alpha + (mo - m);
+    // this lane's output slot: row pair (kq & 1) = parity of l, (kq >> 1) = re / im
+    double* __restrict__ outp = part + chunk * part_chunk_stride + 2 * (mo - m) + (int64_t)k0 * part_map_stride + (kq >> 1);
+    double* __restrict__ Tw = tile[wid];
+    const double* __restrict__ To = tile[1 - wid];
+    const int arow = row * 2 * kMxPitch + kq;
+    for (int l0 = lw; l0 <= lmax; l0 += kMxL) {
+        double acc[NB][4];
+#pragma unroll
+        for (int k = 0; k < NB; ++k) acc[k][0] = acc[k][1] = acc[k][2] = acc[k][3] = 0.0;
+#pragma unroll
+        for (int r = 0; r < NR; ++r) {
+            if (l0 + kMxL <= lwr[r]) continue;
+            if (l0 < lAend) mx_recur<true>(al, l0, x[r], mc[r], mp[r], sc[r], sp[r], ls[r], Tw + lane);
+            else            mx_recur<false>(al, l0, x[r], mc[r], mp[r], sc[r], sp[r], ls[r], Tw + lane);
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#define CMDR_DX_Q(q)                                                                                       \
+            {                                                                                              \
+                const double ae = Tw[arow + 4 * (q)], ao = Tw[arow + kMxPitch + 4 * (q)];                  \
+                _Pragma("unroll") for (int k = 0; k < NB; ++k) {                                           \
+                    fmac_row_bcast<(q)>(acc[k][0], g[r][k][0], ae);                                        \
+                    fmac_row_bcast<(q)>(acc[k][1], g[r][k][1], ae);                                        \
+                    fmac_row_bcast<(q)>(acc[k][2], g[r][k][2], ao);                                        \
+                    fmac_row_bcast<(q)>(acc[k][3], g[r][k][3], ao);                                        \
+                }                                                                                          \
+            }
+            CMDR_DX_Q(0) CMDR_DX_Q(1) CMDR_DX_Q(2) CMDR_DX_Q(3) CMDR_DX_Q(4) CMDR_DX_Q(5) CMDR_DX_Q(6) CMDR_DX_Q(7)
+            CMDR_DX_Q(8) CMDR_DX_Q(9) CMDR_DX_Q(10) CMDR_DX_Q(11) CMDR_DX_Q(12) CMDR_DX_Q(13) CMDR_DX_Q(14) CMDR_DX_Q(15)
+#undef CMDR_DX_Q
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        }
+        // fold the four pair lanes (kq) of every row; t[k]: 16-lane row 0 = even-l re, 1 = odd-l re, 2 = even-l im, 3 = odd-l im
+        double t[NB];
+#pragma unroll
+        for (int k = 0; k < NB; ++k) {
+            double a0 = acc[k][0], a1 = acc[k][1], a2 = acc[k][2], a3 = acc[k][3];
+            swap_halves(a0, a1);
+            swap_halves(a2, a3);
+            double s01 = a0 + a1, s23 = a2 + a3;     // rows: s01 = e_re(0+2), e_re(1+3), e_im(0+2), e_im(1+3); s23 likewise odd
+            swap_rows(s01, s23);
+            t[k] = s01 + s23;
+            Tw[k * 64 + lane] = t[k];
+        }
+        __syncthreads();
+        // wave 0 writes the even-l rows (0, 2), wave 1 the odd-l ones (1, 3): this wave's sub-blocks + the other wave's
+        const int l = l0 + 2 * row + (kq & 1);
+        if ((kq & 1) == wid && l <= lmax) {
+#pragma unroll
+            for (int k = 0; k < NB; ++k) outp[(int64_t)k * part_map_stride + 2 * l] = t[k] + To[k * 64 + lane];
+        }
+        __syncthreads();
+    }
+}
+
 // maps sharing one recursion per wave (register budget).  Tuning knobs: CMDR_LEG_NB caps both kernels,
 // CMDR_LEG_NB_S / CMDR_LEG_NB_A set the synthesis / adjoint value (up to the compiled maximum).
 static int leg_batch(int R, bool adjoint, bool wg = false) {
@@ -719,12 +833,15 @@ void launch_leg_adj(const LegArgs& A, const WaveTask* tasks, int ntasks, const d
         }
         return;
     }
-    // matrix-unit form for batches of up to 8 maps (plans with 256-pair chunks); the rest through the VALU kernel
-    static const int mx_min = [] { const char* e = std::getenv("CMDR_ADJ_MX"); return e ? std::atoi(e) : 6; }();
+    // 6..8 maps (9 with the last one riding along) per launch on the matrix unit; 3..5 maps through the DPP form of the
+    // same task (k_leg_adj_dx: 1.25 + 0.23 nb ms at the cfg3 geometry against a flat 2.47 ms); 1..2 maps, plans with one
+    // ring pair per lane and `square` through the VALU kernel k_leg_adj (0.93 ms per map)
+    const int mx_min = [] { const char* e = std::getenv("CMDR_ADJ_MX"); return e ? std::atoi(e) : 6; }();   // read per call (test hook)
+    const bool x9_on = [] { const char* e = std::getenv("CMDR_ADJ_X9"); return !e || std::atoi(e) != 0; }();
+    const bool dx_on = [] { const char* e = std::getenv("CMDR_ADJ_DX"); return !e || std::atoi(e) != 0; }();
     int kdone = 0, nmx = 0;
     if ((A.R == 4 || A.R == 2) && mx_min > 0)
         for (int left = nmaps; left >= mx_min; left -= std::min(8, left)) nmx += std::min(8, left);
-    static const bool x9_on = [] { const char* e = std::getenv("CMDR_ADJ_X9"); return !e || std::atoi(e) != 0; }();
     while (kdone < nmx) {
         const int nb = std::min(8, nmx - kdone);
         const bool x9 = x9_on && nb == 8 && nmaps - (kdone + 8) == 1;    // a single map left over rides along
@@ -737,6 +854,17 @@ void launch_leg_adj(const LegArgs& A, const WaveTask* tasks, int ntasks, const d
     }
     if (between) between(kdone);
     if (kdone == nmaps) return;
+    if (dx_on && (A.R == 4 || A.R == 2) && nmaps - kdone >= 3) {
+        const int nb = nmaps - kdone;       // 3..5 (6 and more went to the matrix unit), or up to 7 with CMDR_ADJ_MX raised
+#define CMDR_DX(NN) case NN:                                                                                              \
+        if (A.R == 4) hipLaunchKernelGGL((k_leg_adj_dx<2, NN>), dim3(ntasks), dim3(128), 0, s, A, tasks, ntasks, ph,      \
+                                         ph_stride, kdone, part, pms, pcs);                                               \
+        else          hipLaunchKernelGGL((k_leg_adj_dx<1, NN>), dim3(ntasks), dim3(128), 0, s, A, tasks, ntasks, ph,      \
+                                         ph_stride, kdone, part, pms, pcs);                                               \
+        return;
+        switch (nb) { CMDR_DX(3) CMDR_DX(4) CMDR_DX(5) CMDR_DX(6) CMDR_DX(7) default: break; }
+#undef CMDR_DX
+    }
     ph += (int64_t)kdone * ph_stride;
     part += (int64_t)kdone * pms;
     nmaps -= kdone;

@@ -1,16 +1,15 @@
 """How the ranks of one chain split the amplitude-sampling matvec: A = 1 + S^1/2 sum_bands sum_rings (...)
 S^1/2 is a double sum, so ranks may own a subset of the bands, a subset of the ring pairs, or both (hybrid).  Pure ring
 sharding balances perfectly but shrinks the per-rank Legendre problem (256 ring pairs at Nside 1024 on 8 GPUs run at
-63 % of the single-GPU efficiency, measured with tools/cr_time_rank.py); pure band sharding keeps the kernels large
+64 % of the single-GPU efficiency, measured with tools/cr_time_rank.py); pure band sharding keeps the kernels large
 but balances badly (9 bands on 8 GPUs).  ``plan_shards`` picks the factorisation world = band_parts x ring_parts with
 the smallest estimated time."""
 
 # measured on MI355X at the cfg3 geometry with the round-2 kernels (tools/cr_time_rank.py; one rank's
-# matvec + invM: 7.65 ms alone, 4.27 / 2.55 / 1.51 ms as 1 of 2 / 4 / 8 ring sets with block ring ownership): compute
-# efficiency of one rank's share under ring_parts-way ring sharding, and the penalty of holding fewer bands (smaller
-# map batches per launch: below 6 maps the adjoint leaves the matrix-unit kernel; measured before the last kernel
-# round as 2 x 2: 3.55 ms, 4 x 2: 2.25 ms; 2 x 4 with the final kernels: 2.04 ms)
-RING_EFF = {1: 1.0, 2: 0.90, 4: 0.75, 8: 0.63}
+# matvec + invM: 7.5 ms alone, 4.27 / 2.55 / 1.46 ms as 1 of 2 / 4 / 8 ring sets with block ring ownership, 1.60 ms as 1
+# of 16: 128 pairs leave the synthesis without its workgroup form): compute efficiency of one rank's share under
+# ring_parts-way ring sharding
+RING_EFF = {1: 1.0, 2: 0.88, 4: 0.735, 8: 0.64}
 
 
 def _eff(r):
@@ -20,10 +19,10 @@ def _eff(r):
 
 
 def _band_penalty(nb):
-    # cost per band relative to a rank that holds all nine: 5 bands on 1/4 of the rings take 2.04 ms where 9 take 2.55
-    # (1.44 per band: below 6 maps the adjoint leaves the matrix-unit kernel, the synthesis runs one batch of 5); fewer
-    # bands were last measured with the first-half kernels (3 bands on 1/2 of the rings: 2.25 ms) and are scaled likewise
-    return 1.0 if nb >= 9 else (1.44 if nb >= 5 else (1.4 if nb >= 3 else (1.5 if nb == 2 else 1.55)))
+    # cost per band relative to a rank that holds all nine (smaller map batches per launch: 3..5 maps take the DPP form
+    # of the adjoint, 1..2 the VALU kernel, the synthesis runs one batch).  Measured per-rank shares: 2 x 4: 1.68 ms,
+    # 2 x 8: 1.06 ms (5 bands: 1.19 / 1.30); 4 x 2: 2.04 ms, 4 x 4: 1.26 ms (3 bands: 1.44 / 1.48); fewer bands scaled
+    return 1.0 if nb >= 9 else (1.25 if nb >= 5 else (1.46 if nb >= 3 else (1.55 if nb == 2 else 1.6)))
 
 
 def plan_shards(nband, world):

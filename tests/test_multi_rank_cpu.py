@@ -140,7 +140,7 @@ def test_four_rank_band_ring_hybrid_matches_single_rank(tmp_path):
     from helpers import emul_lib, rel
     from commander_amd import synth, shard
     from commander_amd.cr import build_context
-    assert shard.plan_shards(9, 8) == (1, 8) and shard.plan_shards(9, 16) == (4, 4) and shard.plan_shards(9, 4) == (1, 4) and shard.plan_shards(9, 1) == (1, 1)
+    assert shard.plan_shards(9, 8) == (1, 8) and shard.plan_shards(9, 16) == (2, 8) and shard.plan_shards(9, 4) == (1, 4) and shard.plan_shards(9, 1) == (1, 1)
     emul_lib()
     s = socket.socket()
     s.bind(("127.0.0.1", 0))

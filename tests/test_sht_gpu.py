@@ -131,3 +131,26 @@ def test_matrix_unit_adjoint_both_task_sizes(R, oracle_lib, monkeypatch):
     yts = sub.Yt(np.ascontiguousarray(m[pix]))
     for k in (0, 8):
         assert rel(yts[:, k], oracle_lib.Yt(nside, lmax, full[:, k])) < 1e-12
+
+
+@pytest.mark.parametrize("R", [4, 2])
+def test_dpp_adjoint_all_batch_sizes(R, oracle_lib, monkeypatch):
+    """3..5 maps per call go through k_leg_adj_dx (the matrix-unit kernel's task with every map accumulated by DPP
+    row-broadcast FMAs; 6 and 7 too once CMDR_ADJ_MX is raised), at 4 and 2 ring pairs per lane; 1, 2 and the 2 left over
+    of 10 through the VALU kernel."""
+    from commander_amd.sht import ShtPlan
+    monkeypatch.setenv("CMDR_LEG_R", str(R))
+    monkeypatch.setenv("CMDR_ADJ_MX", "8")
+    nside, lmax = 256, 300
+    rng = np.random.default_rng(40 + R)
+    m = rng.standard_normal((12 * nside * nside, 10))
+    ref = {k: oracle_lib.Yt(nside, lmax, m[:, k]) for k in (0, 3, 6, 9)}
+    for nm in (1, 2, 3, 4, 5, 6, 7, 10):
+        plan = ShtPlan(nside, lmax, max_maps=nm)
+        yt = plan.Yt(np.ascontiguousarray(m[:, :nm]))
+        if nm == 1:
+            yt = yt.reshape(-1, 1)
+        for k in ref:
+            if k < nm:
+                assert rel(yt[:, k], ref[k]) < 1e-12, (nm, k)
+        plan.close()
