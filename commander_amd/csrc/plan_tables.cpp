@@ -17,8 +17,11 @@ static inline double eps_lm(int l, int m) {
     return std::sqrt((dl * dl - dm * dm) / (4.0 * dl * dl - 1.0));
 }
 
-// |mu| must reach 2^kStartExp before a (m, pair) column is switched on; everything below is dropped (1e-84).
-static constexpr int kStartExp = -280;
+// |mu| must reach 2^kStartExp before a (m, pair) column is switched on; everything below is dropped.  2^-100 = 8e-31 of
+// the O(1) plateau the recursion grows into: fourteen orders of magnitude below the fp64 rounding of the sums these
+// terms would enter (the first version waited only for representability, 2^-280, and ran 5 % more steps; every parity
+// test holds at either value).  CMDR_START_EXP overrides it for experiments.
+static const int kStartExp = [] { const char* e = std::getenv("CMDR_START_EXP"); return e ? std::atoi(e) : -100; }();
 
 void LegendreTables::build(int lmax_, const std::vector<double>& x_, const std::vector<double>& sth_, int R_,
                            int Rs_, int nthreads, const std::vector<int>* mlim_in) {
@@ -121,10 +124,20 @@ void LegendreTables::build(int lmax_, const std::vector<double>& x_, const std::
                     lo = std::min(lo, v);
                     hi = std::max(hi, v);
                 }
-                if (hi < 0) continue;
                 WaveTask t;
                 t.m = m;
                 t.chunk = ch;
+                if (hi < 0) {
+                    // no pair of the chunk reaches the start threshold by lmax.  Inside the (m, ring) cut the task is
+                    // kept with an empty l range: the ring stage reads every entry with m <= mlim, so the synthesis
+                    // must write its zeros (the adjoint of such a task writes nothing; its columns are skipped)
+                    bool inside = false;
+                    for (int p = ch * pr; p < (ch + 1) * pr; ++p) inside = inside || m <= mlim[p];
+                    if (!inside) continue;
+                    t.lw = t.lAend = lmax + 1 + ((lmax + 1 - m) & 1);
+                    out[m].push_back(t);
+                    continue;
+                }
                 t.lw = lo - ((lo - m) & 1);
                 int a = hi + 1;
                 a += (a - m) & 1;
@@ -165,9 +178,10 @@ void LegendreTables::build(int lmax_, const std::vector<double>& x_, const std::
                 Grp G;
                 G.lw = lmax + 2;
                 for (int k = 0; k < 4; ++k) { G.t[k].m = m; G.t[k].chunk = -1; G.t[k].lw = lmax + 2; G.t[k].lAend = lmax + 2; }
+                bool any = false;
                 for (const WaveTask& t : tm[m])
-                    if (t.chunk / 4 == g) { G.t[t.chunk % 4] = t; G.lw = std::min(G.lw, t.lw); }
-                if (G.lw <= lmax) groups.push_back(G);
+                    if (t.chunk / 4 == g) { G.t[t.chunk % 4] = t; G.lw = std::min(G.lw, t.lw); any = true; }
+                if (any) groups.push_back(G);   // also groups of empty tasks: they write the zeros the ring stage reads
             }
         std::stable_sort(groups.begin(), groups.end(), [](const Grp& a, const Grp& b) { return a.lw < b.lw; });
         for (const Grp& G : groups) tasks_s.insert(tasks_s.end(), G.t, G.t + 4);
