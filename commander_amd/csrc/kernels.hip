@@ -85,7 +85,9 @@ __device__ __forceinline__ void synth_steps16(const double (&C)[2 * NB], const d
 // PREP: the coefficient stream is not read from memory but formed while the tile is staged (k_band_prep folded in)
 // DPPC: the tile is consumed 16 l at a time through DPP row broadcasts (synth_steps16) instead of one LDS broadcast read
 // per coefficient and l
-template <int R, int NB, bool PREP, bool DPPC>
+// UNI (with DPPC): the plan starts every 64-pair lane block at one l == m (mod 32), so seeds are injected once per block
+// at a 16-l block boundary and the stepping code carries no per-l start test at all
+template <int R, int NB, bool PREP, bool DPPC, bool UNI>
 __global__ void __launch_bounds__(256, 3) k_leg_synth_wg(LegArgs A, const WaveTask* __restrict__ tasks, int ntasks,
                                                       const double* __restrict__ ast, int nbs, int k0, int rep,
                                                       double* __restrict__ ph, int64_t ph_stride, PrepDev P) {
@@ -127,6 +129,16 @@ __global__ void __launch_bounds__(256, 3) k_leg_synth_wg(LegArgs A, const WaveTa
         mc[r] = mp[r] = 0.0;
 #pragma unroll
         for (int k = 0; k < NB; ++k) Er[r][k] = Ei[r][k] = Or[r][k] = Oi[r][k] = 0.0;
+    }
+    int lwr[R];                                          // UNI: the common start of lane block r (wave-uniform)
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        int v = ls[r];
+        if (UNI) {
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) v = min(v, __shfl_xor(v, o));
+        }
+        lwr[r] = __builtin_amdgcn_readfirstlane(v);
     }
     // PREP: per (map of this batch, component) where the component's (l = 0, m) entry sits in sx (the packed index is
     // linear in l within one m), where its weight row starts, and up to which l it contributes
@@ -240,6 +252,24 @@ __global__ void __launch_bounds__(256, 3) k_leg_synth_wg(LegArgs A, const WaveTa
         if (DPPC) {
             // 16-l blocks; a block that starts below lw runs with mu = 0 until the seeds are injected, rows beyond
             // lmax + 1 hold zero coefficients (fetch), so neither end needs a bound
+            if (UNI) {
+#pragma unroll 1
+                for (int hb = 0; hb < kTileL; hb += 16) {
+                    const int lb16 = lb + hb;
+                    if (lb16 + 16 <= lw || lb16 > lmax) continue;
+#pragma unroll
+                    for (int r = 0; r < R; ++r)
+                        if (lb16 == lwr[r]) {              // wave-uniform: this block's lanes switch on here
+                            if (ls[r] == lb16) { mc[r] = sc[r]; mp[r] = sp[r]; }
+                        }
+                    double C[2 * NB];
+                    const double* __restrict__ crow = cur + (hb + (lane & 15)) * ROW;
+#pragma unroll
+                    for (int c = 0; c < 2 * NB; ++c) C[c] = crow[c];
+                    synth_steps16<R, NB, false, 0>(C, al + lb16 + 1, lb16, x, mc, mp, sc, sp, ls, Er, Ei, Or, Oi);
+                }
+                continue;
+            }
             // (two loops one after the other, like phases A and B below: both bodies inside one loop would make the
             // register allocator copy the 4 R NB accumulators between them on every pass)
             int hb = 0;
@@ -491,7 +521,6 @@ __global__ void __launch_bounds__(128) k_leg_adj_mx(LegArgs A, const WaveTask* _
     const int m = __builtin_amdgcn_readfirstlane(T.m);
     const int chunk = __builtin_amdgcn_readfirstlane(T.chunk);
     const int lw = __builtin_amdgcn_readfirstlane(T.lw);
-    const int lAend = __builtin_amdgcn_readfirstlane(T.lAend);
     const int lmax = A.lmax;
     int pb[NR];                  // first pair of this wave's sub-blocks
 #pragma unroll
@@ -500,7 +529,7 @@ __global__ void __launch_bounds__(128) k_leg_adj_mx(LegArgs A, const WaveTask* _
         pb[r] = chunk * (128 * NR) + sub * 64;
     }
     double x[NR], mc[NR], mp[NR], sc[NR], sp[NR];
-    int ls[NR], lwr[NR];
+    int ls[NR], lwr[NR], lhi[NR];
 #pragma unroll
     for (int r = 0; r < NR; ++r) {
         const int p = pb[r] + lane;
@@ -514,6 +543,10 @@ __global__ void __launch_bounds__(128) k_leg_adj_mx(LegArgs A, const WaveTask* _
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) v = min(v, __shfl_xor(v, o));
         lwr[r] = __builtin_amdgcn_readfirstlane(v);
+        v = ls[r] == 0x3fffffff ? -1 : ls[r];               // last start among the lanes that start at all
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) v = max(v, __shfl_xor(v, o));
+        lhi[r] = __builtin_amdgcn_readfirstlane(v);
     }
     const int kq = lane >> 4, col = lane & 15, mk = col >> 1, reim = col & 1;
     const bool on = mk < nb;
@@ -556,8 +589,10 @@ __global__ void __launch_bounds__(128) k_leg_adj_mx(LegArgs A, const WaveTask* _
 #pragma unroll
         for (int r = 0; r < NR; ++r) {
             if (l0 + kMxL <= lwr[r]) continue;            // no pair of this sub-block has started yet (wave-uniform)
-            if (l0 < lAend) mx_recur<true>(al, l0, x[r], mc[r], mp[r], sc[r], sp[r], ls[r], Tw + lane);
-            else            mx_recur<false>(al, l0, x[r], mc[r], mp[r], sc[r], sp[r], ls[r], Tw + lane);
+            // seeds are injected only in the groups in which a lane of THIS block starts (with uniform block starts,
+            // plan_tables.cpp, that is its first group alone)
+            if (l0 <= lhi[r]) mx_recur<true>(al, l0, x[r], mc[r], mp[r], sc[r], sp[r], ls[r], Tw + lane);
+            else              mx_recur<false>(al, l0, x[r], mc[r], mp[r], sc[r], sp[r], ls[r], Tw + lane);
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
             __builtin_amdgcn_wave_barrier();
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
@@ -651,7 +686,6 @@ __global__ void __launch_bounds__(128) k_leg_adj_dx(LegArgs A, const WaveTask* _
     const int m = __builtin_amdgcn_readfirstlane(T.m);
     const int chunk = __builtin_amdgcn_readfirstlane(T.chunk);
     const int lw = __builtin_amdgcn_readfirstlane(T.lw);
-    const int lAend = __builtin_amdgcn_readfirstlane(T.lAend);
     const int lmax = A.lmax;
     const int kq = lane >> 4, row = lane & 15;
     int pb[NR];
@@ -661,7 +695,7 @@ __global__ void __launch_bounds__(128) k_leg_adj_dx(LegArgs A, const WaveTask* _
         pb[r] = chunk * (128 * NR) + sub * 64;
     }
     double x[NR], mc[NR], mp[NR], sc[NR], sp[NR];
-    int ls[NR], lwr[NR];
+    int ls[NR], lwr[NR], lhi[NR];
     double g[NR][NB][4];
 #pragma unroll
     for (int r = 0; r < NR; ++r) {
@@ -676,6 +710,10 @@ __global__ void __launch_bounds__(128) k_leg_adj_dx(LegArgs A, const WaveTask* _
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) v = min(v, __shfl_xor(v, o));
         lwr[r] = __builtin_amdgcn_readfirstlane(v);
+        v = ls[r] == 0x3fffffff ? -1 : ls[r];               // last start among the lanes that start at all
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) v = max(v, __shfl_xor(v, o));
+        lhi[r] = __builtin_amdgcn_readfirstlane(v);
 #pragma unroll
         for (int k = 0; k < NB; ++k) {
             const double* gp = ph + (int64_t)(k0 + k) * ph_stride + d_phidx(lmax + 1, pb[r] + 4 * row + kq, m);
@@ -699,8 +737,10 @@ __global__ void __launch_bounds__(128) k_leg_adj_dx(LegArgs A, const WaveTask* _
 #pragma unroll
         for (int r = 0; r < NR; ++r) {
             if (l0 + kMxL <= lwr[r]) continue;
-            if (l0 < lAend) mx_recur<true>(al, l0, x[r], mc[r], mp[r], sc[r], sp[r], ls[r], Tw + lane);
-            else            mx_recur<false>(al, l0, x[r], mc[r], mp[r], sc[r], sp[r], ls[r], Tw + lane);
+            // seeds are injected only in the groups in which a lane of THIS block starts (with uniform block starts,
+            // plan_tables.cpp, that is its first group alone)
+            if (l0 <= lhi[r]) mx_recur<true>(al, l0, x[r], mc[r], mp[r], sc[r], sp[r], ls[r], Tw + lane);
+            else              mx_recur<false>(al, l0, x[r], mc[r], mp[r], sc[r], sp[r], ls[r], Tw + lane);
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
             __builtin_amdgcn_wave_barrier();
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
@@ -768,11 +808,12 @@ static void synth_RN(const LegArgs& A, const WaveTask* tasks, int ntasks, const 
     static const bool dppc = [] { const char* e = std::getenv("CMDR_SYNTH_DPP"); return !e || std::atoi(e) != 0; }();
     constexpr int NBW = NB <= 5 ? NB : 5;
     const dim3 grid((ntasks / 4) * rep);
-#define CMDR_WG(PP, DD) hipLaunchKernelGGL((k_leg_synth_wg<R, NBW, PP, DD>), grid, dim3(256), 0, s, A, tasks, ntasks, ast, nbs, \
-                                           k0, rep, ph, ph_stride, prep ? *prep : PrepDev{})
+#define CMDR_WG(PP, DD, UU) hipLaunchKernelGGL((k_leg_synth_wg<R, NBW, PP, DD, UU>), grid, dim3(256), 0, s, A, tasks, ntasks, ast, \
+                                               nbs, k0, rep, ph, ph_stride, prep ? *prep : PrepDev{})
     if (A.wg && NB <= 5) {
-        if (prep) { if (dppc) CMDR_WG(true, true); else CMDR_WG(true, false); }
-        else      { if (dppc) CMDR_WG(false, true); else CMDR_WG(false, false); }
+        const bool uni = dppc && A.uni;
+        if (prep) { if (uni) CMDR_WG(true, true, true); else if (dppc) CMDR_WG(true, true, false); else CMDR_WG(true, false, false); }
+        else      { if (uni) CMDR_WG(false, true, true); else if (dppc) CMDR_WG(false, true, false); else CMDR_WG(false, false, false); }
     } else {
         hipLaunchKernelGGL((k_leg_synth<R, NB>), grid, dim3(256), 0, s, A, tasks, ntasks, ast, nbs, k0, rep, ph, ph_stride);
     }

@@ -56,6 +56,7 @@ struct LegArgs {
     const double* seedp;   // mu_{ls-1}
     const double* alpha;   // [ntrip]
     int wg;                // synthesis task list grouped by m: the 4 tasks of a workgroup are 4 chunks of one m
+    int uni;               // every 64-pair lane block starts at one l == m (mod 32) (LegendreTables::uniform_start)
 };
 
 // ---------------------------------------------------------------------------------------------------------

@@ -2,6 +2,7 @@
 #include "plan_tables.hpp"
 
 #include <algorithm>
+#include <atomic>
 #include <cmath>
 #include <complex>
 #include <cstdio>
@@ -53,6 +54,8 @@ void LegendreTables::build(int lmax_, const std::vector<double>& x_, const std::
     logpref[0] = -0.5 * std::log(4.0 * kPi);
     for (int m = 1; m <= lmax; ++m) logpref[m] = logpref[m - 1] + 0.5 * std::log((2.0 * m + 1.0) / (2.0 * m));
 
+    const bool want_uniform = [] { const char* e = std::getenv("CMDR_UNIFORM_START"); return !e || std::atoi(e) != 0; }();
+    std::atomic<bool> uniform_fail{false};
     host_parallel_for(nm, [&](int mi) {
         // interleave long and short columns for balance
         const int m = (mi & 1) ? lmax - mi / 2 : mi / 2;
@@ -109,7 +112,51 @@ void LegendreTables::build(int lmax_, const std::vector<double>& x_, const std::
                 }
             }
         }
+        // Uniform starts: the 64 ring pairs of a lane block (one wavefront column of every kernel) all switch on at the
+        // same l -- the first l == m (mod 32) at or below the block's earliest start -- with their true, still tiny
+        // mu there as seeds (representable: a block spans a few hundred binary orders at most).  The kernels then
+        // inject seeds once per block, at a group boundary, instead of testing every lane at every l while the lanes
+        // of a wave trickle in.  A lane whose seed would underflow keeps its own start and clears `uniform_start`.
+        if (want_uniform) {
+            for (int b0 = 0; b0 < npair; b0 += kWave) {
+                const int b1 = std::min(b0 + kWave, npair);
+                int lo = kLsNever;
+                for (int p = b0; p < b1; ++p) lo = std::min(lo, lsm[p]);
+                if (lo == kLsNever) continue;
+                const int s0 = m + ((lo - m) / 32) * 32;
+                for (int p = b0; p < b1; ++p) {
+                    if (lsm[p] == kLsNever || lsm[p] == s0) continue;
+                    const double xx = x[p];
+                    const double l2 = (logpref[m] + (m > 0 ? (double)m * std::log(sth[p]) : 0.0)) / M_LN2;
+                    const double fl = std::floor(l2);
+                    long e = (long)fl;
+                    double lc = std::exp2(l2 - fl), lp = 0.0;
+                    if (m & 1) lc = -lc;
+                    for (int l = m; l < s0; ++l) {
+                        const double ln = al[l + 1] * xx * lc - lp;
+                        lp = lc;
+                        lc = ln;
+                        if (std::fabs(lc) > 0x1p+300) {
+                            lc *= 0x1p-300;
+                            lp *= 0x1p-300;
+                            e += 300;
+                        }
+                    }
+                    int exc, exp_;
+                    (void)std::frexp(lc, &exc);
+                    (void)std::frexp(lp, &exp_);
+                    if (lc == 0.0 || e + exc < -960 || (lp != 0.0 && e + exp_ < -960)) {
+                        uniform_fail.store(true, std::memory_order_relaxed);
+                        continue;
+                    }
+                    lsm[p] = s0;
+                    scm[p] = std::ldexp(lc, (int)e);
+                    spm[p] = std::ldexp(lp, (int)e);
+                }
+            }
+        }
     }, nthreads);
+    uniform_start = want_uniform && !uniform_fail.load();
     // ---- task lists
     auto make_tasks = [&](int Rt, std::vector<std::vector<WaveTask>>& out) {
         const int pr = kWave * Rt, nch = npair_pad / pr;
@@ -160,8 +207,8 @@ void LegendreTables::build(int lmax_, const std::vector<double>& x_, const std::
         double slots = 0, slotsA = 0, steps = 0;
         for (const WaveTask& t : tasks) if (t.chunk >= 0) { slots += (double)(lmax - t.lw + 1) * kWave * R; slotsA += (double)(std::min(t.lAend, lmax + 1) - t.lw) * kWave * R; }
         for (int m = 0; m < nm; ++m) for (int p = 0; p < npair; ++p) { const int v = ls[(size_t)m * npair_pad + p]; if (v != kLsNever) steps += lmax - v + 1; }
-        std::fprintf(stderr, "[cmdr] legendre plan lmax=%d npair=%d R=%d: %zu tasks, lane-slot steps %.4g (phase A %.4g), pruned steps %.4g (%.1f%%)\n",
-                     lmax, npair, R, tasks.size(), slots, slotsA, steps, 100.0 * steps / slots);
+        std::fprintf(stderr, "[cmdr] legendre plan lmax=%d npair=%d R=%d: %zu tasks, lane-slot steps %.4g (phase A %.4g), pruned steps %.4g (%.1f%%), uniform block starts: %s\n",
+                     lmax, npair, R, tasks.size(), slots, slotsA, steps, 100.0 * steps / slots, uniform_start ? "yes" : "no");
     }
     make_tasks(Rs, tm);
     tasks_s.clear();

@@ -32,6 +32,7 @@ struct LegendreTables {
     std::vector<double> cnorm;          // [ntrip] lambda_lm = cnorm * mu_l  (pad entries 0)
     std::vector<int> ls;                // [(lmax+1) * npair_pad] first l with |mu| above threshold
     std::vector<double> seedc, seedp;   // mu_{ls}, mu_{ls-1}
+    bool uniform_start = false;         // every 64-pair lane block switches on at one l == m (mod 32) (plan_tables.cpp)
     // adjoint kernel: R pairs per lane, one task per wavefront, 4 per workgroup, longest first
     std::vector<WaveTask> tasks;
     std::vector<int> lw_chunk;           // [(lmax+1) * nchunk] first l the adjoint writes for (m, chunk); lmax+2: nothing

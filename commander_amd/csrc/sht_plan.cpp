@@ -9,6 +9,7 @@ void LegendreDev::upload(const LegendreTables& T) {
     nchunk = T.nchunk;
     Rs = T.Rs;
     synth_wg = T.synth_wg;
+    uniform_start = T.uniform_start;
     ntasks_s = (int)T.tasks_s.size();
     tasks_s.upload(T.tasks_s);
     ntasks = (int)T.tasks.size();
@@ -33,6 +34,7 @@ LegArgs LegendreDev::args() const {
     A.seedp = seedp.get();
     A.alpha = alpha.get();
     A.wg = 0;
+    A.uni = uniform_start ? 1 : 0;
     return A;
 }
 
@@ -40,6 +42,7 @@ LegArgs LegendreDev::args_synth() const {
     LegArgs A = args();
     A.R = Rs;
     A.wg = synth_wg ? 1 : 0;
+    A.uni = uniform_start ? 1 : 0;
     return A;
 }
 

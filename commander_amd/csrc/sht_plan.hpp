@@ -19,6 +19,7 @@ class LegendreDev {  // device mirror of LegendreTables
     LegArgs args_synth() const;  // synthesis kernel (Rs pairs per lane)
     int lmax = -1, npair_pad = 0, R = 1, Rs = 1, nchunk = 0, ntasks = 0, ntasks_s = 0;
     bool synth_wg = false;
+    bool uniform_start = false;
     DevBuf<double> x, seedc, seedp, alpha, cnorm;
     DevBuf<int> ls, lw_chunk;
     DevBuf<WaveTask> tasks, tasks_s;

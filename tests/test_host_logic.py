@@ -27,6 +27,8 @@ def test_emul_sht_vs_oracle(nside, lmax, EL, oracle_lib):
         m = rng.standard_normal((12 * nside * nside, 2))
         y, yt, ytw, wy = plan.Y(a), plan.Yt(m), plan.YtW(m), plan.WY(a)
     finally:
+        if "plan" in locals():
+            plan.close()        # while the emulation is still the library the handle belongs to
         shtmod.lib = old
     for k in range(2):
         assert rel(y[:, k], oracle_lib.Y(nside, lmax, a[:, k])) < 1e-12
@@ -138,6 +140,8 @@ def test_emul_sht_spin2_vs_oracle(nside, lmax, EL, oracle_lib):
                plan.execute_spin2(2, mapQ=mq, mapU=mu), plan.execute_spin2(0, mapQ=mq, mapU=mu)]
         t = plan.Y(e)   # the scalar path of a polarised plan (T column)
     finally:
+        if "plan" in locals():
+            plan.close()        # while the emulation is still the library the handle belongs to
         shtmod.lib = old
     ref = [oracle_lib.sht_spin2(1, nside, lmax, almE=e, almB=b), oracle_lib.sht_spin2(3, nside, lmax, almE=e, almB=b, wring=w),
            oracle_lib.sht_spin2(2, nside, lmax, mapQ=mq, mapU=mu), oracle_lib.sht_spin2(0, nside, lmax, mapQ=mq, mapU=mu, wring=w)]
@@ -482,14 +486,15 @@ def test_emul_fused_pcg_updates_equal_the_general_sequence(EL, cfg, pol, monkeyp
     fused_pcg_checks(EL, pol, monkeypatch, cfg=cfg)
 
 
-@pytest.mark.parametrize("R,Rs", [(4, 2), (4, 1), (2, 1), (1, 1)])
-def test_emul_sht_pairs_per_lane(R, Rs, EL, oracle_lib, monkeypatch):
+@pytest.mark.parametrize("R,Rs,uniform", [(4, 2, "1"), (4, 1, "1"), (2, 1, "0"), (1, 1, "1"), (4, 2, "0")])
+def test_emul_sht_pairs_per_lane(R, Rs, uniform, EL, oracle_lib, monkeypatch):
     """The plan picks the ring pairs per lane from the shard size (4 / 2 for the adjoint, 2 / 1 for the synthesis);
     every combination the kernels are compiled for gives the same transform (256 pairs: all four are valid)."""
     from commander_amd.sht import ShtPlan
     import commander_amd.sht as shtmod
     monkeypatch.setenv("CMDR_LEG_R", str(R))
     monkeypatch.setenv("CMDR_LEG_RS", str(Rs))
+    monkeypatch.setenv("CMDR_UNIFORM_START", uniform)     # block-uniform starts (default) / per-lane starts
     nside, lmax = 128, 40
     rng = np.random.default_rng(R * 10 + Rs)
     old = shtmod.lib
@@ -500,6 +505,8 @@ def test_emul_sht_pairs_per_lane(R, Rs, EL, oracle_lib, monkeypatch):
         m = rng.standard_normal((12 * nside * nside, 3))
         y, yt = plan.Y(a), plan.Yt(m)
     finally:
+        if "plan" in locals():
+            plan.close()        # while the emulation is still the library the handle belongs to
         shtmod.lib = old
     for k in range(3):
         assert rel(y[:, k], oracle_lib.Y(nside, lmax, a[:, k])) < 1e-12

@@ -154,3 +154,23 @@ def test_dpp_adjoint_all_batch_sizes(R, oracle_lib, monkeypatch):
             if k < nm:
                 assert rel(yt[:, k], ref[k]) < 1e-12, (nm, k)
         plan.close()
+
+
+@pytest.mark.parametrize("uniform", ["1", "0"])
+def test_block_starts_uniform_and_per_lane(uniform, oracle_lib, monkeypatch):
+    """The plan lets the 64 ring pairs of a lane block switch on at one l == m (mod 32) with their true, still tiny mu as
+    seeds (the kernels then inject seeds once per block); CMDR_UNIFORM_START=0 keeps the per-lane starts and the kernels'
+    per-l start tests.  Both against the oracle, synthesis and adjoint, 9 maps (matrix unit + ninth map) and 4 (DPP form)."""
+    from commander_amd.sht import ShtPlan
+    monkeypatch.setenv("CMDR_UNIFORM_START", uniform)
+    nside, lmax = 256, 500
+    rng = np.random.default_rng(77)
+    for nm in (9, 4):
+        plan = ShtPlan(nside, lmax, max_maps=nm)
+        a = rng.standard_normal(((lmax + 1) ** 2, nm))
+        m = rng.standard_normal((12 * nside * nside, nm))
+        y, yt = plan.Y(a), plan.Yt(m)
+        for k in (0, nm - 1):
+            assert rel(y[:, k], oracle_lib.Y(nside, lmax, a[:, k])) < 1e-12
+            assert rel(yt[:, k], oracle_lib.Yt(nside, lmax, m[:, k])) < 1e-12
+        plan.close()
