@@ -402,7 +402,7 @@ def main():
         nbm, steps_pruned = int(info[0]), int(info[2])
         avg = lambda k: ms[k] / max(int(cnt[k]), 1)   # noqa: E731  ms per launch span
         t_syn, t_ring, t_adj, t_mv = avg(0), avg(1), avg(2), avg(3)
-        # ---- roofline of the dominant kernel.  With >= 6 maps per plan the Legendre adjoint of up to 8 maps is ONE launch
+        # ---- roofline of the dominant kernel.  With >= 6 maps per plan the Legendre adjoint of up to 9 maps is ONE launch
         # of k_leg_adj_mx (v_mfma_f64_16x16x4; profile kind 4); otherwise the VALU kernel k_leg_adj (kind 5).
         # F_SHT = 8 flop x (2 Nside ring pairs) x (lmax+1)(lmax+2)/2 (l, m) per scalar map
         # (2 FMA recursion + 2 FMA accumulate per (ring pair, l, m)); a launch = the Legendre stage of `nk` maps.

@@ -805,7 +805,7 @@ int leg_max_batch(int R) { return leg_batch(R, false); }
 template <int R, int NB>
 static void synth_RN(const LegArgs& A, const WaveTask* tasks, int ntasks, const double* ast, int nbs, int k0, int rep,
                      double* ph, int64_t ph_stride, hipStream_t s, const PrepDev* prep) {
-    static const bool dppc = [] { const char* e = std::getenv("CMDR_SYNTH_DPP"); return !e || std::atoi(e) != 0; }();
+    const bool dppc = [] { const char* e = std::getenv("CMDR_SYNTH_DPP"); return !e || std::atoi(e) != 0; }();   // per call (test hook)
     constexpr int NBW = NB <= 5 ? NB : 5;
     const dim3 grid((ntasks / 4) * rep);
 #define CMDR_WG(PP, DD, UU) hipLaunchKernelGGL((k_leg_synth_wg<R, NBW, PP, DD, UU>), grid, dim3(256), 0, s, A, tasks, ntasks, ast, \
@@ -835,7 +835,7 @@ static void for_batches(int nmaps, int nbmax, F f) {
     }
 }
 bool leg_synth_can_prep(const LegArgs& A) {
-    static const bool on = [] { const char* e = std::getenv("CMDR_SYNTH_PREP"); return !e || std::atoi(e) != 0; }();
+    const bool on = [] { const char* e = std::getenv("CMDR_SYNTH_PREP"); return !e || std::atoi(e) != 0; }();   // per call (test hook)
     return on && A.wg;
 }
 void launch_leg_synth(const LegArgs& A, const WaveTask* tasks, int ntasks, const double* ast, double* ph,

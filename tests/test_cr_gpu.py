@@ -376,3 +376,22 @@ def test_coefficients_formed_in_the_synthesis_staging_gpu():
 def test_fused_pcg_updates_equal_the_general_sequence_gpu(cfg, pol, monkeypatch):
     from helpers import fused_pcg_checks
     fused_pcg_checks(None, pol, monkeypatch, nside=32, lmax=64, cfg=cfg)
+
+
+@pytest.mark.parametrize("env", [{}, {"CMDR_SYNTH_DPP": "0"}, {"CMDR_SYNTH_PREP": "0"},
+                                 {"CMDR_SYNTH_DPP": "0", "CMDR_SYNTH_PREP": "0"}, {"CMDR_ADJ_X9": "0"}, {"CMDR_ADJ_DX": "0"}])
+def test_kernel_form_switches_agree_with_the_oracle(env, monkeypatch):
+    """The A/B switches of the Legendre kernels (synthesis through LDS broadcasts instead of DPP, coefficients from the
+    stream instead of the staging, ninth map in its own launch, small batches through the VALU adjoint) select code
+    paths that stay compiled in: each must give the oracle's matvec, on 9 bands (matrix unit) and on 4 (DPP / VALU form)."""
+    from commander_amd import synth
+    from commander_amd.cr import build_context
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
+    for nband in (9, 4):
+        spec = synth.make_problem("cfg3", nside=128, lmax=200, bands=list(range(nband)))
+        ctx = build_context(spec)
+        S = oracle_system(spec)
+        x = np.random.default_rng(3 + nband).standard_normal(ctx.ncr)
+        assert rel(ctx.cr_matmulA(x), S.matmulA(x)) < 1e-11
+        ctx.close()
