@@ -6,10 +6,10 @@ but balances badly (9 bands on 8 GPUs).  ``plan_shards`` picks the factorisation
 the smallest estimated time."""
 
 # measured on MI355X at the cfg3 geometry with the round-2 kernels (tools/cr_time_rank.py, DESIGN.md §6; one rank's
-# matvec + invM: 7.5 ms alone, 4.27 / 2.55 / 1.46 ms as 1 of 2 / 4 / 8 ring sets with block ring ownership, 1.60 ms as 1
+# matvec + invM: 7.23 ms alone, 4.01 / 2.38 / 1.41 ms as 1 of 2 / 4 / 8 ring sets with block ring ownership, 1.6 ms as 1
 # of 16: 128 pairs leave the synthesis without its workgroup form): compute efficiency of one rank's share under
 # ring_parts-way ring sharding
-RING_EFF = {1: 1.0, 2: 0.88, 4: 0.735, 8: 0.64}
+RING_EFF = {1: 1.0, 2: 0.90, 4: 0.76, 8: 0.64}
 
 
 def _eff(r):
