@@ -66,14 +66,46 @@ def launch_ranks(n):
                    MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
                                       stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL))
-    out, _ = procs[0].communicate()
-    rcs = [procs[0].returncode] + [p.wait() for p in procs[1:]]
-    sys.stdout.write(out.decode())
+    # Supervise: rank 0's stdout is drained by a thread while every child is polled.  The first rank that exits non-zero
+    # (or the wall-clock limit) ends the run: the others would sit in a collective until a watchdog fires, holding
+    # their GPUs.  They are fresh children of this process -- terminated here, never re-launched (that is the caller's call).
+    import threading
+    chunks = []
+    reader = threading.Thread(target=lambda: chunks.append(procs[0].stdout.read()), daemon=True)
+    reader.start()
+    limit = float(os.environ.get("CMDR_BENCH_LAUNCH_TIMEOUT", "3000"))
+    t0 = time.time()
+    failed = None
+    while True:
+        rcs = [p.poll() for p in procs]
+        bad = [(r, c) for r, c in enumerate(rcs) if c not in (None, 0)]
+        if bad:
+            failed = "ranks failed: %r" % (bad,)
+            break
+        if all(c == 0 for c in rcs):
+            break
+        if time.time() - t0 > limit:
+            failed = "no result after %.0f s (CMDR_BENCH_LAUNCH_TIMEOUT)" % limit
+            break
+        time.sleep(0.2)
+    if failed:
+        for p in procs:
+            if p.poll() is None:
+                p.terminate()
+        t1 = time.time()
+        while any(p.poll() is None for p in procs) and time.time() - t1 < 10:
+            time.sleep(0.1)
+        for p in procs:
+            if p.poll() is None:
+                p.kill()
+        for p in procs:
+            p.wait()
+    reader.join(timeout=10)
+    sys.stdout.write(b"".join(chunks).decode())
     sys.stdout.flush()
-    bad = [(r, c) for r, c in enumerate(rcs) if c != 0]
-    if bad:
-        sys.stderr.write("bench.py: ranks failed: %r\n" % (bad,))
-        sys.exit(max(abs(c) for _, c in bad) or 1)
+    if failed:
+        sys.stderr.write("bench.py: %s; remaining ranks terminated\n" % failed)
+        sys.exit(1)
     sys.exit(0)
 
 
@@ -224,6 +256,8 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29533")
         dist.init_process_group(backend="gloo" if one_gpu else "nccl", rank=rank, world_size=world)
+        if os.environ.get("CMDR_BENCH_TEST_DIE_RANK") == str(rank):   # test hook: a rank that dies during setup
+            os._exit(3)
     from commander_amd import synth, healpix, shard
     from commander_amd.cr import build_context
 
@@ -290,6 +324,8 @@ def main():
                 flag = torch.tensor([ok], dtype=torch.int32, device=dev)
                 dist.all_reduce(flag, op=dist.ReduceOp.MIN)
             if int(flag.item()) != 1:
+                ctx.drop_rccl()      # a rank whose own init succeeded must not keep using its half-built communicators
+                rccl_world = 0
                 collective = "torch-stream (native RCCL binding failed, see stderr)"
                 if lay["band_parts"] > 1 and lay["ring_parts"] > 1:
                     ring_groups = [dist.new_group([bg * lay["ring_parts"] + i for i in range(lay["ring_parts"])])

@@ -137,6 +137,10 @@ class CRContext:
         """Band x ring-set hybrid: communicator of the ranks holding the same bands (ncclCommSplit); collective."""
         check(self.L.cmdr_ctx_rccl_split_rings(self._h, int(band_group), int(ring_index), int(ring_replicas)), self.L)
 
+    def drop_rccl(self):
+        """Destroy the native communicators; the callback forms apply again."""
+        check(self.L.cmdr_ctx_drop_rccl(self._h), self.L)
+
     def rccl_size(self):
         """ncclCommCount read back from the communicator (0: none)."""
         return int(self.L.cmdr_ctx_rccl_size(self._h))

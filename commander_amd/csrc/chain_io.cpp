@@ -62,12 +62,19 @@ H5& h5() {
     std::call_once(once, [] {
         const char* names[] = {"libhdf5.so.103", "libhdf5.so", "/opt/conda/lib/libhdf5.so.103", "/opt/conda/lib/libhdf5.so",
                                "libhdf5_serial.so.103", "libhdf5_serial.so"};
-        if (const char* e = std::getenv("CMDR_HDF5_LIB")) A.h = dlopen(e, RTLD_NOW | RTLD_LOCAL);
-        for (const char* n : names) {
-            if (A.h) break;
-            A.h = dlopen(n, RTLD_NOW | RTLD_LOCAL);
+        // CMDR_HDF5_LIB names THE library to bind (no fall-back to the default names: a wrong path is an error)
+        const char* forced = std::getenv("CMDR_HDF5_LIB");
+        if (forced) A.h = dlopen(forced, RTLD_NOW | RTLD_LOCAL);
+        else
+            for (const char* n : names) {
+                if (A.h) break;
+                A.h = dlopen(n, RTLD_NOW | RTLD_LOCAL);
+            }
+        if (!A.h) {
+            const char* e = dlerror();           // ONE call: dlerror() clears the message it returns
+            A.err = std::string("cannot load libhdf5: ") + (e ? e : "?");
+            return;
         }
-        if (!A.h) { A.err = std::string("cannot load libhdf5: ") + (dlerror() ? dlerror() : "?"); return; }
         auto sym = [&](const char* n) {
             void* p = dlsym(A.h, n);
             if (!p && A.err.empty()) A.err = std::string("libhdf5 lacks ") + n;

@@ -742,6 +742,16 @@ void CrSystem::rccl_split_rings(int band_group, int ring_index, int ring_replica
     band_sharded_ = true;
 }
 
+// Back to the callbacks: bench.py's "all ranks fall back together" needs a rank whose own init succeeded to stop using
+// its half-built communicators when another rank failed (reduce / reduce_rings give the native ones precedence).
+void CrSystem::drop_rccl() {
+    sync();
+    const bool split = rccl_rings_.ready();
+    rccl_rings_.destroy();
+    rccl_.destroy();
+    if (split) { band_sharded_ = false; ring_replicas_ = 1; }   // set by rccl_split_rings; cmdr_ctx_set_band_sharding sets them again
+}
+
 void CrSystem::reduce_rings(double* v, int64_t n) {
     if (!band_sharded_) { reduce(v, n); return; }
     if (rccl_rings_.ready()) {

@@ -86,6 +86,7 @@ class CrSystem {
     void init_rccl(const char* id, int rank, int nranks);
     void rccl_split_rings(int band_group, int ring_index, int ring_replicas);
     int rccl_size() const { return rccl_.ready() ? rccl_.size() : 0; }
+    void drop_rccl();
 
     int64_t ncr() const { return ncr_; }
     int nband() const { return (int)bands_.size(); }

@@ -39,12 +39,19 @@ Api& api() {
     std::call_once(once, [] {
         // a process that already holds an RCCL (torch's bundled copy) gets that one: same SONAME
         const char* names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
-        if (const char* e = std::getenv("CMDR_RCCL_LIB")) A.h = dlopen(e, RTLD_NOW | RTLD_GLOBAL);
-        for (const char* n : names) {
-            if (A.h) break;
-            A.h = dlopen(n, RTLD_NOW | RTLD_GLOBAL);
+        // CMDR_RCCL_LIB names THE library to bind (no fall-back to the default names: a wrong path is an error)
+        const char* forced = std::getenv("CMDR_RCCL_LIB");
+        if (forced) A.h = dlopen(forced, RTLD_NOW | RTLD_GLOBAL);
+        else
+            for (const char* n : names) {
+                if (A.h) break;
+                A.h = dlopen(n, RTLD_NOW | RTLD_GLOBAL);
+            }
+        if (!A.h) {
+            const char* e = dlerror();           // ONE call: dlerror() clears the message it returns
+            A.err = std::string("cannot load librccl: ") + (e ? e : "?");
+            return;
         }
-        if (!A.h) { A.err = std::string("cannot load librccl: ") + (dlerror() ? dlerror() : "?"); return; }
         auto sym = [&](const char* n) {
             void* p = dlsym(A.h, n);
             if (!p && A.err.empty()) A.err = std::string("librccl lacks ") + n;
@@ -99,9 +106,12 @@ void RcclComm::split_from(const RcclComm& parent, int color, int key) {
     check(api().CommSplit(parent.comm_, color, key, &comm_, nullptr), "ncclCommSplit");
 }
 
-RcclComm::~RcclComm() {
+void RcclComm::destroy() {
     if (comm_) (void)api().CommDestroy(comm_);
+    comm_ = nullptr;
 }
+
+RcclComm::~RcclComm() { destroy(); }
 
 int RcclComm::size() const {
     int n = 0;

@@ -19,6 +19,7 @@ class RcclComm {
     static void unique_id(char out[kRcclIdBytes]);                       // ncclGetUniqueId
     void init(const char id[kRcclIdBytes], int rank, int nranks);        // ncclCommInitRank on the current device
     void split_from(const RcclComm& parent, int color, int key);         // ncclCommSplit (collective over parent)
+    void destroy();                                                      // ncclCommDestroy; ready() is false afterwards
     bool ready() const { return comm_ != nullptr; }
     int size() const;                                                    // ncclCommCount, read back from the library
     int rank() const;                                                    // ncclCommUserRank

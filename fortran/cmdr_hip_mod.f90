@@ -134,6 +134,12 @@ module cmdr_hip_mod
        integer(c_int)        :: ierr
      end function cmdr_ctx_rccl_split_rings
 
+     function cmdr_ctx_drop_rccl(ctx) bind(c, name='cmdr_ctx_drop_rccl') result(ierr)
+       import :: c_ptr, c_int
+       type(c_ptr), value :: ctx
+       integer(c_int) :: ierr
+     end function cmdr_ctx_drop_rccl
+
      function cmdr_ctx_rccl_size(ctx) bind(c, name='cmdr_ctx_rccl_size') result(n)
        import :: c_int, c_ptr
        type(c_ptr), value :: ctx

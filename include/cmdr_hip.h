@@ -115,12 +115,16 @@ int cmdr_ctx_set_band_sharding(cmdr_ctx* ctx, cmdr_allreduce_fn rings_fn, void* 
  * cmdr_ctx_rccl_split_rings: band x ring-set hybrid without callbacks -- ncclCommSplit(color = band_group,
  * key = ring_index) gives the communicator of the ranks holding the same bands; collective over ALL ranks (ranks
  * outside any hybrid layout do not call it).  Replaces cmdr_ctx_set_band_sharding.
+ * cmdr_ctx_drop_rccl: destroys the context's communicators (and the band sharding a split set up), so that the callbacks
+ * of cmdr_ctx_set_allreduce[_stream] / cmdr_ctx_set_band_sharding apply again -- for a driver whose ranks did not ALL get
+ * a communicator and fall back together.  No-op without one.
  * cmdr_ctx_rccl_size: ncclCommCount read back from the communicator (0 = none).  cmdr_rccl_version: ncclGetVersion
  * (< 0: librccl could not be loaded; cmdr_last_error says why). */
 int cmdr_rccl_unique_id(char* out128);
 int cmdr_rccl_version(void);
 int cmdr_ctx_init_rccl(cmdr_ctx* ctx, const char* id128, int rank, int nranks);
 int cmdr_ctx_rccl_split_rings(cmdr_ctx* ctx, int band_group, int ring_index, int ring_replicas);
+int cmdr_ctx_drop_rccl(cmdr_ctx* ctx);
 int cmdr_ctx_rccl_size(cmdr_ctx* ctx);
 int cmdr_ctx_set_only_pol(cmdr_ctx* ctx, int only_pol);
 /* on != 0: reproduce cr_matmulA's re-use of pmap%alm across the components of a band literally

@@ -43,3 +43,14 @@ def test_gpus_flag_launches_that_many_ranks():
 def test_world_size_mismatch_is_an_error_not_a_one_gpu_run():
     out, p = run_bench(["--gpus", "8"], {"WORLD_SIZE": "1", "RANK": "0"}, expect_rc=2)
     assert out == [] and "refusing" in p.stderr
+
+
+def test_a_rank_that_dies_ends_the_run_promptly():
+    """The parent polls its children: when one rank exits non-zero the others (blocked in a collective) are terminated
+    and the launcher itself exits non-zero -- within seconds, not at a watchdog's or the driver's limit."""
+    import time
+    emul_lib()
+    t0 = time.time()
+    out, p = run_bench(["--gpus", "2"], {"CMDR_BENCH_TEST_DIE_RANK": "1"}, expect_rc=1)
+    assert time.time() - t0 < 30, time.time() - t0
+    assert out == [] and "ranks failed" in p.stderr and "terminated" in p.stderr

@@ -67,3 +67,37 @@ def test_hand_written_dpp_fmas_keep_their_hazard_distance():
                        timeout=900)
     assert r.returncode == 0, r.stdout + r.stderr
     assert " 0 hazards" in r.stdout and not r.stdout.startswith("0 DPP"), r.stdout
+
+
+def test_missing_runtime_libraries_fail_cleanly(tmp_path):
+    """librccl / libhdf5 are bound with dlopen at first use.  When the library cannot be loaded the entry points must
+    return < 0 with a message in cmdr_last_error (bench.py's all-ranks fall-back and the chain writer's -1 depend on
+    it), not crash: CMDR_RCCL_LIB / CMDR_HDF5_LIB name THE library to load, so a wrong path hides every candidate.
+    Fresh process (the binding is cached per process); host emulation of the library, same C ABI."""
+    import subprocess
+    import sys
+    from helpers import emul_lib
+    emul_lib()                                    # make sure the emulation library is built
+    code = r'''
+import ctypes, sys, os
+sys.path.insert(0, %r); sys.path.insert(0, os.path.join(%r, "tests"))
+import numpy as np
+from helpers import emul_lib
+L = emul_lib()
+rc = L.cmdr_rccl_version()
+assert rc < 0, rc
+msg = L.cmdr_last_error()
+assert msg and b"librccl" in msg, msg
+buf = ctypes.create_string_buffer(128)
+assert L.cmdr_rccl_unique_id(buf) < 0 and L.cmdr_last_error()
+a = np.zeros(9)
+dp = lambda v: v.ctypes.data_as(ctypes.POINTER(ctypes.c_double))
+rc = L.cmdr_chain_write_comp(os.path.join(%r, "c.h5").encode(), 1, b"cmb", dp(a), 2, 1, None, None, None)
+assert rc < 0, rc
+msg = L.cmdr_last_error()
+assert msg and b"libhdf5" in msg, msg
+print("clean")
+''' % (ROOT, ROOT, str(tmp_path))
+    env = dict(os.environ, CMDR_RCCL_LIB="/nonexistent/librccl.so", CMDR_HDF5_LIB="/nonexistent/libhdf5.so")
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=env, timeout=300)
+    assert r.returncode == 0 and "clean" in r.stdout, r.stdout + r.stderr
