@@ -335,6 +335,29 @@ class CRContext:
         check(self.L.cmdr_compute_residual(self._h, _p(av), arr(*din), arr(*dout)), self.L)
         return keep[1::2]
 
+    MONO_PRIOR = {"monopole": 1, "monopole+dipole": 2}
+
+    def applyMonoDipolePrior(self, comp, amp, nside, mask, prior_type="monopole", b_l_out=None):
+        """``applyMonoDipolePrior`` (comm_diffuse_comp_mod.f90:5738-5827; tail of ``sample_amps_by_CG``,
+        comm_signal_mod.f90:186-194) on the stacked amplitudes ``amp`` (ncr, physical units): returns (amp_new, mu[4])."""
+        a = np.array(amp, dtype=np.float64, order="C")
+        assert a.shape == (self.ncr,)
+        m = np.ascontiguousarray(mask, dtype=np.float64).ravel()
+        bl = None if b_l_out is None else np.ascontiguousarray(b_l_out, dtype=np.float64)
+        mu = np.zeros(4)
+        check(self.L.cmdr_apply_mono_dipole_prior(self._h, int(comp), _p(a), int(nside), None if bl is None else _p(bl),
+                                                  _p(m), m.size, self.MONO_PRIOR[prior_type], _p(mu)), self.L)
+        return a, mu
+
+    def applyMonoDipolePrior_dev(self, comp, amp, nside, mask, prior_type="monopole", b_l_out=None):
+        """The same on device buffers (``ctx.dev``): ``amp`` is edited in place; returns mu[4]."""
+        bl = None if b_l_out is None else np.ascontiguousarray(b_l_out, dtype=np.float64)
+        mu = np.zeros(4)
+        check(self.L.cmdr_apply_mono_dipole_prior_dev(self._h, int(comp), amp.ptr, int(nside),
+                                                      None if bl is None else _p(bl), mask.ptr,
+                                                      self.MONO_PRIOR[prior_type], _p(mu)), self.L)
+        return mu
+
     def solve_cr_eqn_by_CG(self, b, conv_crit="fixed_iter", tol=1e-8, miniter=5, maxiter=40, check_freq=1, x0=None):
         """Returns (x, niter, stat, (delta_new, delta0)); x already multiplied by sqrt(S)."""
         b = np.ascontiguousarray(b, dtype=np.float64)

@@ -594,6 +594,29 @@ int cmdr_compute_residual(cmdr_ctx* ctx, const double* amp, const double* const*
     });
 }
 
+int cmdr_apply_mono_dipole_prior_dev(cmdr_ctx* ctx, int comp, double* amp, int nside, const double* b_l_out,
+                                     const double* mask, int type, double* mu) {
+    return guarded([&] {
+        CMDR_REQUIRE(ctx && amp && mask && mu, "bad arguments");
+        ctx->sys->apply_mono_dipole_prior(comp, amp, nside, b_l_out, mask, type, mu);
+        CMDR_HIP_CHECK(hipGetLastError());
+    });
+}
+int cmdr_apply_mono_dipole_prior(cmdr_ctx* ctx, int comp, double* amp, int nside, const double* b_l_out,
+                                 const double* mask, int64_t npix_local, int type, double* mu) {
+    return guarded([&] {
+        CMDR_REQUIRE(ctx && amp && mask && mu && npix_local >= 0, "bad arguments");
+        const size_t n = (size_t)ctx->sys->ncr();
+        ctx->hx.ensure(n);
+        ctx->hz.ensure((size_t)std::max<int64_t>(npix_local, 1));
+        CMDR_HIP_CHECK(hipMemcpy(ctx->hx.get(), amp, n * sizeof(double), hipMemcpyHostToDevice));
+        CMDR_HIP_CHECK(hipMemcpy(ctx->hz.get(), mask, (size_t)npix_local * sizeof(double), hipMemcpyHostToDevice));
+        if (cmdr_apply_mono_dipole_prior_dev(ctx, comp, ctx->hx.get(), nside, b_l_out, ctx->hz.get(), type, mu) != 0)
+            throw cmdr::Error(g_err);
+        CMDR_HIP_CHECK(hipMemcpy(amp, ctx->hx.get(), n * sizeof(double), hipMemcpyDeviceToHost));
+    });
+}
+
 int cmdr_solve_dev(cmdr_ctx* ctx, const double* b, double* x, int crit, double tol, int miniter, int maxiter,
                    int check_freq, const double* x0, int* niter, double* res, int* stat) {
     return guarded([&] {

@@ -969,6 +969,109 @@ void CrSystem::compute_residual(const double* amp, const double* const* data, do
     flip_active();
 }
 
+// applyMonoDipolePrior (comm_diffuse_comp_mod.f90:5738-5827).  The reference copies the component (comm_map(self%x)),
+// convolves with the output beam, synthesises the map (map%Y; only column 1 is used), fits a monopole (mask-weighted
+// mean, :5764-5768) or monopole + dipole (4 x 4 normal equations over the pixels with mask >= 0.5, :5779-5794, solved with
+// dgesv) and subtracts the fit from four a_lm entries (:5811-5824) -- and from self%x%map (:5771, :5797-5801), a pixel
+// buffer of the driver that the CR path never reads (not mirrored here).  Here: beam (k_alm_copy) -> one Legendre
+// synthesis + ring transform on the component's rings -> per-ring-pair sums (k_md_sums, fixed order) -> sum over ranks
+// -> host 4 x 4 LU with partial pivoting -> four element edits.
+static void solve4_lu(double A[4][4], double* b, double* x) {
+    int piv[4] = {0, 1, 2, 3};
+    for (int k = 0; k < 4; ++k) {
+        int p = k;
+        for (int i = k + 1; i < 4; ++i) if (std::fabs(A[piv[i]][k]) > std::fabs(A[piv[p]][k])) p = i;
+        std::swap(piv[k], piv[p]);
+        const double d = A[piv[k]][k];
+        CMDR_REQUIRE(d != 0.0, "applyMonoDipolePrior: singular normal equations (mask leaves too few pixels)");
+        for (int i = k + 1; i < 4; ++i) {
+            const double f = A[piv[i]][k] / d;
+            for (int j = k; j < 4; ++j) A[piv[i]][j] -= f * A[piv[k]][j];
+            b[piv[i]] -= f * b[piv[k]];
+        }
+    }
+    for (int k = 3; k >= 0; --k) {
+        double s = b[piv[k]];
+        for (int j = k + 1; j < 4; ++j) s -= A[piv[k]][j] * x[j];
+        x[k] = s / A[piv[k]][k];
+    }
+}
+
+void CrSystem::apply_mono_dipole_prior(int comp, double* amp, int nside, const double* b_l_out, const double* mask,
+                                       int type, double* mu) {
+    CMDR_REQUIRE(finalized_, "finalize first");
+    CMDR_REQUIRE(comp >= 0 && comp < (int)comps_.size(), "bad component index");
+    CMDR_REQUIRE(type == 1 || type == 2, "mono prior type must be 1 (monopole) or 2 (monopole+dipole)");
+    CMDR_REQUIRE(amp && mask && mu && nside >= 1, "bad arguments");
+    const CompDev& C = comps_[comp].d;
+    const int lmax = C.lmax;
+    // the component's own map geometry: a band plan of the same (nside, lmax) if there is one, else a plan of its own
+    ShtPlan* P = nullptr;
+    for (Group& G : groups_)
+        if (G.nside == nside && G.lmax == lmax) { P = G.plan.get(); break; }
+    if (!P) {
+        const int64_t key = (int64_t)nside * 65536 + lmax;
+        if (!md_plans_.count(key)) {
+            std::vector<int> rings;
+            for (auto& rs : ring_sets_) if (rs.first == nside) rings = rs.second;
+            md_plans_[key] = std::make_unique<ShtPlan>(nside, lmax, rings, nullptr, 1);
+        }
+        P = md_plans_[key].get();
+    }
+    const int64_t na = nalm_packed(lmax), np = P->npix_local();
+    const int npair = P->npair();
+    md_alm_.ensure((size_t)na);
+    md_map_.ensure((size_t)std::max<int64_t>(np, 1));
+    md_part_.ensure((size_t)std::max(npair, 1) * kMdSums + kMdSums);
+    const double* bl = nullptr;
+    if (b_l_out) {
+        md_bl_.upload(std::vector<double>(b_l_out, b_l_out + lmax + 1));
+        bl = md_bl_.get();
+    }
+    launch_alm_copy(amp + C.pos, lmax, md_alm_.get(), lmax, bl, false, stream_, lmax);      // B_out%conv, T column
+    P->alm2map(md_alm_.get(), na, md_map_.get(), np, 1, false, stream_);                    // map%Y
+    P->md_sums(md_map_.get(), mask, type, md_part_.get(), stream_);
+    sync();
+    std::vector<double> part((size_t)npair * kMdSums);
+    if (npair) CMDR_HIP_CHECK(hipMemcpy(part.data(), md_part_.get(), sizeof(double) * part.size(), hipMemcpyDeviceToHost));
+    double S[kMdSums];
+    for (int k = 0; k < kMdSums; ++k) S[k] = 0.0;
+    for (int p = 0; p < npair; ++p)
+        for (int k = 0; k < kMdSums; ++k) S[k] += part[(size_t)p * kMdSums + k];
+    if (allreduce_ || allreduce_s_ || rccl_.ready()) {   // the mpi_allreduce of a, b / Amat, bmat over the rings' owners
+        double* dv = md_part_.get() + (size_t)npair * kMdSums;
+        CMDR_HIP_CHECK(hipMemcpy(dv, S, sizeof(S), hipMemcpyHostToDevice));
+        reduce(dv, kMdSums);
+        sync();
+        CMDR_HIP_CHECK(hipMemcpy(S, dv, sizeof(S), hipMemcpyDeviceToHost));
+    }
+    mu[0] = mu[1] = mu[2] = mu[3] = 0.0;
+    if (type == 1) {
+        CMDR_REQUIRE(S[1] != 0.0, "applyMonoDipolePrior: the mask is empty");
+        mu[0] = S[0] / S[1];
+    } else {
+        double A[4][4] = {{S[0], S[1], S[2], S[3]}, {S[1], S[4], S[5], S[6]}, {S[2], S[5], S[7], S[8]}, {S[3], S[6], S[8], S[9]}};
+        double b[4] = {S[10], S[11], S[12], S[13]};
+        solve4_lu(A, b, mu);
+    }
+    // (0,0) -= mu0 sqrt(4 pi); (1,-1) -= mu2 sqrt(4 pi / 3); (1,0) -= mu3 sqrt(4 pi / 3); (1,1) += mu1 sqrt(4 pi / 3)
+    const double pi = 3.14159265358979323846, s0 = std::sqrt(4.0 * pi), s1 = std::sqrt(4.0 * pi / 3.0);
+    double e[4];
+    const int64_t i00 = d_packed_index(lmax, 0, 0), i10 = d_packed_index(lmax, 1, 0), i11 = d_packed_index(lmax, 1, 1);
+    CMDR_HIP_CHECK(hipMemcpy(&e[0], amp + C.pos + i00, sizeof(double), hipMemcpyDeviceToHost));
+    e[0] -= mu[0] * s0;
+    CMDR_HIP_CHECK(hipMemcpy(amp + C.pos + i00, &e[0], sizeof(double), hipMemcpyHostToDevice));
+    if (lmax >= 1) {
+        CMDR_HIP_CHECK(hipMemcpy(&e[1], amp + C.pos + i10, sizeof(double), hipMemcpyDeviceToHost));
+        CMDR_HIP_CHECK(hipMemcpy(&e[2], amp + C.pos + i11, 2 * sizeof(double), hipMemcpyDeviceToHost));   // (+1, -1)
+        e[1] -= mu[3] * s1;
+        e[2] += mu[1] * s1;
+        e[3] -= mu[2] * s1;
+        CMDR_HIP_CHECK(hipMemcpy(amp + C.pos + i10, &e[1], sizeof(double), hipMemcpyHostToDevice));
+        CMDR_HIP_CHECK(hipMemcpy(amp + C.pos + i11, &e[2], 2 * sizeof(double), hipMemcpyHostToDevice));
+    }
+}
+
 // cr_compute_chisq (comm_cr_mod.f90:408-465) -> compute_chisq(chisq_fullsky) (comm_chisq_mod.f90:32-118): with the
 // group's amplitudes set to S^1/2 x, chisq = sum_bands sum_pix (sqrtInvN (d - all signal))^2 = || siN (resid - signal
 // of the group) ||^2, resid = the maps the last cmdr_compute_rhs received.  sqrtInvN here carries no samp-group mask.

@@ -62,6 +62,14 @@ class CrSystem {
     void set_comp_f_mean(int comp, const double* F_mean);
     void set_active(int kind, int idx, int active);
     void compute_residual(const double* amp, const double* const* data, double* const* resid);   // device pointers
+    // applyMonoDipolePrior (comm_diffuse_comp_mod.f90:5738-5827; called from sample_amps_by_CG,
+    // comm_signal_mod.f90:186-194) on the amplitudes a chain keeps on the device: amp = the stacked vector after
+    // cr_x2amp (device), mask = the component's mono_prior_map, temperature column, local pixels of the rings
+    // cmdr_ctx_set_rings named for `nside` (device); b_l_out = the output beam B_out%b_l(0:lmax, 1) * mb_eff (host,
+    // nullptr = 1).  type 1 'monopole', 2 'monopole+dipole'.  mu[4] = the fitted (monopole, x, y, z dipole), as printed
+    // by the reference.  Edits the (0,0), (1,-1), (1,0), (1,1) temperature entries of the component in place.
+    void apply_mono_dipole_prior(int comp, double* amp, int nside, const double* b_l_out, const double* mask, int type,
+                                 double* mu);
     void set_cl_diag(int comp, const double* cl);   // getCl(l, p): (lmax_cl+1) x nmaps, for the pseudo-inverse U
     void set_allreduce(AllreduceFn fn, void* user) { allreduce_ = fn; allreduce_user_ = user; }
     void set_allreduce_stream(AllreduceStreamFn fn, void* user) { allreduce_s_ = fn; allreduce_s_user_ = user; }
@@ -173,6 +181,8 @@ class CrSystem {
     };
     std::vector<LowL> lowl_;
     std::map<int, std::unique_ptr<ShtPlan>> lowl_plans_;   // by nside_lowres * 65536 + 2 L
+    std::map<int64_t, std::unique_ptr<ShtPlan>> md_plans_; // applyMonoDipolePrior at (nside, lmax) no band plan has
+    DevBuf<double> md_alm_, md_map_, md_part_, md_bl_;
     void lowl_update(LowL& W);
     struct MixCol { int bm, comp, stokes; };     // one scalar column / first column of a (Q,U) pair of a mixing batch
     struct MixBatch {

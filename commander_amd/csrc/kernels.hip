@@ -1298,6 +1298,42 @@ void launch_ring(int mode, const RingDev* rings, const int* cls, int ncls, int l
 #undef CMDR_RING
 }
 
+// Masked monopole / dipole sums of applyMonoDipolePrior: one workgroup per ring pair, every thread walks its pixels of the
+// northern and the southern ring, the 256 partial sums fold in a fixed tree -> out[pair][16] (deterministic; the host
+// adds the pairs in order).
+__global__ void __launch_bounds__(256) k_md_sums(const RingDev* __restrict__ rings, int nside, const double* __restrict__ map,
+                                                const double* __restrict__ mask, int type, double* __restrict__ out) {
+    __shared__ double red[256];
+    const RingDev d = rings[blockIdx.x];
+    double acc[kMdSums];
+#pragma unroll
+    for (int k = 0; k < kMdSums; ++k) acc[k] = 0.0;
+    const double z = healpix_ring_z(nside, d.ring), sth = sqrt((1.0 - z) * (1.0 + z));
+    const double dphi = 6.283185307179586476925287 / d.nphi;
+    for (int k = threadIdx.x; k < d.nphi; k += 256) {
+        const double phi = d.phi0 + dphi * k;
+        md_pixel_accum(type, z, sth, phi, map[d.startN + k], mask[d.startN + k], acc);
+        if (d.startS >= 0) md_pixel_accum(type, -z, sth, phi, map[d.startS + k], mask[d.startS + k], acc);
+    }
+    const int nsum = type == 1 ? 2 : 14;
+    for (int q = 0; q < nsum; ++q) {
+        red[threadIdx.x] = acc[q];
+        __syncthreads();
+        for (int o = 128; o > 0; o >>= 1) {
+            if ((int)threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
+            __syncthreads();
+        }
+        if (threadIdx.x == 0) out[(int64_t)blockIdx.x * kMdSums + q] = red[0];
+        __syncthreads();
+    }
+    if ((int)threadIdx.x >= nsum && (int)threadIdx.x < kMdSums) out[(int64_t)blockIdx.x * kMdSums + threadIdx.x] = 0.0;
+}
+void launch_md_sums(const RingDev* rings, int npair, int nside, const double* map, const double* mask, int type,
+                    double* out, hipStream_t s) {
+    if (npair == 0) return;
+    hipLaunchKernelGGL(k_md_sums, dim3(npair), dim3(256), 0, s, rings, nside, map, mask, type, out);
+}
+
 // ===================================================================================== a_lm streaming kernels
 // All run on an (l, m) grid: blockIdx.y = m, l = m + blockIdx.x*256 + threadIdx.x.
 

@@ -32,6 +32,9 @@ void launch_ring(int mode, const RingDev* rings, const int* cls, int ncls, int l
 // multiplier spectra of the Toeplitz pairs in cls (class log2M = their circulant size) from t_d in phase layout
 void launch_ring_toeplitz_spec(const RingDev* rings, const int* cls, int ncls, int log2M, const double* td,
                                int64_t prow, cd* that, const cd* tw, int log2Mmax, hipStream_t s);
+// masked monopole / dipole sums per ring pair (applyMonoDipolePrior): out[npair][16], see md_pixel_accum
+void launch_md_sums(const RingDev* rings, int npair, int nside, const double* map, const double* mask, int type,
+                    double* out, hipStream_t s);
 void launch_alm_to_stream(const double* alm, int64_t alm_stride, double* ast, const double* cnorm, int lmax,
                           int nmaps, hipStream_t s);
 // lwtab (optional): [(lmax+1) * nchunk] first l written for (m, chunk) -- entries below it are structurally zero and

@@ -11,6 +11,7 @@
 //     (power-of-two rings directly, polar-cap rings through Bluestein), optionally fusing the per-pixel N^-1
 //     so the map never leaves the CU between synthesis and adjoint.
 #pragma once
+#include <cmath>
 #include <cstdint>
 
 #if defined(__HIPCC__)
@@ -659,6 +660,31 @@ struct RingDev {  // device mirror of RingPairDesc
     int log2T;             // 0, or log2 of the circulant size of this pair's Toeplitz form of Y^t diag(mul) Y (below)
     long long that_off;    // offset of the pair's multiplier spectrum in a per-map array (complex units)
 };
+
+// Masked monopole / dipole sums over the pixels of one ring (applyMonoDipolePrior, comm_diffuse_comp_mod.f90:5761-5794).
+//   type 1 ('monopole'):         acc[0] += map * mask, acc[1] += mask                       (:5764-5765; mask as weight)
+//   type 2 ('monopole+dipole'):  pixels with mask >= 0.5 (:5781): v = (1, pix2vec_ring), acc[0..9] += upper triangle of
+//                                v v^t (row-major: 00 01 02 03 11 12 13 22 23 33), acc[10..13] += v * map   (:5782-5790)
+// z of the ring from its number as HEALPix pix2vec_ring forms it (cap: 1 - i^2 / (3 N^2), belt: (2 N - i) 2 / (3 N));
+// phi of pixel k = phi0 + 2 pi k / nphi.  `south` mirrors the ring (z -> -z).
+constexpr int kMdSums = 16;
+CMDR_HD double healpix_ring_z(int nside, int ring /* northern ring number 1..2 nside */) {
+    if (ring < nside) return 1.0 - (double)ring * ring / (3.0 * nside * (double)nside);
+    return (2.0 * nside - ring) * 2.0 / (3.0 * nside);
+}
+CMDR_HD void md_pixel_accum(int type, double z, double sth, double phi, double mapv, double maskv, double* acc) {
+    if (type == 1) {
+        acc[0] += mapv * maskv;
+        acc[1] += maskv;
+        return;
+    }
+    if (maskv < 0.5) return;
+    const double v1 = sth * cos(phi), v2 = sth * sin(phi), v3 = z;
+    acc[0] += 1.0;     acc[1] += v1;      acc[2] += v2;      acc[3] += v3;
+    acc[4] += v1 * v1; acc[5] += v1 * v2; acc[6] += v1 * v3;
+    acc[7] += v2 * v2; acc[8] += v2 * v3; acc[9] += v3 * v3;
+    acc[10] += mapv;   acc[11] += v1 * mapv; acc[12] += v2 * mapv; acc[13] += v3 * mapv;
+}
 
 // HEALPix rings have n*phi0 = pi (phi0 = pi/(4i), n = 4i; belt: pi/(4N), n = 4N) or phi0 = 0, hence
 //   e^{i (j + k n) phi0} = (-1)^k rot_j ,  e^{i (k n - j) phi0} = (-1)^k conj(rot_j) ,  rot_j = e^{i pi j / n}

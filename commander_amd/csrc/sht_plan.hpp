@@ -70,6 +70,11 @@ class ShtPlan {
     // caller (pixel_weights()).  Needs nT + 2 npol <= max_maps.
     void sandwich(const double* d_in, double* d_out, const double* const* d_mul, int nT, int npol, hipStream_t s, bool share_in = false,
                   bool sum_out = false);
+    // masked monopole / dipole sums of a local map (applyMonoDipolePrior): d_out[npair()][16] per ring pair
+    int npair() const { return T_.ring.npair; }
+    void md_sums(const double* d_map, const double* d_mask, int type, double* d_out, hipStream_t s) {
+        launch_md_sums(rings_.get(), T_.ring.npair, T_.nside, d_map, d_mask, type, d_out, s);
+    }
     // W_ring * 4 pi / Npix for every pixel of the local map (host)
     std::vector<double> pixel_weights() const;
 

@@ -13,6 +13,7 @@ module cmdr_hip_mod
 
   integer(c_int), parameter :: CMDR_YtW = 0, CMDR_Y = 1, CMDR_Yt = 2, CMDR_WY = 3   ! sharp.f90:8-14
   integer(c_int), parameter :: CMDR_CRIT_RESIDUAL = 0, CMDR_CRIT_FIXED_ITER = 1, CMDR_CRIT_CHISQ = 2   ! cpar%cg_conv_crit
+  integer(c_int), parameter :: CMDR_MONO_PRIOR_MONOPOLE = 1, CMDR_MONO_PRIOR_MONOPOLE_DIPOLE = 2       ! mono_prior_type
 
   ! one node of comm_Cl's bins2 tree (comm_Cl_mod.f90:41-47), flattened depth-first; sample /= 0 where stat == 'S'
   type, bind(c) :: cmdr_cl_bin
@@ -370,6 +371,30 @@ module cmdr_hip_mod
        type(c_ptr), intent(in) :: data_dev(*), resid_dev(*)
        integer(c_int)          :: ierr
      end function cmdr_compute_residual_dev
+
+     ! applyMonoDipolePrior (comm_diffuse_comp_mod.f90:5738-5827) after cr_x2amp (comm_signal_mod.f90:186-194):
+     ! prior_type 1 = 'monopole', 2 = 'monopole+dipole'; amp(ncr) stacked amplitudes, edited in place; b_l_out may be
+     ! c_null_ptr (no output beam); mask = mono_prior_map%map(:,1) on the local pixels; mu(4) = the fit the reference prints
+     function cmdr_apply_mono_dipole_prior(ctx, comp, amp, nside, b_l_out, mask, npix_local, prior_type, mu) &
+          & bind(c, name='cmdr_apply_mono_dipole_prior') result(ierr)
+       import :: c_int, c_ptr, c_double, c_int64_t
+       type(c_ptr),        value         :: ctx, b_l_out
+       integer(c_int),     value         :: comp, nside, prior_type
+       integer(c_int64_t), value         :: npix_local
+       real(c_double),     intent(inout) :: amp(*)
+       real(c_double),     intent(in)    :: mask(*)
+       real(c_double),     intent(out)   :: mu(4)
+       integer(c_int)                    :: ierr
+     end function cmdr_apply_mono_dipole_prior
+
+     function cmdr_apply_mono_dipole_prior_dev(ctx, comp, amp_dev, nside, b_l_out, mask_dev, prior_type, mu) &
+          & bind(c, name='cmdr_apply_mono_dipole_prior_dev') result(ierr)
+       import :: c_int, c_ptr, c_double
+       type(c_ptr),    value       :: ctx, amp_dev, b_l_out, mask_dev
+       integer(c_int), value       :: comp, nside, prior_type
+       real(c_double), intent(out) :: mu(4)
+       integer(c_int)              :: ierr
+     end function cmdr_apply_mono_dipole_prior_dev
 
      function cmdr_matmulA(ctx, x, y) bind(c, name='cmdr_matmulA') result(ierr)
        import :: c_int, c_ptr, c_double

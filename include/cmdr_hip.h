@@ -221,6 +221,25 @@ int cmdr_compute_rhs_dev(cmdr_ctx* ctx, int sample, const double* const* resid_d
 int cmdr_compute_residual(cmdr_ctx* ctx, const double* amp, const double* const* data, double* const* resid);
 int cmdr_compute_residual_dev(cmdr_ctx* ctx, const double* amp_dev, const double* const* data_dev,
                               double* const* resid_dev);
+/* applyMonoDipolePrior (comm_diffuse_comp_mod.f90:5738-5827), the tail of sample_amps_by_CG after cr_x2amp
+ * (comm_signal_mod.f90:186-194) for a diffuse component with mono_prior_type /= 'none'
+ * (COMP_MONOPOLE_PRIOR = '<type>:<mask file>', comm_diffuse_comp_mod.f90:352-356): beam-convolve the just-solved
+ * temperature a_lm with the output beam, synthesise the map (map%Y), fit a monopole as the mask-weighted mean
+ * (type 1 'monopole', :5761-5768) or monopole + dipole by least squares over the pixels with mask >= 0.5 (type 2
+ * 'monopole+dipole', :5775-5794) and subtract the fit from the (0,0), (1,-1), (1,0), (1,1) coefficients (:5811-5824).
+ *   comp     : diffuse component index as returned by cmdr_comp_add
+ *   amp      : the stacked amplitudes (ncr) as cmdr_solve left them (physical units); edited in place
+ *   nside    : the component's own map resolution (x%info%nside); rank-local rings as named by cmdr_ctx_set_rings
+ *   b_l_out  : host, B_out%b_l(0:lmax_amp, 1) * mb_eff, or NULL for no output beam
+ *   mask     : mono_prior_map%map(:, 1) on the local pixels of `nside` (npix_local doubles)
+ *   mu[4]    : out, host: the fit (monopole, dipole x, y, z) the reference prints (:5773, :5802)
+ * With several ranks the sums are reduced through the context's communicator / all-reduce callback, like the
+ * mpi_allreduce at :5766-5767, :5792-5793.  'crosscorr' stops the reference too (:5804-5806).  The reference also
+ * subtracts the fit from self%x%map, a pixel buffer of the driver the CR path never reads: not mirrored. */
+int cmdr_apply_mono_dipole_prior(cmdr_ctx* ctx, int comp, double* amp, int nside, const double* b_l_out,
+                                 const double* mask, int64_t npix_local, int type, double* mu);
+int cmdr_apply_mono_dipole_prior_dev(cmdr_ctx* ctx, int comp, double* amp_dev, int nside, const double* b_l_out,
+                                     const double* mask_dev, int type, double* mu);
 /* solve_cr_eqn_by_CG (comm_cr_mod.f90:48-406).  crit: 0 'residual', 1 'fixed_iter', 2 'chisq' (cpar%cg_conv_crit;
  * 'chisq' = relative change of cr_compute_chisq, :223-226, :239-242, :408-465, evaluated against the residual maps the
  * last cmdr_compute_rhs call received -- keep them alive for the _dev form -- with tol as the limit);

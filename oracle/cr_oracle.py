@@ -378,6 +378,51 @@ class CRSystem:
         return healpix.alm_equal(m, b.info, c.info, nmaps_dst=c.nmaps)
 
     # ------------------------------------------------------------------ compute_residual
+    def apply_mono_dipole_prior(self, k, amp, nside, mask, prior_type="monopole", b_l_out=None, pix=None,
+                                allreduce=None):
+        """``applyMonoDipolePrior`` (comm_diffuse_comp_mod.f90:5738-5827), the tail of ``sample_amps_by_CG``
+        (comm_signal_mod.f90:186-194), on component ``k`` of the stacked amplitudes ``amp`` (physical units).
+        Returns (amp_new, mu[0:4]).  ``mask`` = mono_prior_map%map(:,1); ``pix`` = this rank's pixel numbers
+        (info%pix, default: the full sky) and ``allreduce`` the sum over ranks of :5766-5767 / :5792-5793."""
+        c = self.comps[k]
+        if prior_type == "none":                                   # :5746-5748
+            return amp.copy(), np.zeros(4)
+        alm = self.extract(k, amp)
+        # map => comm_map(self%x); B_out%conv(trans=.false.); map%Y   (:5754-5756; only column 1 is read afterwards)
+        a1 = alm[:, 0].copy()
+        if b_l_out is not None:
+            a1 *= np.asarray(b_l_out, dtype=np.float64)[c.info.l]  # comm_B_bl_mod.f90:108-127
+        full = sht.Y(nside, c.lmax_amp, a1)
+        if pix is None:
+            pix = np.arange(12 * nside * nside)
+        m = full[pix]
+        mask = np.asarray(mask, dtype=np.float64).ravel()
+        red = allreduce if allreduce is not None else (lambda v: v)
+        mu = np.zeros(4)
+        if prior_type == "monopole":                               # :5761-5768
+            a = red(np.array([np.sum(m * mask)]))[0]
+            b = red(np.array([np.sum(mask)]))[0]
+            mu[0] = a / b
+        elif prior_type == "monopole+dipole":                      # :5775-5794
+            theta, phi = healpix.pix_angles(nside)
+            v = np.stack([np.ones(pix.size), np.sin(theta[pix]) * np.cos(phi[pix]), np.sin(theta[pix]) * np.sin(phi[pix]),
+                          np.cos(theta[pix])], axis=1)              # v(0) = 1, v(1:3) = pix2vec_ring
+            use = mask >= 0.5                                       # 'if (mask < 0.5d0) cycle'
+            Amat = red(v[use].T @ v[use])
+            bmat = red(v[use].T @ m[use])
+            mu = np.linalg.solve(Amat, bmat)                        # solve_system_real = dgesv (math_tools.f90:846-883)
+        else:
+            raise ValueError("Cross-correlation monopole prior not implemented yet")   # :5804-5806 (the reference stops)
+        # subtract in harmonic space (:5811-5824): the loop over i with lm(:, i) tests, as four index lookups
+        for (l, mm, sgn, j, f) in ((0, 0, -1.0, 0, np.sqrt(4.0 * np.pi)), (1, -1, -1.0, 2, np.sqrt(4.0 * np.pi / 3.0)),
+                                   (1, 0, -1.0, 3, np.sqrt(4.0 * np.pi / 3.0)), (1, 1, +1.0, 1, np.sqrt(4.0 * np.pi / 3.0))):
+            i = c.info.lm2i(l, mm)
+            if i >= 0:
+                alm[i, 0] += sgn * mu[j] * f
+        out = amp.copy()
+        self.insert(k, False, alm, out)
+        return out, mu
+
     def compute_residual(self, data, amp):
         """commander3/src/comm_chisq_mod.f90:196-267 with cg_samp_group given: for every band, the data map minus the
         signal of the components that are NOT active in the sampling group.  amp: stacked amplitudes (c%x, physical

@@ -7,6 +7,8 @@ produced by checkers that are independent of both the oracle's recursions/FFTs a
   * invn_diag_3j_map.npz          : the same together with the noise map it belongs to (pins the product's pipeline)
   * lm2i_tables.json              : Commander's a_lm index maps for lmax=4, P=1 and P=3 (comm_map_mod.f90:228-261)
   * kat.json                      : the reference's own 2x2 PCG known-answer test and the fiducial dipole constants
+  * mini_commander.json           : what fortran/mini_commander.f90 must print: the CPU oracle (oracle/cr_oracle.py)
+                                    run on the same problem and the same LCG draws (python tests/golden/make_golden.py mini)
 """
 import json
 import os
@@ -74,9 +76,61 @@ def invn_map():
                         diag=wigner.invn_diag_3j(nside, lmax, al0))
 
 
+def mini_commander():
+    """mini_commander.json: the third amplitude sample of fortran/mini_commander.f90 (Nside 64, lmax 128, one band, CMB T;
+    cr_computeRHS + 50 fixed PCG iterations + applyMonoDipolePrior 'monopole+dipole') computed by the oracle from the
+    same inputs: the driver's minimal-standard LCG + Box-Muller draws in the driver's order."""
+    from oracle import cr_oracle as cro
+    nside, lmax = 64, 128
+    npix, nalm = 12 * nside * nside, (lmax + 1) ** 2
+    l = np.arange(lmax + 1)
+    sigma = (60.0 / 60.0 * np.pi / 180.0) / np.sqrt(8.0 * np.log(2.0))
+    b_l = np.exp(-0.5 * l * (l + 1.0) * sigma ** 2)
+    Dl = np.full((lmax + 1, 1), 1000.0)
+    z = 1.0 - 2.0 * (np.arange(1, npix + 1) - 0.5) / npix
+    siN = 1.0 / (40.0 * (1.0 + 0.5 * z))
+    siN[np.abs(z) < 0.2] = 0.0
+    cl = cro.Cl(lmax, 1, Dl)
+    # the driver's own S tables: C_0 = D_0, C_l = D_l 2 pi / (l (l + 1))
+    Cl_drv = np.where(l == 0, 1000.0, 1000.0 * 2.0 * np.pi / np.maximum(l * (l + 1.0), 1.0))
+    assert np.allclose(cl.sqrtS_mat[0, 0, :], np.sqrt(Cl_drv), rtol=1e-14)
+    S = cro.CRSystem([cro.Band(nside, lmax, siN[:, None], b_l[:, None])], [cro.DiffuseComp(lmax, 1, cl, [[1.0]])])
+    S.init_precond_diag()
+    state = [163425]
+
+    def uni():
+        state[0] = (16807 * state[0]) % 2147483647
+        return state[0] / 2147483647.0
+
+    def gauss():
+        u1 = uni(); u2 = uni()
+        return np.sqrt(-2.0 * np.log(u1)) * np.cos(2.0 * np.pi * u2)
+    mask = (siN > 0.0).astype(np.float64)
+    for it in range(3):
+        resid, xi = np.zeros(npix), np.zeros(npix)
+        for i in range(npix):
+            if siN[i] > 0.0:
+                resid[i] = gauss() / siN[i]
+            xi[i] = gauss()
+        eta = np.array([gauss() for _ in range(nalm)])
+        if it < 2:
+            continue                       # the samples are independent; only the draws of the earlier ones matter
+        rhs = S.computeRHS([resid[:, None]], "sample", [xi[:, None]], eta)
+        S.update_precond_diag()
+        x, niter, _ = S.solve(rhs, "fixed_iter", 1e-8, 5, 50, 1)
+        amp, mu = S.apply_mono_dipole_prior(0, x, nside, mask, "monopole+dipole", b_l)
+    out = {"nside": nside, "lmax": lmax, "niter": int(niter), "mu": [float(v) for v in mu],
+           "norm": float(np.linalg.norm(amp)), "amp_first8": [float(v) for v in amp[:8]],
+           "generator": "python tests/golden/make_golden.py mini  (oracle/cr_oracle.py)"}
+    json.dump(out, open(os.path.join(HERE, "mini_commander.json"), "w"), indent=1)
+    print(out)
+
+
 if __name__ == "__main__":
     if len(sys.argv) > 1 and sys.argv[1] == "invn_map":
         invn_map()
+    elif len(sys.argv) > 1 and sys.argv[1] == "mini":
+        mini_commander()
     else:
         main()
         invn_map()

@@ -380,6 +380,62 @@ def lowl_precond_checks(_lib=None, nside=16, lmax=32, L=6, nside_low=4, tol=1e-1
         assert np.array_equal(ctx.cr_invM(x), plain)
 
 
+def mono_dipole_prior_checks(_lib=None, tol=1e-11):
+    """``applyMonoDipolePrior`` (comm_diffuse_comp_mod.f90:5738-5827), the tail of ``sample_amps_by_CG``
+    (comm_signal_mod.f90:186-194): product vs oracle for 'monopole' and 'monopole+dipole', with and without an output
+    beam, T and T,Q,U components, the component on a band plan's geometry and on one of its own (other lmax, other
+    nside) -- and, independent of the reference's text, the property that pins the four sign / normalisation factors of
+    :5811-5824: without an output beam the masked fit of the corrected map is zero."""
+    from commander_amd import synth, healpix
+    from commander_amd.cr import build_context
+    from oracle import sht as osht, healpix as ohp
+    rng = np.random.default_rng(31)
+    for pol, comp_lmax, ns_c in ((False, [32, 24], 16), (True, [32, 32], 16), (False, [20, 32], 8)):
+        spec = synth.make_problem("cfg2", nside=16, lmax=32, comp_lmax=comp_lmax, pol=pol)
+        S = oracle_system(spec)
+        ctx = build_context(spec, _lib=_lib)
+        amp = rng.standard_normal(ctx.ncr) * 10.0
+        z = healpix.pix_z(ns_c)
+        mask = ((np.abs(z) > 0.3) & (rng.random(z.size) > 0.1)).astype(np.float64)
+        wmask = mask * (0.6 + 0.4 * rng.random(z.size))             # 'monopole' uses the mask as a weight (:5764-5765)
+        for k in range(2):
+            lm = spec["comps"][k]["lmax"]
+            bl = np.exp(-0.5 * np.arange(lm + 1) * (np.arange(lm + 1) + 1.0) * (np.radians(1.5) / 2.355) ** 2)
+            for ptype, m in (("monopole", wmask), ("monopole+dipole", wmask)):
+                for b_l_out in (None, bl):
+                    got, mu = ctx.applyMonoDipolePrior(k, amp, ns_c, m, ptype, b_l_out)
+                    want, muo = S.apply_mono_dipole_prior(k, amp, ns_c, m, ptype, b_l_out)
+                    assert rel(got, want) < tol, (pol, k, ptype, rel(got, want))
+                    assert np.allclose(mu, muo, rtol=1e-9, atol=1e-11 * np.abs(muo).max()), (mu, muo)
+                    changed = np.flatnonzero(got != amp)
+                    assert 1 <= changed.size <= (1 if ptype == "monopole" else 4)      # only (0,0), (1,-1), (1,0), (1,1)
+                    if b_l_out is None:      # the corrected map has no masked monopole (/ dipole) left
+                        _, mu2 = S.apply_mono_dipole_prior(k, got, ns_c, m, ptype, None)
+                        assert np.abs(mu2).max() < 1e-10 * max(np.abs(muo).max(), 1.0), mu2
+        # device-resident form == host form
+        if hasattr(ctx, "dev"):
+            d_amp, d_mask = ctx.dev(ctx.ncr, amp), ctx.dev(wmask.size, wmask)
+            mu_d = ctx.applyMonoDipolePrior_dev(0, d_amp, ns_c, d_mask, "monopole+dipole")
+            ref, mu_h = ctx.applyMonoDipolePrior(0, amp, ns_c, wmask, "monopole+dipole")
+            assert np.array_equal(d_amp.download(), ref) and np.array_equal(mu_d, mu_h)
+    # the dipole of a pure (1, m) map in HEALPix vector components: unit x, y, z dipoles come back as mu = e_x, e_y, e_z
+    nside, lmax = 8, 4
+    th, ph = ohp.pix_angles(nside)
+    spec = synth.make_problem("cfg1", nside=nside, lmax=lmax)
+    ctx = build_context(spec, _lib=_lib)
+    info = ohp.AlmInfo(lmax)
+    s1 = np.sqrt(4.0 * np.pi / 3.0)
+    for j, vec in enumerate((np.sin(th) * np.cos(ph), np.sin(th) * np.sin(ph), np.cos(th))):
+        a = np.zeros(info.nalm)
+        a[info.lm2i(0, 0)] = 3.0 * np.sqrt(4.0 * np.pi)
+        a[info.lm2i(1, (1, -1, 0)[j])] = 2.0 * s1 * (-1.0, 1.0, 1.0)[j]
+        assert np.allclose(osht.Y(nside, lmax, a), 3.0 + 2.0 * vec, atol=1e-12)      # the SHT is pinned by brute force
+        got, mu = ctx.applyMonoDipolePrior(0, a, nside, np.ones(th.size), "monopole+dipole")
+        e = np.zeros(4); e[0] = 3.0; e[1 + j] = 2.0
+        assert np.allclose(mu, e, atol=1e-10), (j, mu)
+        assert np.abs(got).max() < 1e-10                                             # nothing is left of the map
+
+
 def literal_quirks_checks(_lib=None, nside=16, lmax=32, tol=1e-11):
     """cr_matmulA's literal buffer re-use (comm_cr_mod.f90:846-861): with components of different lmax_amp the later,
     smaller one reads the earlier one's coefficients above its own lmax.  Product and oracle agree in both modes, the

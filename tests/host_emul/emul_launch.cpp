@@ -236,6 +236,22 @@ void launch_ring_toeplitz_spec(const RingDev* rings, const int* cls, int ncls, i
     }
 }
 
+void launch_md_sums(const RingDev* rings, int npair, int nside, const double* map, const double* mask, int type,
+                    double* out, hipStream_t) {
+    for (int p = 0; p < npair; ++p) {
+        const RingDev d = rings[p];
+        double acc[kMdSums];
+        for (int k = 0; k < kMdSums; ++k) acc[k] = 0.0;
+        const double z = healpix_ring_z(nside, d.ring), sth = std::sqrt((1.0 - z) * (1.0 + z));
+        const double dphi = 6.283185307179586476925287 / d.nphi;
+        for (int k = 0; k < d.nphi; ++k) {
+            const double phi = d.phi0 + dphi * k;
+            md_pixel_accum(type, z, sth, phi, map[d.startN + k], mask[d.startN + k], acc);
+            if (d.startS >= 0) md_pixel_accum(type, -z, sth, phi, map[d.startS + k], mask[d.startS + k], acc);
+        }
+        for (int k = 0; k < kMdSums; ++k) out[(int64_t)p * kMdSums + k] = acc[k];
+    }
+}
 void launch_alm_to_stream(const double* alm, int64_t alm_stride, double* ast, const double* cnorm, int lmax,
                           int nmaps, hipStream_t) {
     for (int k = 0; k < nmaps; ++k)

@@ -362,6 +362,12 @@ def test_lowl_preconditioner_gpu():
     lowl_precond_checks(None, nside=32, lmax=64, L=8, nside_low=8)
 
 
+def test_mono_dipole_prior_gpu():
+    """applyMonoDipolePrior (comm_diffuse_comp_mod.f90:5738-5827) on the GPU vs the oracle."""
+    from helpers import mono_dipole_prior_checks
+    mono_dipole_prior_checks(None)
+
+
 def test_literal_quirks_switch_gpu():
     from helpers import literal_quirks_checks
     literal_quirks_checks(None, nside=32, lmax=64)

@@ -19,6 +19,22 @@ def test_mini_commander_runs():
     assert out.returncode == 0, out.stdout + out.stderr
     assert "mini_commander: OK" in out.stdout
     assert out.stdout.count("CG iters =  50") == 3
+    # numbers, not only "OK": the third sample (RHS + 50 PCG iterations + applyMonoDipolePrior) against the CPU oracle's
+    # solution of the same LCG draws (tests/golden/mini_commander.json <- tests/golden/make_golden.py mini)
+    import json
+    import re
+    import numpy as np
+    gold = json.load(open(os.path.join(ROOT, "tests", "golden", "mini_commander.json")))
+    num = r"[-+]?\d\.\d+E[-+]\d+"
+    mu = [float(v) for v in re.findall(num, re.search(r"golden mu   =(.*)", out.stdout).group(1))]
+    norm = float(re.search(r"golden norm =\s*(%s)" % num, out.stdout).group(1))
+    amp = [float(re.search(r"golden amp%d =\s*(%s)" % (i, num), out.stdout).group(1)) for i in range(1, 9)]
+    assert len(mu) == 4
+    # fixed_iter, 50 iterations: rel-L2 <= 1e-8 between GPU and oracle; Box-Muller through two libm's
+    # (measured: 1e-15 on a 10-iteration solve; the margin is for the two Box-Muller libm's and 50 iterations)
+    assert abs(norm - gold["norm"]) < 1e-9 * gold["norm"]
+    assert np.allclose(amp, gold["amp_first8"], rtol=1e-8, atol=1e-9)
+    assert np.allclose(mu, gold["mu"], rtol=1e-7, atol=1e-10)
 
 
 def test_api_tour_runs():

@@ -464,6 +464,13 @@ def test_emul_lowl_preconditioner(EL):
     lowl_precond_checks(EL)
 
 
+def test_emul_mono_dipole_prior(EL):
+    """the tail of sample_amps_by_CG, applyMonoDipolePrior on the solved a_lm (product vs oracle + the
+    zero-refit property)."""
+    from helpers import mono_dipole_prior_checks
+    mono_dipole_prior_checks(EL)
+
+
 def test_emul_literal_quirks_switch(EL):
     """the reference's stale-l behaviour in cr_matmulA is available behind a switch (oracle + product)."""
     from helpers import literal_quirks_checks

@@ -24,6 +24,12 @@ def _spec(nside, lmax, pix, mode):
     return spec
 
 
+def _md_mask(nside):
+    from commander_amd import healpix
+    z = healpix.pix_z(nside)
+    return ((np.abs(z) > 0.25) * (0.5 + 0.5 * np.random.default_rng(3).random(z.size))).astype(np.float64)
+
+
 def _worker(rank, world, port, out_dir, mode):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
     sys.path.insert(0, ROOT)
@@ -60,7 +66,13 @@ def _worker(rank, world, port, out_dir, mode):
     d0 = ctx.alpha_nu(0) if mode == "varying" else ctx.invN_diag(0)
     # the 'chisq' criterion sums squared residuals over the ranks' pixels: same stopping iteration as one rank
     solc, nc, statc, _ = ctx.solve_cr_eqn_by_CG(b, "chisq", 1e-3, 2, 60, 1)
-    np.savez(os.path.join(out_dir, "rank%d.npz" % rank), y=y, b=b, sol=sol, d0=d0, solc=solc, nc=nc)
+    # applyMonoDipolePrior on the ring-sharded map: the masked sums are reduced over the ranks (mpi_allreduce at
+    # comm_diffuse_comp_mod.f90:5766-5767, :5792-5793)
+    mask = _md_mask(nside)[pix]
+    md1, mu1 = ctx.applyMonoDipolePrior(0, sol, nside, mask, "monopole")
+    md2, mu2 = ctx.applyMonoDipolePrior(0, sol, nside, mask, "monopole+dipole")
+    np.savez(os.path.join(out_dir, "rank%d.npz" % rank), y=y, b=b, sol=sol, d0=d0, solc=solc, nc=nc, md1=md1, md2=md2,
+             mu1=mu1, mu2=mu2)
     dist.barrier()
     dist.destroy_process_group()
 
@@ -88,6 +100,8 @@ def test_two_rank_ring_sharding_matches_single_rank(tmp_path, mode):
     b = ctx.cr_computeRHS("sample", resid, xi, eta)
     sol, n, stat, res = ctx.solve_cr_eqn_by_CG(b, "fixed_iter", 1e-8, 5, 12, 1)
     solc, nc, statc, _ = ctx.solve_cr_eqn_by_CG(b, "chisq", 1e-3, 2, 60, 1)
+    md1, mu1 = ctx.applyMonoDipolePrior(0, sol, 16, _md_mask(16), "monopole")
+    md2, mu2 = ctx.applyMonoDipolePrior(0, sol, 16, _md_mask(16), "monopole+dipole")
     for r in range(2):
         g = np.load(os.path.join(str(tmp_path), "rank%d.npz" % r))
         assert int(g["nc"]) == nc and 2 <= nc < 60 and rel(g["solc"], solc) < 1e-8
@@ -95,6 +109,9 @@ def test_two_rank_ring_sharding_matches_single_rank(tmp_path, mode):
         assert rel(g["b"], b) < 1e-12
         assert rel(g["d0"], ctx.alpha_nu(0) if mode == "varying" else ctx.invN_diag(0)) < 1e-12
         assert rel(g["sol"], sol) < 1e-10
+        # the prior correction of the (slightly different) 2-rank solution equals the single-rank one to the same level
+        assert np.allclose(g["mu1"], mu1, rtol=1e-8, atol=1e-10) and np.allclose(g["mu2"], mu2, rtol=1e-8, atol=1e-10)
+        assert rel(g["md1"], md1) < 1e-10 and rel(g["md2"], md2) < 1e-10
 
 
 def _hybrid_worker(rank, world, port, out_dir):
