@@ -670,6 +670,13 @@ int cmdr_problem_info(cmdr_ctx* ctx, int64_t* out) {
     });
 }
 
+int cmdr_problem_info_ext(cmdr_ctx* ctx, int n, int64_t* out) {
+    return guarded([&] {
+        CMDR_REQUIRE(ctx && out, "bad arguments");
+        ctx->sys->problem_info_ext(n, out);
+    });
+}
+
 int cmdr_sigma_l(const double* alm, int lmax, int nmaps, double* sigma_l) {
     return guarded([&] {
         CMDR_REQUIRE(alm && sigma_l && lmax >= 0 && nmaps >= 1 && nmaps <= 3, "bad arguments");

@@ -62,6 +62,22 @@ void CrSystem::problem_info(int64_t* out) const {
     out[2] = steps;
 }
 
+void CrSystem::problem_info_ext(int n, int64_t* out) const {
+    CMDR_REQUIRE(n >= 3 && n <= 8, "bad size");
+    problem_info(out);
+    const Group& G = groups_[0];
+    int64_t v[8] = {out[0], out[1], out[2], 0, G.nT, G.npol, G.plan->tables().leg.npair, (int64_t)groups_.size()};
+    if (G.npol) {   // (ring pair, l, m) steps of one spin-2 launch for ONE polarisation pair
+        const Legendre2Tables& L2 = G.plan->tables().leg2;
+        for (int m = 0; m <= L2.lmax; ++m)
+            for (int p = 0; p < G.plan->tables().leg.npair; ++p) {
+                const int s = L2.ls[(size_t)m * L2.npair_pad + p];
+                if (s != kLsNever) v[3] += L2.lmax - s + 1;
+            }
+    }
+    for (int k = 0; k < n; ++k) out[k] = v[k];
+}
+
 void CrSystem::span_begin(int kind, hipStream_t st) {
     if (!profile_) return;
     Span s;
@@ -801,7 +817,7 @@ void CrSystem::adjoint_groups_to_yc(bool from_maps) {
                 span_begin(5);
             });
             span_end();
-            if (G.npol) P.adjoint2_to_partials(G.npol, G.nT, stream_);
+            if (G.npol) { span_begin(7); P.adjoint2_to_partials(G.npol, G.nT, stream_); span_end(); }
         }
         span_end();
         launch_band_post(comps_dev_.get(), ncomp, lmax_max_, P.partials(), P.part_map_stride(), P.leg().tri_elems(),
@@ -889,7 +905,7 @@ void CrSystem::matmulA_impl(const double* x, double* y, bool sx_ready, bool fini
         }
         span_begin(0);
         synth_T_of(G, sx_.get(), wfwd, extra);                                       // Y        :891 (T: spin 0)
-        if (G.npol) P.synth2_from_stream(G.npol, G.nT, stream_);                     // (Q,U): spin 2, comm_map_mod.f90:446
+        if (G.npol) { span_begin(6); P.synth2_from_stream(G.npol, G.nT, stream_); span_end(); }   // (Q,U): spin 2, comm_map_mod.f90:446
         span_end();
         span_begin(1);
         P.rings(2, nullptr, 0, G.mul_ptrs.get(), false, G.nbm, stream_, G.that.get());   // N^-1 :905 fused with both FFTs

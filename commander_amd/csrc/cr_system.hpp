@@ -126,8 +126,9 @@ class CrSystem {
     // HIP-event timing of the dominant kernels on the library stream (bench.py roofline leg).
     // kinds: 0 Legendre synthesis, 1 fused ring stage, 2 Legendre adjoint, 3 whole matvec
     void set_profile(bool on);
-    void read_profile(double* ms_sum, long long* count, int nkinds = 4);   // [nkinds <= 6] each; drains pending events
+    void read_profile(double* ms_sum, long long* count, int nkinds = 4);   // [nkinds <= 8] each; drains pending events
     void problem_info(int64_t* out) const;
+    void problem_info_ext(int n, int64_t* out) const;
 
   private:
     struct Band {
@@ -245,9 +246,11 @@ class CrSystem {
     bool pipeline_ = false;
     std::vector<Span> spans_;
     std::vector<int> open_;
-    static constexpr int kProfKinds = 6;   // 0..3 as cmdr_profile_read; 4 matrix-unit adjoint launch, 5 VALU adjoint launches
-    double prof_ms_[kProfKinds] = {0, 0, 0, 0, 0, 0};
-    long long prof_n_[kProfKinds] = {0, 0, 0, 0, 0, 0};
+    // 0..3 as cmdr_profile_read; 4 matrix-unit adjoint launch, 5 VALU adjoint launches; 6 / 7 the spin-2 synthesis / adjoint
+    // launches of a polarised plan (inside kinds 0 / 2)
+    static constexpr int kProfKinds = 8;
+    double prof_ms_[kProfKinds] = {0, 0, 0, 0, 0, 0, 0, 0};
+    long long prof_n_[kProfKinds] = {0, 0, 0, 0, 0, 0, 0, 0};
     void reduce(double* v, int64_t n);         // over all ranks
     void reduce_rings(double* v, int64_t n);   // over the ranks holding the same bands (== reduce without band sharding)
 

@@ -1135,6 +1135,165 @@ __global__ void __launch_bounds__(256) k_leg2_adj_np2(Leg2Args A, const WaveTask
     }
 }
 
+// ---- spin-2 adjoint on the matrix unit (round 3) -----------------------------------------------------------------
+// (E', B') += sum_pairs [ mu+_l (Bw + Bx) + mu-_l (Bw - Bx) ] in the mu+- basis (no W = mu+ + mu-, X = mu+ - mu- adds):
+//     l + m even : Bw = (Q+.re, Q+.im, U+.re, U+.im),  Bx = (-U-.im, U-.re, Q-.im, -Q-.re)      Q+- = Q_N +- Q_S
+//     l + m odd  : Bw = (Q-.re, Q-.im, U-.re, U-.im),  Bx = (-U+.im, U+.re, Q+.im, -Q+.re)
+// is the contraction of k_leg_adj_mx with TWO A operands (the mu+ and the mu- tile) and 4 output columns per
+// polarisation pair: with four pairs in a launch (polarised multi-band runs) the 16 MFMA columns are full, the two
+// spin-weighted recursions are shared by the four pairs and the wave-wide reduction of k_leg2_adj (wave_reduce16 per
+// 4 l: ~40 % of its instructions) is gone.  Same task shape as k_leg_adj_mx (2 waves = one (m, 128 NR pairs) task,
+// wave-private LDS tile [32 l][64 pairs], B operands in registers for the whole task); the two chains go through the
+// tile one after the other, so the LDS footprint -- which sets the occupancy -- stays that of the scalar kernel.
+//   lane i: A[row = i & 15][k = i >> 4],  B[k = i >> 4][col = i & 15],  col = 4 (pair of the launch) + component.
+template <bool INJECT, bool MINUS>
+__device__ __forceinline__ void mx2_recur(const double* __restrict__ al, const double* __restrict__ be, int l0, double x,
+                                          double& cur, double& prev, int ls, const double* __restrict__ sd,
+                                          double* __restrict__ trow) {
+#pragma unroll
+    for (int j = 0; j < kMxL; ++j) {
+        const double a1 = al[l0 + j + 1], b1 = be[l0 + j + 1];
+        if (INJECT) if (ls == l0 + j) { cur = sd[MINUS ? 2 : 0]; prev = sd[MINUS ? 3 : 1]; }
+        trow[j * kMxPitch] = cur;
+        const double t = MINUS ? a1 * x - b1 : a1 * x + b1;
+        const double n = t * cur - prev;
+        prev = cur;
+        cur = n;
+    }
+}
+
+template <int NR>
+__global__ void __launch_bounds__(128) k_leg2_adj_mx(Leg2Args A, const WaveTask* __restrict__ tasks, int ntasks,
+                                                     const double* __restrict__ ph, int64_t ph_stride, int kq0, int nb,
+                                                     double* __restrict__ part, int64_t part_pol_stride,
+                                                     int64_t part_chunk_stride) {
+    __shared__ __attribute__((aligned(16))) double tile[2][kMxL * kMxPitch];
+    const int wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    if ((int)blockIdx.x >= ntasks) return;
+    const WaveTask T = tasks[blockIdx.x];
+    if (T.chunk < 0) return;
+    const int m = __builtin_amdgcn_readfirstlane(T.m);
+    const int chunk = __builtin_amdgcn_readfirstlane(T.chunk);
+    const int lw = __builtin_amdgcn_readfirstlane(T.lw);
+    const int lmax = A.lmax;
+    int pb[NR];
+#pragma unroll
+    for (int r = 0; r < NR; ++r) {
+        const int sub = NR == 1 ? wid : (wid == 0 ? 3 * r : 1 + r);
+        pb[r] = chunk * (128 * NR) + sub * 64;
+    }
+    double x[NR], pc[NR], pp[NR], mc[NR], mp[NR];
+    const double* sd[NR];
+    int ls[NR], lwr[NR], lhi[NR];
+#pragma unroll
+    for (int r = 0; r < NR; ++r) {
+        const int p = pb[r] + lane;
+        const int64_t idx = (int64_t)m * A.npair_pad + p;
+        x[r] = A.x[p];
+        ls[r] = A.ls[idx];
+        sd[r] = A.seed + idx * 4;
+        pc[r] = pp[r] = mc[r] = mp[r] = 0.0;
+        int v = ls[r];
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) v = min(v, __shfl_xor(v, o));
+        lwr[r] = __builtin_amdgcn_readfirstlane(v);
+        v = ls[r] == 0x3fffffff ? -1 : ls[r];
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) v = max(v, __shfl_xor(v, o));
+        lhi[r] = __builtin_amdgcn_readfirstlane(v);
+    }
+    // B operands.  Lane (kq, col): polarisation pair ipp = col >> 2, component c = col & 3 (E'r, E'i, B'r, B'i).
+    //   Bw source a = (c < 2 ? Q : U) part (c & 1);  Bx source b = sB * (c < 2 ? U : Q) part 1 - (c & 1), sB = -1 for c = 0, 3
+    const int kq = lane >> 4, col = lane & 15, ipp = col >> 2, c = col & 3;
+    const bool on = ipp < nb;
+    const int par0 = (lw + m) & 1;                     // parity class (l + m) & 1 of the even rows (l - l0 even)
+    double Bpe[NR][16], Bme[NR][16], Bpo[NR][16], Bmo[NR][16];   // mu+ / mu- operands of the even / odd rows
+    {
+        const int mapA = kq0 + 2 * (on ? ipp : 0) + (c < 2 ? 0 : 1), mapB = kq0 + 2 * (on ? ipp : 0) + (c < 2 ? 1 : 0);
+        const double* __restrict__ ga = ph + (int64_t)mapA * ph_stride + (c & 1);
+        const double* __restrict__ gb = ph + (int64_t)mapB * ph_stride + (1 - (c & 1));
+        const double sB = (c == 0 || c == 3) ? -1.0 : 1.0;
+#pragma unroll
+        for (int r = 0; r < NR; ++r)
+#pragma unroll
+            for (int q = 0; q < 16; ++q) {
+                const int64_t o = d_phidx(lmax + 1, pb[r] + kq + 4 * q, m);
+                const double an = on ? ga[o] : 0.0, as = on ? ga[o + 2] : 0.0;
+                const double bn = on ? gb[o] : 0.0, bs = on ? gb[o + 2] : 0.0;
+                const double ap = an + as, am = an - as, bp = sB * (bn + bs), bm = sB * (bn - bs);
+                // class 0 (l + m even): Bw = ap, Bx = bm;  class 1: Bw = am, Bx = bp
+                const double w0 = ap, x0 = bm, w1 = am, x1 = bp;
+                const double we = par0 ? w1 : w0, xe = par0 ? x1 : x0, wo = par0 ? w0 : w1, xo = par0 ? x0 : x1;
+                Bpe[r][q] = we + xe; Bme[r][q] = we - xe;
+                Bpo[r][q] = wo + xo; Bmo[r][q] = wo - xo;
+            }
+    }
+    const int64_t mo = d_moffp(lmax, m);
+    const double* __restrict__ al = A.alpha + (mo - m);
+    const double* __restrict__ be = A.beta + (mo - m);
+    double* __restrict__ outp = part + (int64_t)(on ? ipp : 0) * part_pol_stride + chunk * part_chunk_stride + 4 * (mo - m) + c;
+    double* __restrict__ Tw = tile[wid];
+    const double* __restrict__ To = tile[1 - wid];
+    const int arow = (lane & 15) * 2 * kMxPitch + kq;
+    for (int l0 = lw; l0 <= lmax; l0 += kMxL) {
+        mx_d4 De0 = {0.0, 0.0, 0.0, 0.0}, De1 = De0, Do0 = De0, Do1 = De0;
+#pragma unroll
+        for (int r = 0; r < NR; ++r) {
+            if (l0 + kMxL <= lwr[r]) continue;            // no pair of this sub-block has started yet (wave-uniform)
+#define CMDR_MX2_Q(q, BE, BO)                                                                              \
+            {                                                                                              \
+                const double ae0 = Tw[arow + 4 * (q)], ao0 = Tw[arow + kMxPitch + 4 * (q)];                \
+                const double ae1 = Tw[arow + 4 * (q) + 4], ao1 = Tw[arow + kMxPitch + 4 * (q) + 4];        \
+                De0 = __builtin_amdgcn_mfma_f64_16x16x4f64(ae0, BE[r][(q)], De0, 0, 0, 0);                 \
+                Do0 = __builtin_amdgcn_mfma_f64_16x16x4f64(ao0, BO[r][(q)], Do0, 0, 0, 0);                 \
+                De1 = __builtin_amdgcn_mfma_f64_16x16x4f64(ae1, BE[r][(q) + 1], De1, 0, 0, 0);             \
+                Do1 = __builtin_amdgcn_mfma_f64_16x16x4f64(ao1, BO[r][(q) + 1], Do1, 0, 0, 0);             \
+            }
+#define CMDR_MX2_ALL(BE, BO) CMDR_MX2_Q(0, BE, BO) CMDR_MX2_Q(2, BE, BO) CMDR_MX2_Q(4, BE, BO) CMDR_MX2_Q(6, BE, BO) \
+                             CMDR_MX2_Q(8, BE, BO) CMDR_MX2_Q(10, BE, BO) CMDR_MX2_Q(12, BE, BO) CMDR_MX2_Q(14, BE, BO)
+#define CMDR_WAVE_SYNC()                                                                                   \
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");                                         \
+            __builtin_amdgcn_wave_barrier();                                                               \
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            const bool inj = l0 <= lhi[r];                // seeds only in the groups in which a lane of this block starts
+            // ---- mu+ through the tile
+            if (inj) mx2_recur<true, false>(al, be, l0, x[r], pc[r], pp[r], ls[r], sd[r], Tw + lane);
+            else     mx2_recur<false, false>(al, be, l0, x[r], pc[r], pp[r], ls[r], sd[r], Tw + lane);
+            CMDR_WAVE_SYNC()
+            CMDR_MX2_ALL(Bpe, Bpo)
+            CMDR_WAVE_SYNC()
+            // ---- mu- through the same tile
+            if (inj) mx2_recur<true, true>(al, be, l0, x[r], mc[r], mp[r], ls[r], sd[r], Tw + lane);
+            else     mx2_recur<false, true>(al, be, l0, x[r], mc[r], mp[r], ls[r], sd[r], Tw + lane);
+            CMDR_WAVE_SYNC()
+            CMDR_MX2_ALL(Bme, Bmo)
+            CMDR_WAVE_SYNC()
+#undef CMDR_MX2_Q
+#undef CMDR_MX2_ALL
+#undef CMDR_WAVE_SYNC
+        }
+        De0 += De1;
+        Do0 += Do1;
+        // wave 0 finishes the even rows (l - l0 even), wave 1 the odd ones: hand the other half over
+        const mx_d4 give = wid == 0 ? Do0 : De0;
+        mx_d4 keep = wid == 0 ? De0 : Do0;
+#pragma unroll
+        for (int v = 0; v < 4; ++v) Tw[v * 64 + lane] = give[v];
+        __syncthreads();
+#pragma unroll
+        for (int v = 0; v < 4; ++v) keep[v] += To[v * 64 + lane];
+        if (on) {
+#pragma unroll
+            for (int v = 0; v < 4; ++v) {
+                const int l = l0 + 2 * (kq + 4 * v) + wid;
+                if (l <= lmax) outp[4 * l] = keep[v];
+            }
+        }
+        __syncthreads();
+    }
+}
+
 // CMDR_LEG2_NP_S=1 / CMDR_LEG2_NP_A=1 switch the two-pairs-per-wave synthesis / adjoint off
 static bool leg2_pairs2(bool adjoint) {
     static int v[2] = {-1, -1};
@@ -1162,7 +1321,18 @@ void launch_leg2_adj(const Leg2Args& A, const WaveTask* tasks, int ntasks, const
                      int kq0, double* part, int64_t part_pol_stride, int64_t part_chunk_stride, int npol,
                      hipStream_t s) {
     if (ntasks == 0) return;
-    for (int ip = 0; ip < npol; ++ip) {
+    // three and more polarisation pairs: four at a time on the matrix unit (k_leg2_adj_mx; CMDR_ADJ2_MX sets the smallest
+    // batch that goes there, 0 disables); the rest -- and plans with one ring pair per lane -- through the VALU kernels
+    const int mx_min = [] { const char* e = std::getenv("CMDR_ADJ2_MX"); return e ? std::atoi(e) : 3; }();   // per call (test hook)
+    int ip0 = 0;
+    if (A.R == 2 && mx_min > 0)
+        while (npol - ip0 >= mx_min) {
+            const int nb = std::min(4, npol - ip0);
+            hipLaunchKernelGGL(k_leg2_adj_mx<1>, dim3(ntasks), dim3(128), 0, s, A, tasks, ntasks, ph, ph_stride, kq0 + 2 * ip0, nb,
+                               part + ip0 * part_pol_stride, part_pol_stride, part_chunk_stride);
+            ip0 += nb;
+        }
+    for (int ip = ip0; ip < npol; ++ip) {
         if (A.R == 2 && ip + 1 < npol && leg2_pairs2(true)) {
             hipLaunchKernelGGL(k_leg2_adj_np2<2>, dim3(ntasks / 4), dim3(256), 0, s, A, tasks, ntasks, ph, ph_stride, kq0 + 2 * ip, part + ip * part_pol_stride, part_pol_stride, part_chunk_stride);
             ++ip;

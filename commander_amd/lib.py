@@ -107,6 +107,7 @@ def _sig(L):
     L.cmdr_compute_rhs_dev.argtypes = [c_vp, c_int, pvp, pvp, c_vp, c_vp, c_vp]
     L.cmdr_compute_residual.argtypes = [c_vp, dp, pdp, pdp]
     L.cmdr_compute_residual_dev.argtypes = [c_vp, c_vp, pvp, pvp]
+    L.cmdr_problem_info_ext.argtypes = [c_vp, c_int, ctypes.POINTER(c_i64)]
     L.cmdr_apply_mono_dipole_prior.argtypes = [c_vp, c_int, dp, c_int, dp, dp, c_i64, c_int, dp]
     L.cmdr_apply_mono_dipole_prior_dev.argtypes = [c_vp, c_int, c_vp, c_int, dp, c_vp, c_int, dp]
     pint = ctypes.POINTER(c_int)

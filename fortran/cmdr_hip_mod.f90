@@ -396,6 +396,14 @@ module cmdr_hip_mod
        integer(c_int)              :: ierr
      end function cmdr_apply_mono_dipole_prior_dev
 
+     function cmdr_problem_info_ext(ctx, n, out) bind(c, name='cmdr_problem_info_ext') result(ierr)
+       import :: c_int, c_ptr, c_int64_t
+       type(c_ptr),        value       :: ctx
+       integer(c_int),     value       :: n
+       integer(c_int64_t), intent(out) :: out(*)
+       integer(c_int)                  :: ierr
+     end function cmdr_problem_info_ext
+
      function cmdr_matmulA(ctx, x, y) bind(c, name='cmdr_matmulA') result(ierr)
        import :: c_int, c_ptr, c_double
        type(c_ptr),    value       :: ctx

@@ -311,12 +311,16 @@ int cmdr_cl_apply_apod(int lmax, int nmaps, int l_apod, int lmax_prior, double* 
  * launches, 1 fused ring-stage launches, 2 Legendre adjoint launches, 3 whole cr_matmulA.  ms_sum[4], count[4]. */
 int cmdr_profile_enable(cmdr_ctx* ctx, int on);
 int cmdr_profile_read(cmdr_ctx* ctx, double* ms_sum, long long* count);
-/* the same with nkinds <= 6 entries: kind 4 = launches of the matrix-unit Legendre adjoint kernel (k_leg_adj_mx, up to 8
- * maps per launch: the dominant kernel), kind 5 = the VALU adjoint launches of the maps it leaves over; 4 + 5 = kind 2 */
+/* the same with nkinds <= 8 entries: kind 4 = launches of the matrix-unit Legendre adjoint kernel (k_leg_adj_mx, up to 8
+ * maps per launch: the dominant kernel), kind 5 = the VALU adjoint launches of the maps it leaves over; 4 + 5 = the
+ * scalar part of kind 2; kinds 6 / 7 = the spin-2 (Q,U) synthesis / adjoint launches of a polarised plan (parts of 0 / 2) */
 int cmdr_profile_read_ext(cmdr_ctx* ctx, int nkinds, double* ms_sum, long long* count);
 /* out[0] = number of (band, Stokes) maps, out[1] = wave tasks of the first plan, out[2] = total (ring pair, l, m)
  * recursion steps one Legendre launch of the first plan performs for ONE map (algorithmic work, mlim-pruned) */
 int cmdr_problem_info(cmdr_ctx* ctx, int64_t* out);
+/* n <= 8 entries: [0..2] as above, [3] = the same step count for ONE (Q,U) pair of the first plan's spin-2 launches (0:
+ * unpolarised), [4] / [5] = scalar maps / polarisation pairs of the first plan, [6] = its local ring pairs, [7] = plans */
+int cmdr_problem_info_ext(cmdr_ctx* ctx, int n, int64_t* out);
 
 /* Chain-file order of component amplitudes (the "alm" dataset written by comm_map%writeFITS into the HDF chain file,
  * comm_map_mod.f90:712-740: single precision, index l^2 + l + m with m = -l..l, nmaps columns) <-> Commander's packed

@@ -152,6 +152,30 @@ def test_polarised_cr_path_gpu():
     assert n == no == 20 and rel(xs, xo) < 1e-8
 
 
+@pytest.mark.parametrize("nband", [9, 3, 6])
+def test_spin2_adjoint_kernel_forms_gpu(nband, monkeypatch):
+    """Polarised bands: three and more (Q,U) pairs per plan take the matrix-unit spin-2 adjoint (k_leg2_adj_mx, four
+    pairs per launch: 9 = 4 + 4 + 1, 3 = one launch with an empty column group, 6 = 4 + 2), the rest and
+    CMDR_ADJ2_MX=0 the VALU kernels.  Both forms against the oracle, aniso noise (every (m, m') block of Yt N^-1 Y is
+    populated), and against each other."""
+    from commander_amd import synth
+    from commander_amd.cr import build_context
+    cfg = dict(synth.CONFIGS["cfg3"])
+    cfg["nu"], cfg["fwhm"] = cfg["nu"][:nband], cfg["fwhm"][:nband]
+    spec = synth.make_problem(cfg, nside=128, lmax=200, pol=True, aniso=0.3)
+    S = oracle_system(spec)
+    ctx = build_context(spec)
+    x = np.random.default_rng(100 + nband).standard_normal(ctx.ncr)
+    want = S.matmulA(x)
+    got_mx = ctx.cr_matmulA(x)
+    monkeypatch.setenv("CMDR_ADJ2_MX", "0")
+    got_valu = ctx.cr_matmulA(x)
+    assert rel(got_mx, want) < 1e-11 and rel(got_valu, want) < 1e-11
+    assert rel(got_mx, got_valu) < 1e-12 and not np.array_equal(got_mx, got_valu)     # different kernels did run
+    monkeypatch.delenv("CMDR_ADJ2_MX")
+    assert np.array_equal(ctx.cr_matmulA(x), got_mx)                                   # deterministic
+
+
 def test_varying_mixing_and_pseudoinv_gpu():
     """BASELINE.json configs[4] shape at reduced size (Nside=32, lmax=64): five diffuse components, synchrotron and
     dust with spatially varying spectral indices (Y . F . YtW branch of evalDiffuseBand / projectDiffuseBand,

@@ -3,7 +3,11 @@
 * configs[2] (the headline workload: 9 Planck-like bands, CMB T, Nside 1024, lmax 2000): cr_matmulA, cr_computeRHS
   ('sample') and cr_invM, each <= 1e-11 (comm_cr_mod.f90:771-1024, 542-769, 1026-1077).  This is where the multi-map
   batching of the Legendre kernels (5+4 / 3+3+3 maps per recursion), the XCD-ordered ring launches and k_band_post at
-  nine bands meet the oracle.
+  nine bands meet the oracle.  The fixture carries azimuth-dependent noise and mask (aniso = 0.3: every (m, m') block of
+  Yt N^-1 Y is populated, every ring's Toeplitz spectrum is non-trivial); the benchmark noise (rms = f(z)) meets the
+  oracle in one extra matvec.
+* configs[4] (five diffuse components, synchrotron and dust with varying mixing) on five of the nine bands at full size:
+  the 5-map DPP adjoint and the shared-transform sandwich at Nside 1024 / lmax 2000.
 * nine POLARISED bands at Nside 512 / lmax 1000 with azimuth-dependent noise: the two-pairs-per-wave spin-2 kernels
   (k_leg2_*_np2), k_band_post2 and the merged (m, ring) cut of polarised plans.
 * configs[3] (T/E/B, Nside 2048, lmax 4000, one band): one matvec, the second call of the context.
@@ -21,7 +25,7 @@ pytestmark = pytest.mark.gpu
 def cfg3():
     from commander_amd import synth
     from commander_amd.cr import build_context
-    spec = synth.make_problem("cfg3")
+    spec = synth.make_problem("cfg3", aniso=0.3)
     ctx = build_context(spec)
     S = oracle_system(spec)
     return spec, ctx, S
@@ -56,6 +60,40 @@ def test_cfg3_invM_full_size_vs_oracle(cfg3):
     assert rel(ctx.cr_invM(x), S.invM(x)) < 1e-11
     for b in (0, 8):
         assert rel(ctx.invN_diag(b)[:, 0], S.bands[b].invN_diag[:, 0]) < 1e-11
+
+
+def test_cfg3_benchmark_noise_matmulA_full_size_vs_oracle():
+    """The exact workload bench.py times (rms and mask functions of cos theta only): one matvec against the oracle."""
+    from commander_amd import synth
+    from commander_amd.cr import build_context
+    spec = synth.make_problem("cfg3")
+    ctx = build_context(spec)
+    S = oracle_system(spec)
+    x = np.random.default_rng(1025).standard_normal(ctx.ncr)
+    assert rel(ctx.cr_matmulA(x), S.matmulA(x)) < 1e-11
+    ctx.close()
+
+
+def test_cfg5_matmulA_full_size_vs_oracle():
+    """BASELINE.json configs[4] at Nside 1024 / lmax 2000 on bands 30, 70, 143, 353, 857 GHz with all five components
+    (synchrotron and dust with spatially varying spectral indices): the mixing operators' shared-transform sandwich
+    (CMDR_MIX_SHARE), the 5-map k_leg_adj_dx launch and the components' different lmax at full size."""
+    from commander_amd import synth
+    from commander_amd.cr import build_context
+    spec = synth.make_problem("cfg5", bands=[0, 2, 4, 6, 8], aniso=0.3)
+    ctx = build_context(spec)
+    S = oracle_system(spec)
+    rng = np.random.default_rng(5000)
+    x0, x = rng.standard_normal(ctx.ncr), rng.standard_normal(ctx.ncr)
+    ctx.cr_matmulA(x0)
+    y = ctx.cr_matmulA(x)
+    yo = S.matmulA(x)
+    assert rel(y, yo) < 1e-11
+    for k in range(len(S.comps)):            # every component block, not only the norm-dominating one
+        pos, n, _ = S.ind_comp[k]
+        assert rel(y[pos:pos + n], yo[pos:pos + n]) < 1e-10, k
+    assert np.array_equal(ctx.cr_matmulA(x), y)
+    ctx.close()
 
 
 def test_polarised_pruned_plan_repeats_and_matches_oracle():

@@ -87,7 +87,7 @@ def _local_alm_index(lmax, ms):
     return np.array(idx)
 
 
-def _sharp_rank(rank, world, port, out_dir, nside, lmax):
+def _sharp_rank(rank, world, port, out_dir, nside, lmax, gpu=False):
     import os
     import sys
     from helpers import ROOT
@@ -97,7 +97,11 @@ def _sharp_rank(rank, world, port, out_dir, nside, lmax):
     import torch.distributed as dist
     from oracle import healpix
     dist.init_process_group("gloo", rank=rank, world_size=world)
-    L = emul_lib()
+    if gpu:     # the PRODUCT library: both ranks on device 0, the a_lm sum over the "communicator" through gloo on host buffers
+        from commander_amd import get_lib
+        L = get_lib()
+    else:
+        L = emul_lib()
     vp = ctypes.c_void_p
     L.sharp_alm_count.restype = ctypes.c_ssize_t
     L.sharp_alm_count.argtypes = [vp]
@@ -152,20 +156,30 @@ def _sharp_rank(rank, world, port, out_dir, nside, lmax):
     dist.destroy_process_group()
 
 
+@pytest.mark.gpu
+def test_sharp_two_ranks_rings_and_m_distributed_gpu(tmp_path, oracle_lib):
+    """The same with the product library on the GPU: two fresh processes on device 0."""
+    _two_rank_sharp(tmp_path, oracle_lib, 32, 64, True)
+
+
 def test_sharp_two_ranks_rings_and_m_distributed(tmp_path, oracle_lib):
     """VERDICT r1 item 6 / SURVEY 8(a14): the nine symbols driven as sharp.f90:186-241 does with P = 2 -- each rank owns
     every second ring pair and every second m -- give each rank its slice of the one-rank result."""
+    _two_rank_sharp(tmp_path, oracle_lib, 8, 16, False)
+
+
+def _two_rank_sharp(tmp_path, oracle_lib, nside, lmax, gpu):
     import os
     import socket
     import torch.multiprocessing as mp
     from oracle import sht as osht
-    nside, lmax = 8, 16
-    emul_lib()
+    if not gpu:
+        emul_lib()
     s = socket.socket()
     s.bind(("127.0.0.1", 0))
     port = s.getsockname()[1]
     s.close()
-    mp.spawn(_sharp_rank, args=(2, port, str(tmp_path), nside, lmax), nprocs=2, join=True)
+    mp.spawn(_sharp_rank, args=(2, port, str(tmp_path), nside, lmax, gpu), nprocs=2, join=True)
     g = np.random.default_rng(11)
     na, npx = (lmax + 1) ** 2, 12 * nside * nside
     a_full, e_full, b_full = g.standard_normal(na), g.standard_normal(na), g.standard_normal(na)
