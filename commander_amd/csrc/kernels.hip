@@ -1294,6 +1294,153 @@ __global__ void __launch_bounds__(128) k_leg2_adj_mx(Leg2Args A, const WaveTask*
     }
 }
 
+// ---- spin-2 adjoint of one or two (Q,U) pairs without the matrix unit: the task, recursions and LDS transposition of
+// k_leg2_adj_mx, the accumulation of k_leg_adj_dx: lane = (l row, pair kq of quad q); per pair of the launch and 64-pair
+// block the 16 B values (mu+ / mu- operand x even / odd rows x 4 components) of ring pair 4 row + kq sit in registers and
+// step q takes lane q of every 16-lane row inside the FMA (v_fmac_f64_dpp row_newbcast:q).  8 + 16 NP flop per (ring
+// pair, l) -- the VALU kernels' count without W / X and without the wave-wide reduction (wave_reduce16 per 4 l).
+template <int NR, int NP>
+__global__ void __launch_bounds__(128) k_leg2_adj_dx(Leg2Args A, const WaveTask* __restrict__ tasks, int ntasks,
+                                                     const double* __restrict__ ph, int64_t ph_stride, int kq0,
+                                                     double* __restrict__ part, int64_t part_pol_stride,
+                                                     int64_t part_chunk_stride) {
+    __shared__ __attribute__((aligned(16))) double tile[2][kMxL * kMxPitch];
+    const int wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    if ((int)blockIdx.x >= ntasks) return;
+    const WaveTask T = tasks[blockIdx.x];
+    if (T.chunk < 0) return;
+    const int m = __builtin_amdgcn_readfirstlane(T.m);
+    const int chunk = __builtin_amdgcn_readfirstlane(T.chunk);
+    const int lw = __builtin_amdgcn_readfirstlane(T.lw);
+    const int lmax = A.lmax;
+    const int kq = lane >> 4, row = lane & 15;
+    int pb[NR];
+#pragma unroll
+    for (int r = 0; r < NR; ++r) {
+        const int sub = NR == 1 ? wid : (wid == 0 ? 3 * r : 1 + r);
+        pb[r] = chunk * (128 * NR) + sub * 64;
+    }
+    double x[NR], pc[NR], pp[NR], mc[NR], mp[NR];
+    const double* sd[NR];
+    int ls[NR], lwr[NR], lhi[NR];
+    const int par0 = (lw + m) & 1;
+    // B[r][p][s][e/o][c]: s = 0 the mu+ operand (Bw + Bx), 1 the mu- operand (Bw - Bx); see k_leg2_adj_mx
+    double B[NR][NP][2][2][4];
+#pragma unroll
+    for (int r = 0; r < NR; ++r) {
+        const int p = pb[r] + lane;
+        const int64_t idx = (int64_t)m * A.npair_pad + p;
+        x[r] = A.x[p];
+        ls[r] = A.ls[idx];
+        sd[r] = A.seed + idx * 4;
+        pc[r] = pp[r] = mc[r] = mp[r] = 0.0;
+        int v = ls[r];
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) v = min(v, __shfl_xor(v, o));
+        lwr[r] = __builtin_amdgcn_readfirstlane(v);
+        v = ls[r] == 0x3fffffff ? -1 : ls[r];
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) v = max(v, __shfl_xor(v, o));
+        lhi[r] = __builtin_amdgcn_readfirstlane(v);
+        const int64_t o = d_phidx(lmax + 1, pb[r] + 4 * row + kq, m);
+#pragma unroll
+        for (int ip = 0; ip < NP; ++ip) {
+            const double* q = ph + (int64_t)(kq0 + 2 * ip) * ph_stride + o;
+            const double* u = q + ph_stride;
+            const double qpr = q[0] + q[2], qpi = q[1] + q[3], qmr = q[0] - q[2], qmi = q[1] - q[3];
+            const double upr = u[0] + u[2], upi = u[1] + u[3], umr = u[0] - u[2], umi = u[1] - u[3];
+            // class 0 (l + m even): Bw = (Q+r, Q+i, U+r, U+i), Bx = (-U-i, U-r, Q-i, -Q-r); class 1: + and - exchanged
+            const double w0[4] = {qpr, qpi, upr, upi}, x0[4] = {-umi, umr, qmi, -qmr};
+            const double w1[4] = {qmr, qmi, umr, umi}, x1[4] = {-upi, upr, qpi, -qpr};
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                const double we = par0 ? w1[c] : w0[c], xe = par0 ? x1[c] : x0[c];
+                const double wo = par0 ? w0[c] : w1[c], xo = par0 ? x0[c] : x1[c];
+                B[r][ip][0][0][c] = we + xe; B[r][ip][1][0][c] = we - xe;
+                B[r][ip][0][1][c] = wo + xo; B[r][ip][1][1][c] = wo - xo;
+            }
+        }
+    }
+    const int64_t mo = d_moffp(lmax, m);
+    const double* __restrict__ al = A.alpha + (mo - m);
+    const double* __restrict__ be = A.beta + (mo - m);
+    // after the fold the 16-lane row kq of a lane holds component {0, 2, 1, 3}[kq] (swap_halves / swap_rows below)
+    const int cidx = ((kq & 1) << 1) | (kq >> 1);
+    double* __restrict__ outp = part + chunk * part_chunk_stride + 4 * (mo - m) + cidx;
+    double* __restrict__ Tw = tile[wid];
+    const double* __restrict__ To = tile[1 - wid];
+    const int arow = row * 2 * kMxPitch + kq;
+    for (int l0 = lw; l0 <= lmax; l0 += kMxL) {
+        double ae_[NP][4], ao_[NP][4];
+#pragma unroll
+        for (int ip = 0; ip < NP; ++ip)
+#pragma unroll
+            for (int c = 0; c < 4; ++c) ae_[ip][c] = ao_[ip][c] = 0.0;
+#pragma unroll
+        for (int r = 0; r < NR; ++r) {
+            if (l0 + kMxL <= lwr[r]) continue;
+            const bool inj = l0 <= lhi[r];
+#define CMDR_DX2_Q(q, S)                                                                                   \
+            {                                                                                              \
+                const double ae = Tw[arow + 4 * (q)], ao = Tw[arow + kMxPitch + 4 * (q)];                  \
+                _Pragma("unroll") for (int ip = 0; ip < NP; ++ip)                                          \
+                _Pragma("unroll") for (int c = 0; c < 4; ++c) {                                            \
+                    fmac_row_bcast<(q)>(ae_[ip][c], B[r][ip][S][0][c], ae);                                \
+                    fmac_row_bcast<(q)>(ao_[ip][c], B[r][ip][S][1][c], ao);                                \
+                }                                                                                          \
+            }
+#define CMDR_DX2_ALL(S) CMDR_DX2_Q(0, S) CMDR_DX2_Q(1, S) CMDR_DX2_Q(2, S) CMDR_DX2_Q(3, S) CMDR_DX2_Q(4, S) CMDR_DX2_Q(5, S) \
+                        CMDR_DX2_Q(6, S) CMDR_DX2_Q(7, S) CMDR_DX2_Q(8, S) CMDR_DX2_Q(9, S) CMDR_DX2_Q(10, S) CMDR_DX2_Q(11, S) \
+                        CMDR_DX2_Q(12, S) CMDR_DX2_Q(13, S) CMDR_DX2_Q(14, S) CMDR_DX2_Q(15, S)
+#define CMDR_WAVE_SYNC()                                                                                   \
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");                                         \
+            __builtin_amdgcn_wave_barrier();                                                               \
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            if (inj) mx2_recur<true, false>(al, be, l0, x[r], pc[r], pp[r], ls[r], sd[r], Tw + lane);
+            else     mx2_recur<false, false>(al, be, l0, x[r], pc[r], pp[r], ls[r], sd[r], Tw + lane);
+            CMDR_WAVE_SYNC()
+            CMDR_DX2_ALL(0)
+            CMDR_WAVE_SYNC()
+            if (inj) mx2_recur<true, true>(al, be, l0, x[r], mc[r], mp[r], ls[r], sd[r], Tw + lane);
+            else     mx2_recur<false, true>(al, be, l0, x[r], mc[r], mp[r], ls[r], sd[r], Tw + lane);
+            CMDR_WAVE_SYNC()
+            CMDR_DX2_ALL(1)
+            CMDR_WAVE_SYNC()
+#undef CMDR_DX2_Q
+#undef CMDR_DX2_ALL
+#undef CMDR_WAVE_SYNC
+        }
+        // fold the four pair lanes (kq) of every row: te / to hold, in 16-lane row kq, component {0, 2, 1, 3}[kq] of the
+        // even / odd l rows; this wave keeps the parity it writes and hands the other one over
+        double keep[NP];
+#pragma unroll
+        for (int ip = 0; ip < NP; ++ip) {
+            double a0 = ae_[ip][0], a1 = ae_[ip][1], a2 = ae_[ip][2], a3 = ae_[ip][3];
+            swap_halves(a0, a1);
+            swap_halves(a2, a3);
+            double s01 = a0 + a1, s23 = a2 + a3;
+            swap_rows(s01, s23);
+            const double te = s01 + s23;
+            a0 = ao_[ip][0]; a1 = ao_[ip][1]; a2 = ao_[ip][2]; a3 = ao_[ip][3];
+            swap_halves(a0, a1);
+            swap_halves(a2, a3);
+            s01 = a0 + a1; s23 = a2 + a3;
+            swap_rows(s01, s23);
+            const double to = s01 + s23;
+            keep[ip] = wid == 0 ? te : to;
+            Tw[ip * 64 + lane] = wid == 0 ? to : te;
+        }
+        __syncthreads();
+        const int l = l0 + 2 * row + wid;
+        if (l <= lmax) {
+#pragma unroll
+            for (int ip = 0; ip < NP; ++ip) outp[(int64_t)ip * part_pol_stride + 4 * l] = keep[ip] + To[ip * 64 + lane];
+        }
+        __syncthreads();
+    }
+}
+
 // CMDR_LEG2_NP_S=1 / CMDR_LEG2_NP_A=1 switch the two-pairs-per-wave synthesis / adjoint off
 static bool leg2_pairs2(bool adjoint) {
     static int v[2] = {-1, -1};
@@ -1313,6 +1460,7 @@ void launch_leg2_synth(const Leg2Args& A, const WaveTask* tasks, int ntasks, con
             ++ip;
             continue;
         }
+        if (A.R == 4) { hipLaunchKernelGGL(k_leg2_synth<4>, dim3(ntasks / 4), dim3(256), 0, s, A, tasks, ntasks, st, npol, ip, ph, ph_stride, kq0 + 2 * ip); continue; }
         if (A.R == 1) hipLaunchKernelGGL(k_leg2_synth<1>, dim3(ntasks / 4), dim3(256), 0, s, A, tasks, ntasks, st, npol, ip, ph, ph_stride, kq0 + 2 * ip);
         else hipLaunchKernelGGL(k_leg2_synth<2>, dim3(ntasks / 4), dim3(256), 0, s, A, tasks, ntasks, st, npol, ip, ph, ph_stride, kq0 + 2 * ip);
     }
@@ -1332,12 +1480,27 @@ void launch_leg2_adj(const Leg2Args& A, const WaveTask* tasks, int ntasks, const
                                part + ip0 * part_pol_stride, part_pol_stride, part_chunk_stride);
             ip0 += nb;
         }
+    // one or two pairs left: the DPP form of the same task is available (CMDR_ADJ2_DX=1) but OFF by default: measured at
+    // Nside 2048 / lmax 4000, one pair, 23.0 ms against 19.7 ms for k_leg2_adj -- two tile round trips per 32 l (mu+ and
+    // mu-: the LDS store path, ~85 B/clk/CU, carries 16 B per (ring pair, l)) at two waves per SIMD cost more than the
+    // wave-wide reductions they replace
+    const bool dx_on = [] { const char* e = std::getenv("CMDR_ADJ2_DX"); return e && std::atoi(e) != 0; }();
+    if (dx_on && A.R == 2 && npol - ip0 >= 1 && npol - ip0 <= 2) {
+        if (npol - ip0 == 2)
+            hipLaunchKernelGGL((k_leg2_adj_dx<1, 2>), dim3(ntasks), dim3(128), 0, s, A, tasks, ntasks, ph, ph_stride, kq0 + 2 * ip0,
+                               part + ip0 * part_pol_stride, part_pol_stride, part_chunk_stride);
+        else
+            hipLaunchKernelGGL((k_leg2_adj_dx<1, 1>), dim3(ntasks), dim3(128), 0, s, A, tasks, ntasks, ph, ph_stride, kq0 + 2 * ip0,
+                               part + ip0 * part_pol_stride, part_pol_stride, part_chunk_stride);
+        return;
+    }
     for (int ip = ip0; ip < npol; ++ip) {
         if (A.R == 2 && ip + 1 < npol && leg2_pairs2(true)) {
             hipLaunchKernelGGL(k_leg2_adj_np2<2>, dim3(ntasks / 4), dim3(256), 0, s, A, tasks, ntasks, ph, ph_stride, kq0 + 2 * ip, part + ip * part_pol_stride, part_pol_stride, part_chunk_stride);
             ++ip;
             continue;
         }
+        if (A.R == 4) { hipLaunchKernelGGL(k_leg2_adj<4>, dim3(ntasks / 4), dim3(256), 0, s, A, tasks, ntasks, ph, ph_stride, kq0 + 2 * ip, part + ip * part_pol_stride, part_chunk_stride); continue; }
         if (A.R == 1) hipLaunchKernelGGL(k_leg2_adj<1>, dim3(ntasks / 4), dim3(256), 0, s, A, tasks, ntasks, ph, ph_stride, kq0 + 2 * ip, part + ip * part_pol_stride, part_chunk_stride);
         else hipLaunchKernelGGL(k_leg2_adj<2>, dim3(ntasks / 4), dim3(256), 0, s, A, tasks, ntasks, ph, ph_stride, kq0 + 2 * ip, part + ip * part_pol_stride, part_chunk_stride);
     }

@@ -260,6 +260,10 @@ void Legendre2Tables::build(int lmax_, const std::vector<double>& x, const std::
     cnorm.assign(ntrip(lmax), 0.0);
     ls.assign((size_t)nm * npair_pad, kLsNever);
     seed.assign((size_t)nm * npair_pad * 4, 0.0);
+    // CMDR_START_EXP2 overrides the spin-2 start threshold alone (tests: -280 = the round-2 tables)
+    const int start_exp = [] { const char* e = std::getenv("CMDR_START_EXP2"); return e ? std::atoi(e) : kStartExp; }();
+    const bool want_uniform = [] { const char* e = std::getenv("CMDR_UNIFORM_START"); return !e || std::atoi(e) != 0; }();
+    std::atomic<bool> uniform_fail{false};
     host_parallel_for(nm, [&](int mi) {
         const int m = (mi & 1) ? lmax - mi / 2 : mi / 2;
         const int l0 = std::max(m, 2);
@@ -284,14 +288,15 @@ void Legendre2Tables::build(int lmax_, const std::vector<double>& x, const std::
             be[l + 1] = 2.0 * a * (double)m / ((double)l * (l + 1.0));
         }
         for (int l = l0; l <= lmax; ++l) cn[l] = c[l];
-        // seeds: both chains from their closed-form start, scaled recursion until either exceeds the threshold
+        // seeds: both chains from their closed-form start, scaled recursion until either exceeds the start threshold
+        // (2^kStartExp, as for the scalar tables: round 2 waited only for representability, 2^-280, and ran ~5 % more steps)
         int* lsm = ls.data() + (size_t)m * npair_pad;
         double* sd = seed.data() + (size_t)m * npair_pad * 4;
-        for (int p = 0; p < npair; ++p) {
-            if (m > mlim[p]) continue;
+        struct Chains { double lc[2], lp[2]; long e; };
+        auto init = [&](int p, Chains& S) {            // closed-form (+-2)lambda at l0, both chains on one exponent
             const double th = std::atan2(sth[p], x[p]), c2 = std::cos(0.5 * th), s2 = std::sin(0.5 * th);
-            double lc[2], lp[2] = {0.0, 0.0};
             long e[2];
+            S.lp[0] = S.lp[1] = 0.0;
             for (int ch = 0; ch < 2; ++ch) {
                 const int s = ch == 0 ? 2 : -2;
                 double l2, sign;
@@ -318,57 +323,89 @@ void Legendre2Tables::build(int lmax_, const std::vector<double>& x, const std::
                     l2 = v == 0.0 ? -1e30 : std::log2(std::fabs(v));
                     sign = v < 0 ? -1.0 : 1.0;
                 }
-                if (l2 < -1e20) { lc[ch] = 0.0; e[ch] = 0; }
+                if (l2 < -1e20) { S.lc[ch] = 0.0; e[ch] = 0; }
                 else {
                     const double fl = std::floor(l2);
                     e[ch] = (long)fl;
-                    lc[ch] = sign * std::exp2(l2 - fl);
+                    S.lc[ch] = sign * std::exp2(l2 - fl);
                 }
             }
             // bring both chains to the common (larger) exponent
-            auto align = [&]() {
-                const long E = std::max(e[0], e[1]);
-                for (int ch = 0; ch < 2; ++ch) {
-                    const long d = E - e[ch];
-                    if (d > 0) {
-                        const double f = d > 2000 ? 0.0 : std::ldexp(1.0, (int)-d);
-                        lc[ch] *= f;
-                        lp[ch] *= f;
-                        e[ch] = E;
-                    }
-                }
-            };
-            align();
+            const long E = std::max(e[0], e[1]);
+            for (int ch = 0; ch < 2; ++ch) {
+                const long d = E - e[ch];
+                if (d > 0) S.lc[ch] *= d > 2000 ? 0.0 : std::ldexp(1.0, (int)-d);
+            }
+            S.e = E;
+        };
+        auto step = [&](int p, int l, Chains& S) {     // l -> l + 1
+            for (int ch = 0; ch < 2; ++ch) {
+                const double t = al[l + 1] * x[p] + (ch == 0 ? be[l + 1] : -be[l + 1]);
+                const double ln = t * S.lc[ch] - S.lp[ch];
+                S.lp[ch] = S.lc[ch];
+                S.lc[ch] = ln;
+            }
+            if (std::max(std::fabs(S.lc[0]), std::fabs(S.lc[1])) > 0x1p+300) {
+                for (int ch = 0; ch < 2; ++ch) { S.lc[ch] *= 0x1p-300; S.lp[ch] *= 0x1p-300; }
+                S.e += 300;
+            }
+        };
+        auto store = [&](int p, int l, const Chains& S) {
+            lsm[p] = l;
+            sd[4 * p + 0] = std::ldexp(S.lc[0], (int)S.e);
+            sd[4 * p + 1] = std::ldexp(S.lp[0], (int)S.e);
+            sd[4 * p + 2] = std::ldexp(S.lc[1], (int)S.e);
+            sd[4 * p + 3] = std::ldexp(S.lp[1], (int)S.e);
+        };
+        for (int p = 0; p < npair; ++p) {
+            if (m > mlim[p]) continue;
+            Chains S;
+            init(p, S);
             int l = l0;
             for (;;) {
                 int ex;
-                (void)std::frexp(std::max(std::max(std::fabs(lc[0]), std::fabs(lp[0])),
-                                          std::max(std::fabs(lc[1]), std::fabs(lp[1]))), &ex);
-                if (e[0] + ex >= -280) {
-                    lsm[p] = l;
-                    sd[4 * p + 0] = std::ldexp(lc[0], (int)e[0]);
-                    sd[4 * p + 1] = std::ldexp(lp[0], (int)e[0]);
-                    sd[4 * p + 2] = std::ldexp(lc[1], (int)e[0]);
-                    sd[4 * p + 3] = std::ldexp(lp[1], (int)e[0]);
-                    break;
-                }
+                (void)std::frexp(std::max(std::max(std::fabs(S.lc[0]), std::fabs(S.lp[0])),
+                                          std::max(std::fabs(S.lc[1]), std::fabs(S.lp[1]))), &ex);
+                if (S.e + ex >= start_exp) { store(p, l, S); break; }
                 if (l == lmax) break;
-                for (int ch = 0; ch < 2; ++ch) {
-                    const double t = al[l + 1] * x[p] + (ch == 0 ? be[l + 1] : -be[l + 1]);
-                    const double ln = t * lc[ch] - lp[ch];
-                    lp[ch] = lc[ch];
-                    lc[ch] = ln;
-                }
+                step(p, l, S);
                 ++l;
-                if (std::max(std::fabs(lc[0]), std::fabs(lc[1])) > 0x1p+300) {
-                    for (int ch = 0; ch < 2; ++ch) { lc[ch] *= 0x1p-300; lp[ch] *= 0x1p-300; e[ch] += 300; }
+            }
+        }
+        // Uniform starts (as LegendreTables::build): the 64 ring pairs of a lane block switch on at one l == l0 (mod 32),
+        // the last such l at or below the block's earliest start, with their true, still tiny mu+- there as seeds; the
+        // matrix-unit adjoint then injects seeds in one 32-l group per block.  A lane whose seeds would underflow keeps
+        // its own start (the kernels handle per-lane starts in every group up to the block's last one).
+        if (want_uniform) {
+            for (int b0 = 0; b0 < npair; b0 += kWave) {
+                const int b1 = std::min(b0 + kWave, npair);
+                int lo = kLsNever;
+                for (int p = b0; p < b1; ++p) lo = std::min(lo, lsm[p]);
+                if (lo == kLsNever) continue;
+                const int s0 = l0 + ((lo - l0) / 32) * 32;
+                for (int p = b0; p < b1; ++p) {
+                    if (lsm[p] == kLsNever || lsm[p] == s0) continue;
+                    Chains S;
+                    init(p, S);
+                    for (int l = l0; l < s0; ++l) step(p, l, S);
+                    bool ok = true;
+                    for (int ch = 0; ch < 2; ++ch) {
+                        int exc, exp_;
+                        (void)std::frexp(S.lc[ch], &exc);
+                        (void)std::frexp(S.lp[ch], &exp_);
+                        if (S.lc[ch] == 0.0 || S.e + exc < -960 || (S.lp[ch] != 0.0 && S.e + exp_ < -960)) ok = false;
+                    }
+                    if (!ok) { uniform_fail.store(true, std::memory_order_relaxed); continue; }
+                    store(p, s0, S);
                 }
             }
         }
     }, nthreads);
+    uniform_start = want_uniform && !uniform_fail.load();
     tasks.clear();
     for (int m = 0; m < nm; ++m) {
         const int l0 = std::max(m, 2);
+        if (l0 > lmax) continue;
         const int* lsm = ls.data() + (size_t)m * npair_pad;
         for (int ch = 0; ch < nchunk; ++ch) {
             int lo = kLsNever, hi = -1;
@@ -378,10 +415,19 @@ void Legendre2Tables::build(int lmax_, const std::vector<double>& x, const std::
                 lo = std::min(lo, v);
                 hi = std::max(hi, v);
             }
-            if (hi < 0) continue;
             WaveTask t;
             t.m = m;
             t.chunk = ch;
+            if (hi < 0) {
+                // no pair of the chunk reaches the start threshold by lmax.  Inside the (m, ring) cut the task is kept with
+                // an empty l range: the ring stage reads every entry with m <= mlim, so the synthesis must write its zeros
+                bool inside = false;
+                for (int p = ch * per; p < (ch + 1) * per; ++p) inside = inside || m <= mlim[p];
+                if (!inside) continue;
+                t.lw = t.lAend = lmax + 1 + ((lmax + 1 - l0) & 1);
+                tasks.push_back(t);
+                continue;
+            }
             t.lw = lo - ((lo - l0) & 1);           // pairs (l, l+1) start at l0-parity
             int a = hi + 1;
             a += (a - l0) & 1;
@@ -397,6 +443,7 @@ void ShtTables::build_spin2(int nthreads) {
     if (leg2.lmax == lmax) return;
     std::vector<double> x(leg.x.begin(), leg.x.begin() + leg.npair), sth(leg.sth.begin(), leg.sth.begin() + leg.npair);
     int R2 = 2;
+    if (const char* e = std::getenv("CMDR_LEG2_R")) { const int v = std::atoi(e); if (v == 1 || v == 2 || v == 4) R2 = v; }   // experiment
     while (R2 > 1 && leg.npair_pad % (kWave * R2) != 0) R2 >>= 1;
     // leg.mlim is already the merged cut on polarised plans (ShtTables::build)
     std::vector<int> ml(leg.mlim.begin(), leg.mlim.begin() + leg.npair);

@@ -152,12 +152,13 @@ def test_polarised_cr_path_gpu():
     assert n == no == 20 and rel(xs, xo) < 1e-8
 
 
-@pytest.mark.parametrize("nband", [9, 3, 6])
+@pytest.mark.parametrize("nband", [9, 3, 6, 1, 2])
 def test_spin2_adjoint_kernel_forms_gpu(nband, monkeypatch):
     """Polarised bands: three and more (Q,U) pairs per plan take the matrix-unit spin-2 adjoint (k_leg2_adj_mx, four
-    pairs per launch: 9 = 4 + 4 + 1, 3 = one launch with an empty column group, 6 = 4 + 2), the rest and
-    CMDR_ADJ2_MX=0 the VALU kernels.  Both forms against the oracle, aniso noise (every (m, m') block of Yt N^-1 Y is
-    populated), and against each other."""
+    pairs per launch: 9 = 4 + 4 + 1, 3 = one launch with an empty column group, 6 = 4 + 2), one or two (left over) pairs
+    the VALU kernels of rounds 1-2 or, with CMDR_ADJ2_DX=1, the DPP form of the matrix-unit task (k_leg2_adj_dx: correct but
+    slower for one pair, off by default); CMDR_ADJ2_MX=0 sends everything to the VALU kernels.  All forms against the
+    oracle, aniso noise (every (m, m') block of Yt N^-1 Y is populated), and against each other."""
     from commander_amd import synth
     from commander_amd.cr import build_context
     cfg = dict(synth.CONFIGS["cfg3"])
@@ -167,13 +168,19 @@ def test_spin2_adjoint_kernel_forms_gpu(nband, monkeypatch):
     ctx = build_context(spec)
     x = np.random.default_rng(100 + nband).standard_normal(ctx.ncr)
     want = S.matmulA(x)
-    got_mx = ctx.cr_matmulA(x)
+    got_def = ctx.cr_matmulA(x)
+    monkeypatch.setenv("CMDR_ADJ2_DX", "1")
+    got_mx = ctx.cr_matmulA(x)                                                         # matrix unit + DPP form
     monkeypatch.setenv("CMDR_ADJ2_MX", "0")
+    monkeypatch.setenv("CMDR_ADJ2_DX", "0")
     got_valu = ctx.cr_matmulA(x)
-    assert rel(got_mx, want) < 1e-11 and rel(got_valu, want) < 1e-11
+    assert rel(got_def, want) < 1e-11 and rel(got_mx, want) < 1e-11 and rel(got_valu, want) < 1e-11
     assert rel(got_mx, got_valu) < 1e-12 and not np.array_equal(got_mx, got_valu)     # different kernels did run
+    if nband % 4:
+        assert not np.array_equal(got_mx, got_def)                                     # the DPP form took the left-over pairs
     monkeypatch.delenv("CMDR_ADJ2_MX")
-    assert np.array_equal(ctx.cr_matmulA(x), got_mx)                                   # deterministic
+    monkeypatch.delenv("CMDR_ADJ2_DX")
+    assert np.array_equal(ctx.cr_matmulA(x), got_def)                                  # deterministic
 
 
 def test_varying_mixing_and_pseudoinv_gpu():
