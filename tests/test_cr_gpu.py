@@ -176,7 +176,7 @@ def test_spin2_adjoint_kernel_forms_gpu(nband, monkeypatch):
     got_valu = ctx.cr_matmulA(x)
     assert rel(got_def, want) < 1e-11 and rel(got_mx, want) < 1e-11 and rel(got_valu, want) < 1e-11
     assert rel(got_mx, got_valu) < 1e-12 and not np.array_equal(got_mx, got_valu)     # different kernels did run
-    if nband % 4:
+    if nband != 3:                                                                     # 3 pairs = one matrix-unit launch
         assert not np.array_equal(got_mx, got_def)                                     # the DPP form took the left-over pairs
     monkeypatch.delenv("CMDR_ADJ2_MX")
     monkeypatch.delenv("CMDR_ADJ2_DX")
