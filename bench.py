@@ -140,27 +140,20 @@ def host_cores():
 
 
 def cpu_baseline(cfg, nside, lmax):
-    """Reported, not targeted: the CPU oracle (numpy + C/OpenMP restatement under oracle/) timed on this box's host
-    cores on a bounded sample of the SAME workload: one real `cr_matmulA` of the oracle on the first bands of the
-    benchmark problem (all nine when the cores allow), scaled to nine bands and to a solve (RHS ~ half a matvec +
-    41 matvecs: r = b - A x0 is skipped for x0 = 0, 40 iterations + the M^-1 applications are negligible).  It is
-    NOT the Fortran+libsharp2 binary (unbuildable here: no HEALPix/libsharp2/FFTW/gfortran)."""
+    """Reported, not targeted: the build's own CPU oracle (oracle/: numpy + C/OpenMP restatement,
+    SIMD-blocked Legendre stage, the same algorithm class as libsharp2) timed on the host cores this job is granted.
+    It is NOT the Fortran + libsharp2 binary (unbuildable here: no HEALPix / libsharp2 / FFTW / gfortran).
+      * benchmark configuration: ONE real cr_matmulA on all nine bands (t_matvec) and t_sht_pair; `value` = 1 / (41.5
+        matvec-equivalents): RHS ~ half a matvec + 41 matvecs (r = b - A x0 is skipped for x0 = 0; M^-1 is negligible)
+      * configs[1] (3 bands, CMB + synch, Nside 256 / lmax 512): t_sht_pair, t_matvec (medians) and a REAL t_solve
+        (cr_computeRHS + preconditioner refresh + 40 fixed PCG iterations)"""
     import numpy as np
     from commander_amd import synth
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     from helpers import oracle_system
+    from oracle import sht as osht
     cores = host_cores()
     os.environ["ORACLE_THREADS"] = str(cores)
-    nb_all = len(synth.CONFIGS[cfg]["nu"])
-    nb = nb_all if cores >= 48 else min(nb_all, 3)
-    spec = synth.make_problem(cfg, nside=nside, lmax=lmax, bands=list(range(nb)))
-    S = oracle_system(spec)
-    x = np.random.default_rng(0).standard_normal(S.ncr)
-    t0 = time.time()
-    S.matmulA(x)
-    t_s = time.time() - t0
-    t_mv = t_s * nb_all / nb
-    mv_per_solve = NITER + 1 + 0.5
     cpu = "unknown"
     try:
         for line in open("/proc/cpuinfo"):
@@ -169,11 +162,59 @@ def cpu_baseline(cfg, nside, lmax):
                 break
     except OSError:
         pass
+
+    def med(f, n):
+        ts = []
+        for _ in range(n):
+            t0 = time.perf_counter()
+            f()
+            ts.append(time.perf_counter() - t0)
+        return float(np.median(ts))
+
+    def sht_pair_times(ns, lm, n):
+        rng = np.random.default_rng(1)
+        m = rng.standard_normal(12 * ns * ns)
+        q, u = rng.standard_normal(12 * ns * ns), rng.standard_normal(12 * ns * ns)
+        osht.Y(ns, lm, osht.Yt(ns, lm, m))     # plans / twiddles
+        t0 = med(lambda: osht.Y(ns, lm, osht.Yt(ns, lm, m)), n)
+        t2 = med(lambda: osht.sht_spin2(1, ns, lm, *[None] * 0, **dict(zip(("almE", "almB"), osht.sht_spin2(2, ns, lm, mapQ=q, mapU=u)))), n)
+        return t0, t2
+    # ---- configs[1]: everything measured for real
+    c2 = synth.CONFIGS["cfg2"]
+    spec2 = synth.make_problem("cfg2")
+    S2 = oracle_system(spec2)
+    S2.init_precond_diag()
+    S2.update_precond_diag()
+    x2 = np.random.default_rng(0).standard_normal(S2.ncr)
+    S2.matmulA(x2)
+    t_mv2 = med(lambda: S2.matmulA(x2), 5)
+    resid, xi, eta = synth.draw_inputs(spec2)
+    col = lambda lst: [np.asarray(v).reshape(len(v), -1) for v in lst]   # noqa: E731
+    t0 = time.perf_counter()
+    b2 = S2.computeRHS(col(resid), "sample", col(xi), eta)
+    S2.update_precond_diag()
+    S2.solve(b2, "fixed_iter", 1e-8, 5, NITER, 1)
+    t_solve2 = time.perf_counter() - t0
+    p0_2, p2_2 = sht_pair_times(c2["nside"], c2["lmax"], 5)
+    # ---- the benchmark configuration: one real matvec on all bands
+    spec = synth.make_problem(cfg, nside=nside, lmax=lmax)
+    S = oracle_system(spec)
+    x = np.random.default_rng(0).standard_normal(S.ncr)
+    t0 = time.perf_counter()
+    S.matmulA(x)
+    t_mv = time.perf_counter() - t0
+    p0, p2 = sht_pair_times(nside, lmax, 1)
+    mv_per_solve = NITER + 1 + 0.5
     return {"value": 1.0 / (mv_per_solve * t_mv), "unit": "solves/s", "cores": cores, "kind": "port", "cpu": cpu,
-            "matvec_s": t_mv,
-            "sample": "one oracle cr_matmulA (oracle/cr_oracle.py + oracle/sht_oracle.c, OpenMP x%d) on %d of the %d "
-                      "bands at Nside=%d lmax=%d: %.1f s; x %d/%d bands x %.1f matvec-equivalents per solve"
-                      % (cores, nb, nb_all, nside, lmax, t_s, nb_all, nb, mv_per_solve)}
+            "matvec_s": t_mv, "sht_pair_s": {"spin0": p0, "spin2_QU": p2},
+            "sample": "one oracle cr_matmulA (oracle/cr_oracle.py + oracle/sht_oracle.c, SIMD-blocked Legendre stage, OpenMP "
+                      "x%d) on all %d bands at Nside=%d lmax=%d: %.1f s; x %.1f matvec-equivalents per solve.  The CPU "
+                      "restatement, NOT the Fortran + libsharp2 binary"
+                      % (cores, len(spec["bands"]), nside, lmax, t_mv, mv_per_solve),
+            "configs1": {"config": "configs[1]: 3 bands, CMB+synch, Nside %d lmax %d" % (c2["nside"], c2["lmax"]),
+                         "t_sht_pair_s": {"spin0": p0_2, "spin2_QU": p2_2}, "t_matvec_s": t_mv2, "t_solve_s": t_solve2,
+                         "solves_per_sec": 1.0 / t_solve2,
+                         "note": "t_solve = cr_computeRHS + preconditioner refresh + 40 fixed PCG iterations, measured"}}
 
 
 def sht_pairs(L, nside, lmax, reps=10, pols=(False, True)):

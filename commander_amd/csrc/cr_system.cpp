@@ -1134,7 +1134,9 @@ void CrSystem::compute_rhs(bool sample, const double* const* resid, const double
                            const double* mu, double* rhs) {
     CMDR_REQUIRE(finalized_, "finalize first");
     const int ncomp = (int)comps_.size();
-    last_resid_.assign(resid, resid + bands_.size());   // the 'chisq' convergence criterion evaluates against these
+    // the 'chisq' convergence criterion evaluates against these; a solve that asks for it copies them on entry
+    last_resid_.assign(resid, resid + bands_.size());
+    resid_owned_ = false;
     for (Compact& K : compacts_) CMDR_HIP_CHECK(hipMemsetAsync(yc_.get() + K.pos, 0, sizeof(double) * K.nparam, stream_));
     for (Group& G : groups_) {
         ShtPlan& P = *G.plan;
@@ -1750,6 +1752,19 @@ SolveResult CrSystem::solve(const double* b, double* x, int crit, double tol, in
     const bool fixed_iter = (crit == 1), by_chisq = (crit == 2);
     const int ncomp = (int)comps_.size();
     const int64_t n = ncr_;
+    if (by_chisq && !resid_owned_) {
+        // the criterion reads the residual maps of the last cmdr_compute_rhs at every check: take copies now, so the
+        // caller's maps only have to live until this call is entered (not through the solve)
+        CMDR_REQUIRE(!last_resid_.empty(), "the chisq criterion needs the residual maps: call cmdr_compute_rhs first");
+        resid_own_.resize(bands_.size());
+        for (size_t b = 0; b < bands_.size(); ++b) {
+            const size_t nb = (size_t)band_npix((int)b) * bands_[b].nmaps;
+            resid_own_[b].ensure(nb);
+            CMDR_HIP_CHECK(hipMemcpyAsync(resid_own_[b].get(), last_resid_[b], nb * sizeof(double), hipMemcpyDeviceToDevice, stream_));
+            last_resid_[b] = resid_own_[b].get();
+        }
+        resid_owned_ = true;
+    }
     double* scal = scal_.get();      // [0] delta_new [1] delta_old [2] d.q [3] delta0
     SolveResult R;
     if (!x0) {                                                                          // :133-134

@@ -226,7 +226,9 @@ class CrSystem {
     void synth_T_of(Group& G, const double* v, const double* w, const double* extra);
     void forward_maps(Group& G, const double* sx);
     double chisq_of(const double* x);
-    std::vector<const double*> last_resid_;
+    std::vector<const double*> last_resid_;   // residual maps of the last compute_rhs (caller's until a chisq solve copies them)
+    std::vector<DevBuf<double>> resid_own_;
+    bool resid_owned_ = false;
     void rebuild_mixing();
     void mix_forward(Group& G, const double* sx);
     void mix_adjoint(Group& G, bool rhs);

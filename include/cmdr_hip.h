@@ -242,7 +242,8 @@ int cmdr_apply_mono_dipole_prior_dev(cmdr_ctx* ctx, int comp, double* amp_dev, i
                                      const double* mask_dev, int type, double* mu);
 /* solve_cr_eqn_by_CG (comm_cr_mod.f90:48-406).  crit: 0 'residual', 1 'fixed_iter', 2 'chisq' (cpar%cg_conv_crit;
  * 'chisq' = relative change of cr_compute_chisq, :223-226, :239-242, :408-465, evaluated against the residual maps the
- * last cmdr_compute_rhs call received -- keep them alive for the _dev form -- with tol as the limit);
+ * last cmdr_compute_rhs call received -- the _dev form copies them when such a solve is entered, so they only have to be
+ * alive until then -- with tol as the limit);
  * tol = cg_tol, miniter = cg_miniter, maxiter = cg_samp_group_maxiter, check_freq = cg_check_conv_freq;
  * x0 = NULL <=> cg_init_zero, else the current amplitudes (cr_amp2x).  On return x is already multiplied by
  * sqrt(S) (:350-389).  stat follows :392-395 (1 = not converged within maxiter; the caller may ignore it, as

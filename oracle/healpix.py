@@ -62,27 +62,45 @@ class AlmInfo:
     block holds interleaved (+m, -m) for l=m..lmax.  ``lm[:, i] = (l, m)``, ``mind[m]`` = start (or -1).
     """
 
+    _cache = {}
+
+    def __new__(cls, lmax, myid=0, nprocs=1):
+        # the tables are immutable: one instance per (lmax, myid, nprocs) (cr_matmulA builds one per band and call)
+        key = (int(lmax), int(myid), int(nprocs))
+        inst = cls._cache.get(key)
+        if inst is None:
+            inst = super().__new__(cls)
+            inst._build(*key)
+            if len(cls._cache) > 64:
+                cls._cache.clear()
+            cls._cache[key] = inst
+        return inst
+
     def __init__(self, lmax, myid=0, nprocs=1):
+        pass
+
+    def _build(self, lmax, myid, nprocs):
+        self.key = (int(lmax), int(myid), int(nprocs))
         self.lmax = int(lmax)
         self.ms = list(range(myid, lmax + 1, nprocs))
         self.mind = -np.ones(lmax + 1, dtype=np.int64)
-        lm = []
+        ls, ms = [], []
         ind = 0
-        for m in self.ms:
+        for m in self.ms:                    # the loop of comm_map_mod.f90:237-258, one numpy block per m
             self.mind[m] = ind
             if m == 0:
-                for l in range(0, lmax + 1):
-                    lm.append((l, 0))
+                ls.append(np.arange(0, lmax + 1, dtype=np.int64))
+                ms.append(np.zeros(lmax + 1, dtype=np.int64))
                 ind += lmax + 1
             else:
-                for l in range(m, lmax + 1):
-                    lm.append((l, m))
-                    lm.append((l, -m))
-                ind += 2 * (lmax - m + 1)
+                n = lmax - m + 1
+                ls.append(np.repeat(np.arange(m, lmax + 1, dtype=np.int64), 2))
+                ms.append(np.tile(np.array([m, -m], dtype=np.int64), n))
+                ind += 2 * n
         self.nalm = ind
-        self.lm = np.array(lm, dtype=np.int64).T.reshape(2, -1)
-        self.l = self.lm[0]
-        self.m = self.lm[1]
+        self.l = np.concatenate(ls) if ls else np.zeros(0, dtype=np.int64)
+        self.m = np.concatenate(ms) if ms else np.zeros(0, dtype=np.int64)
+        self.lm = np.stack([self.l, self.m])
 
     def lm2i(self, l, m):
         """comm_map_mod.f90:1213-1246."""
@@ -107,6 +125,9 @@ class AlmInfo:
         return np.where(ok, idx, -1)
 
 
+_EQ_CACHE = {}
+
+
 def alm_equal(src, src_info, dst_info, nmaps_dst=None):
     """comm_map_mod.f90:1148-1165: copy a_lm between two layouts via (l,m) lookup, zero fill."""
     src = np.asarray(src)
@@ -114,8 +135,15 @@ def alm_equal(src, src_info, dst_info, nmaps_dst=None):
         src = src[:, None]
     nd = src.shape[1] if nmaps_dst is None else nmaps_dst
     out = np.zeros((dst_info.nalm, nd))
-    j = src_info.lm2i_vec(dst_info.l, dst_info.m)
-    ok = j >= 0
+    key = (src_info.key, dst_info.key)          # the lookup depends on the two layouts only
+    hit = _EQ_CACHE.get(key)
+    if hit is None:
+        j = src_info.lm2i_vec(dst_info.l, dst_info.m)
+        hit = (j, j >= 0)
+        if len(_EQ_CACHE) > 256:
+            _EQ_CACHE.clear()
+        _EQ_CACHE[key] = hit
+    j, ok = hit
     q = min(src.shape[1], nd)
     out[ok, :q] = src[j[ok], :q]
     return out

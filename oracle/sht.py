@@ -39,6 +39,10 @@ def lib():
         L.orc_sht_spin2.argtypes = [ctypes.c_int, ctypes.c_int, ctypes.c_int, dp, dp, dp, dp, dp, ctypes.c_int,
                                     ctypes.c_int, ctypes.c_int]
         L.orc_sht_spin2.restype = ctypes.c_int
+        L.orc_sht_fast.argtypes = L.orc_sht.argtypes
+        L.orc_sht_fast.restype = ctypes.c_int
+        L.orc_sht_spin2_fast.argtypes = L.orc_sht_spin2.argtypes
+        L.orc_sht_spin2_fast.restype = ctypes.c_int
         L.orc_lm2i.argtypes = [ctypes.c_int, ctypes.c_int, ctypes.c_int]
         L.orc_lm2i.restype = ctypes.c_int64
         _LIB = L
@@ -60,6 +64,15 @@ def _threads(nthreads, nside):
     return max(n, 1)
 
 
+def _fast(fast):
+    """Which Legendre stage: the plain per-ring loops (the restatement as first written) or the same arithmetic blocked
+    over ring pairs for SIMD (orc_sht_fast; pinned against the plain form and the brute-force goldens in
+    tests/test_oracle.py).  Default: fast, ORACLE_FAST=0 selects the plain loops everywhere."""
+    if fast is None:
+        return os.environ.get("ORACLE_FAST", "1") != "0"
+    return bool(fast)
+
+
 def _p(a):
     return a.ctypes.data_as(ctypes.POINTER(ctypes.c_double))
 
@@ -72,9 +85,10 @@ def npix(nside):
     return 12 * nside * nside
 
 
-def sht(job, nside, lmax, alm=None, map=None, wring=None, fft_mode=1, use_mlim=True, nthreads=0):
+def sht(job, nside, lmax, alm=None, map=None, wring=None, fft_mode=1, use_mlim=True, nthreads=0, fast=None):
     """Run one scalar SHT.  Returns the output array (map for Y/WY, alm for Yt/YtW)."""
     L = lib()
+    fn = L.orc_sht_fast if _fast(fast) else L.orc_sht
     wp = None
     if wring is not None:
         wring = np.ascontiguousarray(wring, dtype=np.float64)
@@ -84,12 +98,12 @@ def sht(job, nside, lmax, alm=None, map=None, wring=None, fft_mode=1, use_mlim=T
         a = np.ascontiguousarray(alm, dtype=np.float64)
         assert a.shape == (nalm(lmax),), a.shape
         out = np.zeros(npix(nside))
-        rc = L.orc_sht(job, nside, lmax, wp, _p(a), _p(out), int(fft_mode), int(use_mlim), _threads(nthreads, nside))
+        rc = fn(job, nside, lmax, wp, _p(a), _p(out), int(fft_mode), int(use_mlim), _threads(nthreads, nside))
     else:
         m = np.ascontiguousarray(map, dtype=np.float64)
         assert m.shape == (npix(nside),), m.shape
         out = np.zeros(nalm(lmax))
-        rc = L.orc_sht(job, nside, lmax, wp, _p(out), _p(m), int(fft_mode), int(use_mlim), _threads(nthreads, nside))
+        rc = fn(job, nside, lmax, wp, _p(out), _p(m), int(fft_mode), int(use_mlim), _threads(nthreads, nside))
     if rc != 0:
         raise RuntimeError("orc_sht failed")
     return out
@@ -122,7 +136,7 @@ def invn_diag(nside, lmax, al0, nthreads=0):
 
 
 def sht_spin2(job, nside, lmax, almE=None, almB=None, mapQ=None, mapU=None, wring=None, fft_mode=1, use_mlim=True,
-              nthreads=0):
+              nthreads=0, fast=None):
     """One spin-2 transform (Q,U) <-> (E,B), Commander's polarisation call (comm_map_mod.f90:446-449).
     Returns (mapQ, mapU) for Y/WY, (almE, almB) for Yt/YtW."""
     L = lib()
@@ -138,8 +152,8 @@ def sht_spin2(job, nside, lmax, almE=None, almB=None, mapQ=None, mapU=None, wrin
         q = np.ascontiguousarray(mapQ, dtype=np.float64)
         u = np.ascontiguousarray(mapU, dtype=np.float64)
         e, b = np.zeros(nalm(lmax)), np.zeros(nalm(lmax))
-    rc = L.orc_sht_spin2(job, nside, lmax, wp, _p(e), _p(b), _p(q), _p(u), int(fft_mode), int(use_mlim),
-                         _threads(nthreads, nside))
+    fn = L.orc_sht_spin2_fast if _fast(fast) else L.orc_sht_spin2
+    rc = fn(job, nside, lmax, wp, _p(e), _p(b), _p(q), _p(u), int(fft_mode), int(use_mlim), _threads(nthreads, nside))
     if rc != 0:
         raise RuntimeError("orc_sht_spin2 failed")
     return (q, u) if job in (JOB_Y, JOB_WY) else (e, b)

@@ -98,7 +98,28 @@ int64_t orc_lm2i(int lmax, int l, int m) { /* comm_map_mod.f90:1213-1246 */
 }
 
 /* ---------------------------------------------------------------- FFT (radix-2 + Bluestein), fft_mode=1 */
+/* twiddles exp(2 pi i k / M), k < M/2, per power of two M, built once (the first version called cos / sin for every
+   butterfly group of every transform: ~3 M libm calls per Bluestein ring, which dominated the whole oracle) */
+static cplx* g_tw[40];
+static const cplx* tw_get(int n) {
+    int lg = 0;
+    while ((1 << lg) < n) ++lg;
+    if (!g_tw[lg]) {
+#pragma omp critical(orc_tw)
+        if (!g_tw[lg]) {
+            cplx* t = (cplx*)malloc(sizeof(cplx) * (n / 2 + 1));
+            for (int k = 0; k < n / 2; ++k) {
+                const double ang = TWOPI * (double)k / (double)n;
+                t[k] = cos(ang) + I * sin(ang);
+            }
+            g_tw[lg] = t;
+        }
+    }
+    return g_tw[lg];
+}
+
 static void fft_pow2(cplx* a, int n, int sign) { /* in place, unnormalised, exp(sign*2*pi*i*jk/n) */
+    const cplx* tw = n > 1 ? tw_get(n) : NULL;
     for (int i = 1, j = 0; i < n; ++i) {
         int bit = n >> 1;
         for (; j & bit; bit >>= 1) j ^= bit;
@@ -107,9 +128,9 @@ static void fft_pow2(cplx* a, int n, int sign) { /* in place, unnormalised, exp(
     }
     for (int len = 2; len <= n; len <<= 1) {
         int half = len >> 1;
+        const int stride = n / len;
         for (int k = 0; k < half; ++k) {
-            double ang = sign * TWOPI * (double)k / (double)len;
-            cplx w = cos(ang) + I * sin(ang);
+            const cplx w = sign > 0 ? tw[k * stride] : conj(tw[k * stride]);   /* exp(sign 2 pi i k / len) */
             for (int i = k; i < n; i += len) {
                 cplx u = a[i], v = a[i + half] * w;
                 a[i] = u + v;
@@ -145,6 +166,20 @@ static void plan_init(fftplan* p, int n) {
     fft_pow2(p->chat, M, -1);
 }
 static void plan_free(fftplan* p) { free(p->w); free(p->chat); }
+
+/* the Bluestein plans of all ring lengths 4 i, i <= nside, kept for the most recent nside (built in parallel) */
+static fftplan* g_plans;
+static int g_plans_nside;
+static const fftplan* plans_get(int nside) {
+    if (g_plans_nside == nside) return g_plans;
+    if (g_plans) { for (int i = 1; i <= g_plans_nside; ++i) plan_free(&g_plans[i]); free(g_plans); }
+    g_plans = (fftplan*)malloc(sizeof(fftplan) * (nside + 1));
+    for (int lg = 1; (1 << lg) <= 16 * nside; ++lg) (void)tw_get(1 << lg);   /* outside the parallel loop */
+#pragma omp parallel for schedule(dynamic, 8)
+    for (int i = 1; i <= nside; ++i) plan_init(&g_plans[i], 4 * i);
+    g_plans_nside = nside;
+    return g_plans;
+}
 
 /* y_k = sum_j x_j exp(sign*2*pi*i*jk/n); x,y length n; work length >= max(n,M) */
 static void fft_any(const fftplan* p, const cplx* x, cplx* y, cplx* work, int sign) {
@@ -195,11 +230,7 @@ static void ring_stage(int synth, int nside, int lmax, const double* wring, int 
                        int fft_mode, const ringinfo* ri) {
     const int nring = 4 * nside - 1, mmax = lmax, nm = mmax + 1;
     const int64_t npix = 12 * (int64_t)nside * nside;
-    fftplan* plans = NULL;
-    if (fft_mode) {
-        plans = (fftplan*)malloc(sizeof(fftplan) * (nside + 1));
-        for (int i = 1; i <= nside; ++i) plan_init(&plans[i], 4 * i);
-    }
+    const fftplan* plans = fft_mode ? plans_get(nside) : NULL;
     /* ---------------- analysis: pixels -> phases (per ring) */
     if (!synth) {
 #pragma omp parallel
@@ -289,7 +320,6 @@ static void ring_stage(int synth, int nside, int lmax, const double* wring, int 
             free(x); free(y); free(work); free(ct); free(st);
         }
     }
-    if (plans) { for (int i = 1; i <= nside; ++i) plan_free(&plans[i]); free(plans); }
 }
 
 /*
@@ -305,7 +335,6 @@ static void ring_stage(int synth, int nside, int lmax, const double* wring, int 
 int orc_sht(int job, int nside, int lmax, const double* wring, double* alm, double* map, int fft_mode,
             int use_mlim, int nthreads) {
     const int nring = 4 * nside - 1, npair = 2 * nside, mmax = lmax, nm = mmax + 1;
-    const int64_t npix = 12 * (int64_t)nside * nside;
     const int synth = (job == JOB_Y || job == JOB_WY);
     const int weighted = (job == JOB_YtW || job == JOB_WY);
     const double sqrt2 = sqrt(2.0);
@@ -653,6 +682,340 @@ int orc_sht_spin2(int job, int nside, int lmax, const double* wring, double* alm
     }
     if (!synth) { /* columns m > lmax never run; l < 2 entries stay as initialised by the caller: zero them */
         for (int64_t i = 0; i < (int64_t)(lmax + 1) * (lmax + 1); ++i) { (void)i; }
+    }
+    if (synth) {
+        ring_stage(1, nside, lmax, wring, weighted, mapQ, phQ, fft_mode, ri);
+        ring_stage(1, nside, lmax, wring, weighted, mapU, phU, fft_mode, ri);
+    }
+    free(ri); free(phQ); free(phU);
+    return 0;
+}
+
+/* ======================================================================================= vectorised Legendre stages
+ * The same transforms with the Legendre stage blocked over ring pairs: NV ring pairs advance together in explicit SIMD
+ * vectors (GCC vector extensions, 4 doubles each; l stays sequential).  Identical arithmetic per ring pair -- recursion,
+ * 2^e scaling, mlim cut, parity split -- except that (i) the order in which ring pairs are summed into a_lm differs and
+ * (ii) the 2^300 rescale is looked for every 8th l instead of every l (the mantissa grows by < 4 per step, so it stays
+ * far inside the double range; scaling by powers of two is exact).  Used as the default oracle and as the in-run CPU
+ * baseline of bench.py ("same algorithm class as libsharp2"); tests/test_oracle.py pins it
+ * against the plain loops above and against the brute-force goldens.  TEST INFRASTRUCTURE like the rest of this file. */
+typedef double v4d __attribute__((vector_size(32), aligned(32)));
+typedef long long v4l __attribute__((vector_size(32), aligned(32)));
+#define VL 4                 /* doubles per vector */
+#define NVV 4                /* vectors per block, scalar transform: 16 ring pairs */
+#define NVV2 2               /* spin-2: 8 ring pairs */
+typedef union { v4d v; double s[VL]; } u4d;
+typedef union { v4l v; long long s[VL]; } u4l;
+static inline v4d vbc(double a) { return (v4d){a, a, a, a}; }
+static inline double vsum(v4d a) { u4d u; u.v = a; return (u.s[0] + u.s[1]) + (u.s[2] + u.s[3]); }
+
+int orc_sht_fast(int job, int nside, int lmax, const double* wring, double* alm, double* map, int fft_mode,
+                 int use_mlim, int nthreads) {
+    const int nring = 4 * nside - 1, npair = 2 * nside, mmax = lmax, nm = mmax + 1;
+    const int synth = (job == JOB_Y || job == JOB_WY);
+    const int weighted = (job == JOB_YtW || job == JOB_WY);
+    const double sqrt2 = sqrt(2.0);
+    enum { NVs = VL * NVV };
+#ifdef _OPENMP
+    if (nthreads > 0) omp_set_num_threads(nthreads);
+#endif
+    (void)nthreads;
+    cplx* ph = (cplx*)calloc((size_t)nring * nm, sizeof(cplx));
+    if (!ph) return -1;
+    ringinfo* ri = (ringinfo*)malloc(sizeof(ringinfo) * (nring + 1));
+    for (int r = 1; r <= nring; ++r) ri[r] = ring_info(nside, r);
+    double* logpref = (double*)malloc(sizeof(double) * nm);
+    logpref[0] = -0.5 * log(4.0 * PI);
+    for (int m = 1; m <= mmax; ++m) logpref[m] = logpref[m - 1] + 0.5 * log((2.0 * m + 1.0) / (2.0 * m));
+    if (!synth) ring_stage(0, nside, lmax, wring, weighted, map, ph, fft_mode, ri);
+#pragma omp parallel
+    {
+        double* ieps = (double*)malloc(sizeof(double) * (lmax + 2));
+        double* epsv = (double*)malloc(sizeof(double) * (lmax + 2));
+        double* are = (double*)malloc(sizeof(double) * (lmax + 1));
+        double* aim = (double*)malloc(sizeof(double) * (lmax + 1));
+#pragma omp for schedule(dynamic, 1)
+        for (int mi = 0; mi <= mmax; ++mi) {
+            const int m = (mi & 1) ? mmax - mi / 2 : mi / 2;
+            for (int l = m; l <= lmax; ++l) { epsv[l] = eps_lm(l, m); ieps[l] = l > m ? 1.0 / epsv[l] : 0.0; }
+            ieps[lmax + 1] = 0.0;
+            const int64_t base = mind(lmax, m);
+            const double mfac = m > 0 ? sqrt2 : 1.0;
+            for (int l = m; l <= lmax; ++l) {
+                if (synth) {
+                    are[l] = (m == 0 ? alm[base + l] : alm[base + 2 * (l - m)] * mfac);
+                    aim[l] = (m == 0 ? 0.0 : alm[base + 2 * (l - m) + 1] * mfac);
+                } else are[l] = aim[l] = 0.0;
+            }
+            for (int rp0 = 1; rp0 <= npair; rp0 += NVs) {
+                u4d x[NVV], lc[NVV], lp[NVV], sf[NVV], Ger[NVV], Gei[NVV], Gor[NVV], Goi[NVV];
+                v4d Fer[NVV], Fei[NVV], For[NVV], Foi[NVV];
+                long e[NVs];
+                int on[NVs], any = 0;
+                for (int v = 0; v < NVs; ++v) {
+                    const int rp = rp0 + v, k = v / VL, j = v % VL;
+                    x[k].s[j] = lc[k].s[j] = lp[k].s[j] = sf[k].s[j] = 0;
+                    Ger[k].s[j] = Gei[k].s[j] = Gor[k].s[j] = Goi[k].s[j] = 0;
+                    e[v] = 0; on[v] = 0;
+                    if (rp > npair) continue;
+                    const ringinfo R = ri[rp];
+                    if (use_mlim && m > mlim_of(lmax, 0, R.sth, R.z)) continue;
+                    on[v] = 1; any = 1;
+                    x[k].s[j] = R.z;
+                    const double l2 = (logpref[m] + (m > 0 ? (double)m * log(R.sth) : 0.0)) / M_LN2;
+                    const double fl = floor(l2);
+                    e[v] = (long)fl;
+                    lc[k].s[j] = (m & 1) ? -exp2(l2 - fl) : exp2(l2 - fl);
+                    sf[k].s[j] = (e[v] < -900) ? 0.0 : ldexp(1.0, (int)e[v]);
+                    if (!synth) {
+                        const cplx Gn = ph[(size_t)(rp - 1) * nm + m];
+                        const cplx Gs = rp < npair ? ph[(size_t)(4 * nside - rp - 1) * nm + m] : 0;
+                        Ger[k].s[j] = creal(Gn + Gs); Gei[k].s[j] = cimag(Gn + Gs);
+                        Gor[k].s[j] = creal(Gn - Gs); Goi[k].s[j] = cimag(Gn - Gs);
+                    }
+                }
+                if (!any) continue;
+                for (int k = 0; k < NVV; ++k) Fer[k] = Fei[k] = For[k] = Foi[k] = vbc(0.0);
+                const v4d big = vbc(RESCALE_BIG), nbig = vbc(-RESCALE_BIG);
+                for (int lb = m; lb <= lmax; lb += 8) {
+                    const int le = lb + 8 <= lmax + 1 ? lb + 8 : lmax + 1;
+                    v4l over = {0, 0, 0, 0};
+                    for (int l = lb; l < le; ++l) {
+                        const int odd = (l - m) & 1;
+                        const v4d el = vbc(epsv[l]), ie1 = vbc(ieps[l + 1]);
+                        if (synth) {
+                            const v4d ar = vbc(are[l]), ai = vbc(aim[l]);
+                            for (int k = 0; k < NVV; ++k) {
+                                const v4d lam = lc[k].v * sf[k].v;
+                                if (odd) { For[k] += ar * lam; Foi[k] += ai * lam; }
+                                else     { Fer[k] += ar * lam; Fei[k] += ai * lam; }
+                                const v4d ln = (x[k].v * lc[k].v - el * lp[k].v) * ie1;
+                                lp[k].v = lc[k].v;
+                                lc[k].v = ln;
+                                over |= (ln > big) | (ln < nbig);
+                            }
+                        } else {
+                            v4d sr = vbc(0.0), si = vbc(0.0);
+                            for (int k = 0; k < NVV; ++k) {
+                                const v4d lam = lc[k].v * sf[k].v;
+                                sr += (odd ? Gor[k].v : Ger[k].v) * lam;
+                                si += (odd ? Goi[k].v : Gei[k].v) * lam;
+                                const v4d ln = (x[k].v * lc[k].v - el * lp[k].v) * ie1;
+                                lp[k].v = lc[k].v;
+                                lc[k].v = ln;
+                                over |= (ln > big) | (ln < nbig);
+                            }
+                            are[l] += vsum(sr);
+                            aim[l] += vsum(si);
+                        }
+                    }
+                    u4l ov; ov.v = over;
+                    if (ov.s[0] | ov.s[1] | ov.s[2] | ov.s[3])
+                        for (int v = 0; v < NVs; ++v) {
+                            const int k = v / VL, j = v % VL;
+                            if (fabs(lc[k].s[j]) > RESCALE_BIG) {
+                                lc[k].s[j] *= RESCALE_INV; lp[k].s[j] *= RESCALE_INV; e[v] += 300;
+                                sf[k].s[j] = (e[v] < -900) ? 0.0 : ldexp(1.0, (int)e[v]);
+                            }
+                        }
+                }
+                if (synth)
+                    for (int v = 0; v < NVs; ++v) {
+                        const int rp = rp0 + v, k = v / VL, j = v % VL;
+                        if (!on[v]) continue;
+                        u4d er, ei, or_, oi; er.v = Fer[k]; ei.v = Fei[k]; or_.v = For[k]; oi.v = Foi[k];
+                        ph[(size_t)(rp - 1) * nm + m] = (er.s[j] + or_.s[j]) + I * (ei.s[j] + oi.s[j]);
+                        if (rp < npair) ph[(size_t)(4 * nside - rp - 1) * nm + m] = (er.s[j] - or_.s[j]) + I * (ei.s[j] - oi.s[j]);
+                    }
+            }
+            if (!synth) {
+                if (m == 0) for (int l = 0; l <= lmax; ++l) alm[base + l] = are[l];
+                else for (int l = m; l <= lmax; ++l) {
+                    alm[base + 2 * (l - m)] = are[l] * mfac;
+                    alm[base + 2 * (l - m) + 1] = aim[l] * mfac;
+                }
+            }
+        }
+        free(ieps); free(epsv); free(are); free(aim);
+    }
+    if (synth) ring_stage(1, nside, lmax, wring, weighted, map, ph, fft_mode, ri);
+    free(logpref); free(ri); free(ph);
+    return 0;
+}
+
+int orc_sht_spin2_fast(int job, int nside, int lmax, const double* wring, double* almE, double* almB, double* mapQ,
+                       double* mapU, int fft_mode, int use_mlim, int nthreads) {
+    const int nring = 4 * nside - 1, npair = 2 * nside, mmax = lmax, nm = mmax + 1;
+    const int synth = (job == JOB_Y || job == JOB_WY);
+    const int weighted = (job == JOB_YtW || job == JOB_WY);
+    const double sqrt2 = sqrt(2.0);
+    enum { NVs = VL * NVV2 };
+#ifdef _OPENMP
+    if (nthreads > 0) omp_set_num_threads(nthreads);
+#endif
+    (void)nthreads;
+    cplx* phQ = (cplx*)calloc((size_t)nring * nm, sizeof(cplx));
+    cplx* phU = (cplx*)calloc((size_t)nring * nm, sizeof(cplx));
+    if (!phQ || !phU) return -1;
+    ringinfo* ri = (ringinfo*)malloc(sizeof(ringinfo) * (nring + 1));
+    for (int r = 1; r <= nring; ++r) ri[r] = ring_info(nside, r);
+    if (!synth) {
+        ring_stage(0, nside, lmax, wring, weighted, mapQ, phQ, fft_mode, ri);
+        ring_stage(0, nside, lmax, wring, weighted, mapU, phU, fft_mode, ri);
+    }
+#pragma omp parallel
+    {
+        double* Cl = (double*)malloc(sizeof(double) * (lmax + 3));
+        double* iCl = (double*)malloc(sizeof(double) * (lmax + 3));
+        double* smv = (double*)malloc(sizeof(double) * (lmax + 3));
+        double* Er = (double*)malloc(sizeof(double) * (lmax + 1));
+        double* Ei = (double*)malloc(sizeof(double) * (lmax + 1));
+        double* Br = (double*)malloc(sizeof(double) * (lmax + 1));
+        double* Bi = (double*)malloc(sizeof(double) * (lmax + 1));
+#pragma omp for schedule(dynamic, 1)
+        for (int mi = 0; mi <= mmax; ++mi) {
+            const int m = (mi & 1) ? mmax - mi / 2 : mi / 2;
+            const int l0 = m > 2 ? m : 2;
+            if (l0 > lmax) continue;
+            for (int l = l0; l <= lmax + 1; ++l) {
+                const double dl = l, dm = m;
+                Cl[l] = sqrt((dl * dl - dm * dm) * (dl * dl - 4.0) / (dl * dl * (4.0 * dl * dl - 1.0)));
+                iCl[l] = 1.0 / Cl[l];
+                smv[l] = 2.0 * m / (dl * (dl + 1.0));
+            }
+            const int64_t base = mind(lmax, m);
+            const double mfac = m > 0 ? sqrt2 : 1.0;
+            for (int l = 0; l <= lmax; ++l) { Er[l] = Ei[l] = Br[l] = Bi[l] = 0.0; }
+            if (synth)
+                for (int l = l0; l <= lmax; ++l) {
+                    if (m == 0) { Er[l] = almE[base + l]; Br[l] = almB[base + l]; }
+                    else {
+                        Er[l] = almE[base + 2 * (l - m)] * mfac; Ei[l] = almE[base + 2 * (l - m) + 1] * mfac;
+                        Br[l] = almB[base + 2 * (l - m)] * mfac; Bi[l] = almB[base + 2 * (l - m) + 1] * mfac;
+                    }
+                }
+            for (int rp0 = 1; rp0 <= npair; rp0 += NVs) {
+                u4d x[NVV2], pc[NVV2], pp[NVV2], ps[NVV2], mc[NVV2], mp[NVV2], ms[NVV2];
+                /* analysis: ring combinations with the parity sign folded in: [0] for l + m even, [1] for odd:
+                   gW = G[odd], gX = G[1 - odd]  (gQW = GQn + sW GQs, sW = +1 even / -1 odd; gQX = GQn - sW GQs) */
+                u4d QWr[2][NVV2], QWi[2][NVV2], UWr[2][NVV2], UWi[2][NVV2];
+                v4d Qkr[NVV2], Qki[NVV2], Qfr[NVV2], Qfi[NVV2], Ukr[NVV2], Uki[NVV2], Ufr[NVV2], Ufi[NVV2];
+                long pe[NVs], me[NVs];
+                int on[NVs], any = 0;
+                for (int v = 0; v < NVs; ++v) {
+                    const int rp = rp0 + v, k = v / VL, j = v % VL;
+                    x[k].s[j] = pc[k].s[j] = pp[k].s[j] = ps[k].s[j] = mc[k].s[j] = mp[k].s[j] = ms[k].s[j] = 0;
+                    pe[v] = me[v] = 0; on[v] = 0;
+                    for (int q = 0; q < 2; ++q) QWr[q][k].s[j] = QWi[q][k].s[j] = UWr[q][k].s[j] = UWi[q][k].s[j] = 0;
+                    if (rp > npair) continue;
+                    const ringinfo R = ri[rp];
+                    if (use_mlim && m > mlim_of(lmax, 2, R.sth, R.z)) continue;
+                    on[v] = 1; any = 1;
+                    x[k].s[j] = R.z;
+                    const double th = atan2(R.sth, R.z), c2 = cos(0.5 * th), s2 = sin(0.5 * th);
+                    chain cp, cm;
+                    double lg, sg;
+                    sg = slam_start(2, m, c2, s2, &lg);  chain_init(&cp, sg, lg);
+                    sg = slam_start(-2, m, c2, s2, &lg); chain_init(&cm, sg, lg);
+                    pc[k].s[j] = cp.lc; pp[k].s[j] = cp.lp; ps[k].s[j] = cp.sf; pe[v] = cp.e;
+                    mc[k].s[j] = cm.lc; mp[k].s[j] = cm.lp; ms[k].s[j] = cm.sf; me[v] = cm.e;
+                    if (!synth) {
+                        const cplx GQn = phQ[(size_t)(rp - 1) * nm + m], GUn = phU[(size_t)(rp - 1) * nm + m];
+                        cplx GQs = 0, GUs = 0;
+                        if (rp < npair) { GQs = phQ[(size_t)(4 * nside - rp - 1) * nm + m]; GUs = phU[(size_t)(4 * nside - rp - 1) * nm + m]; }
+                        QWr[0][k].s[j] = creal(GQn + GQs); QWi[0][k].s[j] = cimag(GQn + GQs);
+                        QWr[1][k].s[j] = creal(GQn - GQs); QWi[1][k].s[j] = cimag(GQn - GQs);
+                        UWr[0][k].s[j] = creal(GUn + GUs); UWi[0][k].s[j] = cimag(GUn + GUs);
+                        UWr[1][k].s[j] = creal(GUn - GUs); UWi[1][k].s[j] = cimag(GUn - GUs);
+                    }
+                }
+                if (!any) continue;
+                for (int k = 0; k < NVV2; ++k) Qkr[k] = Qki[k] = Qfr[k] = Qfi[k] = Ukr[k] = Uki[k] = Ufr[k] = Ufi[k] = vbc(0.0);
+                const v4d big = vbc(RESCALE_BIG), nbig = vbc(-RESCALE_BIG), half = vbc(0.5);
+                for (int lb = l0; lb <= lmax; lb += 8) {
+                    const int le = lb + 8 <= lmax + 1 ? lb + 8 : lmax + 1;
+                    v4l over = {0, 0, 0, 0};
+                    for (int l = lb; l < le; ++l) {
+                        const int odd = (l + m) & 1;
+                        const v4d cl = vbc(l > l0 ? Cl[l] : 0.0), ic1 = vbc(iCl[l + 1]), sm = vbc(smv[l]);
+                        if (synth) {
+                            /* F^Q = -(E W + i B X), F^U = -(B W - i E X); even: W-terms keep, X-terms flip; odd: reverse */
+                            const v4d er = vbc(Er[l]), ei = vbc(Ei[l]), br = vbc(Br[l]), bi = vbc(Bi[l]);
+                            for (int k = 0; k < NVV2; ++k) {
+                                const v4d lp2 = pc[k].v * ps[k].v, lm2 = mc[k].v * ms[k].v;
+                                const v4d W = half * (lp2 + lm2), X = half * (lp2 - lm2);
+                                if (!odd) {
+                                    Qkr[k] -= er * W; Qki[k] -= ei * W; Qfr[k] += bi * X; Qfi[k] -= br * X;
+                                    Ukr[k] -= br * W; Uki[k] -= bi * W; Ufr[k] -= ei * X; Ufi[k] += er * X;
+                                } else {
+                                    Qfr[k] -= er * W; Qfi[k] -= ei * W; Qkr[k] += bi * X; Qki[k] -= br * X;
+                                    Ufr[k] -= br * W; Ufi[k] -= bi * W; Ukr[k] -= ei * X; Uki[k] += er * X;
+                                }
+                                v4d ln = ((x[k].v + sm) * pc[k].v - cl * pp[k].v) * ic1;
+                                pp[k].v = pc[k].v; pc[k].v = ln;
+                                over |= (ln > big) | (ln < nbig);
+                                ln = ((x[k].v - sm) * mc[k].v - cl * mp[k].v) * ic1;
+                                mp[k].v = mc[k].v; mc[k].v = ln;
+                                over |= (ln > big) | (ln < nbig);
+                            }
+                        } else {
+                            /* E += -W gQW - i X gUX ; B += -W gUW + i X gQX */
+                            v4d ser = vbc(0.0), sei = vbc(0.0), sbr = vbc(0.0), sbi = vbc(0.0);
+                            for (int k = 0; k < NVV2; ++k) {
+                                const v4d lp2 = pc[k].v * ps[k].v, lm2 = mc[k].v * ms[k].v;
+                                const v4d W = half * (lp2 + lm2), X = half * (lp2 - lm2);
+                                ser += X * UWi[1 - odd][k].v - W * QWr[odd][k].v;
+                                sei -= W * QWi[odd][k].v + X * UWr[1 - odd][k].v;
+                                sbr -= W * UWr[odd][k].v + X * QWi[1 - odd][k].v;
+                                sbi += X * QWr[1 - odd][k].v - W * UWi[odd][k].v;
+                                v4d ln = ((x[k].v + sm) * pc[k].v - cl * pp[k].v) * ic1;
+                                pp[k].v = pc[k].v; pc[k].v = ln;
+                                over |= (ln > big) | (ln < nbig);
+                                ln = ((x[k].v - sm) * mc[k].v - cl * mp[k].v) * ic1;
+                                mp[k].v = mc[k].v; mc[k].v = ln;
+                                over |= (ln > big) | (ln < nbig);
+                            }
+                            Er[l] += vsum(ser); Ei[l] += vsum(sei); Br[l] += vsum(sbr); Bi[l] += vsum(sbi);
+                        }
+                    }
+                    u4l ov; ov.v = over;
+                    if (ov.s[0] | ov.s[1] | ov.s[2] | ov.s[3])
+                        for (int v = 0; v < NVs; ++v) {
+                            const int k = v / VL, j = v % VL;
+                            if (fabs(pc[k].s[j]) > RESCALE_BIG) {
+                                pc[k].s[j] *= RESCALE_INV; pp[k].s[j] *= RESCALE_INV; pe[v] += 300;
+                                ps[k].s[j] = (pe[v] < -900) ? 0.0 : ldexp(1.0, (int)pe[v]);
+                            }
+                            if (fabs(mc[k].s[j]) > RESCALE_BIG) {
+                                mc[k].s[j] *= RESCALE_INV; mp[k].s[j] *= RESCALE_INV; me[v] += 300;
+                                ms[k].s[j] = (me[v] < -900) ? 0.0 : ldexp(1.0, (int)me[v]);
+                            }
+                        }
+                }
+                if (synth)
+                    for (int v = 0; v < NVs; ++v) {
+                        const int rp = rp0 + v, k = v / VL, j = v % VL;
+                        if (!on[v]) continue;
+                        u4d a, b, c, d, e2, f, g, h;
+                        a.v = Qkr[k]; b.v = Qki[k]; c.v = Qfr[k]; d.v = Qfi[k]; e2.v = Ukr[k]; f.v = Uki[k]; g.v = Ufr[k]; h.v = Ufi[k];
+                        phQ[(size_t)(rp - 1) * nm + m] = (a.s[j] + c.s[j]) + I * (b.s[j] + d.s[j]);
+                        phU[(size_t)(rp - 1) * nm + m] = (e2.s[j] + g.s[j]) + I * (f.s[j] + h.s[j]);
+                        if (rp < npair) {
+                            phQ[(size_t)(4 * nside - rp - 1) * nm + m] = (a.s[j] - c.s[j]) + I * (b.s[j] - d.s[j]);
+                            phU[(size_t)(4 * nside - rp - 1) * nm + m] = (e2.s[j] - g.s[j]) + I * (f.s[j] - h.s[j]);
+                        }
+                    }
+            }
+            if (!synth)
+                for (int l = m; l <= lmax; ++l) {
+                    if (m == 0) { almE[base + l] = Er[l]; almB[base + l] = Br[l]; }
+                    else {
+                        almE[base + 2 * (l - m)] = Er[l] * mfac; almE[base + 2 * (l - m) + 1] = Ei[l] * mfac;
+                        almB[base + 2 * (l - m)] = Br[l] * mfac; almB[base + 2 * (l - m) + 1] = Bi[l] * mfac;
+                    }
+                }
+        }
+        free(Cl); free(iCl); free(smv); free(Er); free(Ei); free(Br); free(Bi);
     }
     if (synth) {
         ring_stage(1, nside, lmax, wring, weighted, mapQ, phQ, fft_mode, ri);

@@ -11,26 +11,54 @@ from helpers import rel
 G = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 
 
+@pytest.mark.parametrize("fast", [False, True])
 @pytest.mark.parametrize("nside", [4, 8])
 @pytest.mark.parametrize("fft_mode", [0, 1])
-def test_sht_oracle_vs_bruteforce_golden(nside, fft_mode, oracle_lib):
+def test_sht_oracle_vs_bruteforce_golden(nside, fft_mode, fast, oracle_lib):
+    """both Legendre stages of the oracle -- the plain per-ring loops and the SIMD-blocked form -- against the goldens"""
     g = np.load(os.path.join(G, "sht_bruteforce_nside%d.npz" % nside))
     ns, lmax, w = int(g["nside"]), int(g["lmax"]), g["wring"]
-    kw = dict(fft_mode=fft_mode)
+    kw = dict(fft_mode=fft_mode, fast=fast)
     assert rel(oracle_lib.Y(ns, lmax, g["alm"], **kw), g["Y"]) < 1e-13
     assert rel(oracle_lib.Yt(ns, lmax, g["map"], **kw), g["Yt"]) < 1e-13
     assert rel(oracle_lib.YtW(ns, lmax, g["map"], wring=w, **kw), g["YtW"]) < 1e-13
     assert rel(oracle_lib.WY(ns, lmax, g["alm"], wring=w, **kw), g["WY"]) < 1e-13
 
 
+@pytest.mark.parametrize("fast", [False, True])
 @pytest.mark.parametrize("fft_mode", [0, 1])
-def test_sht_spin2_oracle_vs_bruteforce_golden(fft_mode, oracle_lib):
+def test_sht_spin2_oracle_vs_bruteforce_golden(fft_mode, fast, oracle_lib):
     g = np.load(os.path.join(G, "sht_spin2_bruteforce_nside4.npz"))
     ns, lmax = int(g["nside"]), int(g["lmax"])
-    q, u = oracle_lib.sht_spin2(1, ns, lmax, almE=g["almE"], almB=g["almB"], fft_mode=fft_mode)
+    q, u = oracle_lib.sht_spin2(1, ns, lmax, almE=g["almE"], almB=g["almB"], fft_mode=fft_mode, fast=fast)
     assert rel(np.concatenate([q, u]), np.concatenate([g["Y_Q"], g["Y_U"]])) < 1e-12
-    e, b = oracle_lib.sht_spin2(2, ns, lmax, mapQ=g["mapQ"], mapU=g["mapU"], fft_mode=fft_mode)
+    e, b = oracle_lib.sht_spin2(2, ns, lmax, mapQ=g["mapQ"], mapU=g["mapU"], fft_mode=fft_mode, fast=fast)
     assert rel(np.concatenate([e, b]), np.concatenate([g["Yt_E"], g["Yt_B"]])) < 1e-12
+
+
+def test_simd_blocked_legendre_equals_the_plain_loops(oracle_lib):
+    """The SIMD-blocked Legendre stages (orc_sht_fast / orc_sht_spin2_fast: the default oracle and bench.py's CPU
+    baseline) against the plain per-ring loops: all four jobs, ring weights, aliasing (lmax > 2 Nside), ring counts
+    that do not fill the last block, sizes where the 2^300 rescale and the mlim cut are active."""
+    rng = np.random.default_rng(12)
+    for nside, lmax in [(2, 5), (4, 20), (8, 40), (16, 47), (40, 100), (64, 150), (128, 380)]:
+        na, npx = (lmax + 1) ** 2, 12 * nside * nside
+        a, m = rng.standard_normal(na), rng.standard_normal(npx)
+        w = 1.0 + 0.1 * rng.standard_normal(2 * nside)
+        for job, kw in [(1, dict(alm=a)), (3, dict(alm=a, wring=w)), (2, dict(map=m)), (0, dict(map=m, wring=w))]:
+            f = oracle_lib.sht(job, nside, lmax, fast=True, **kw)
+            p = oracle_lib.sht(job, nside, lmax, fast=False, **kw)
+            assert rel(f, p) < 2e-15, (nside, lmax, job, rel(f, p))
+        e, b = rng.standard_normal(na), rng.standard_normal(na)
+        q, u = rng.standard_normal(npx), rng.standard_normal(npx)
+        for job in (1, 3):
+            f = np.concatenate(oracle_lib.sht_spin2(job, nside, lmax, almE=e, almB=b, wring=w if job == 3 else None, fast=True))
+            p = np.concatenate(oracle_lib.sht_spin2(job, nside, lmax, almE=e, almB=b, wring=w if job == 3 else None, fast=False))
+            assert rel(f, p) < 2e-15, (nside, lmax, job)
+        for job in (2, 0):
+            f = np.concatenate(oracle_lib.sht_spin2(job, nside, lmax, mapQ=q, mapU=u, wring=w if job == 0 else None, fast=True))
+            p = np.concatenate(oracle_lib.sht_spin2(job, nside, lmax, mapQ=q, mapU=u, wring=w if job == 0 else None, fast=False))
+            assert rel(f, p) < 2e-15, (nside, lmax, job)
 
 
 def test_sht_spin2_oracle_properties(oracle_lib):
