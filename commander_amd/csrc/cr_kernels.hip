@@ -55,18 +55,20 @@ void launch_band_prep(const CompDev* comps, int ncomp, const double* sx, const d
 __global__ void k_band_post(const CompDev* __restrict__ comps, int ncomp, const double* __restrict__ part,
                             int64_t pms, int64_t pcs, int nchunk, int nbm, const int* __restrict__ bm_stokes,
                             const double* __restrict__ w, const double* __restrict__ cnorm, int lmax_g, int lmax_max,
-                            double* __restrict__ yc, int accumulate, const int* __restrict__ lwtab) {
-    const int m = blockIdx.y, l = m + blockIdx.x * 256 + threadIdx.x;
+                            double* __restrict__ yc, int accumulate, const int* __restrict__ lwtab, int m0) {
+    const int m = m0 + blockIdx.y, l = m + blockIdx.x * 256 + threadIdx.x;
     if (l > lmax_max) return;
     band_post_elem(comps, ncomp, part, pms, pcs, nchunk, nbm, bm_stokes, w, cnorm, lmax_g, yc, accumulate, m, l,
                    m <= lmax_g ? lwtab : nullptr);
 }
 void launch_band_post(const CompDev* comps, int ncomp, int lmax_max, const double* part, int64_t pms, int64_t pcs,
                       int nchunk, int nbm, const int* bm_stokes, const double* w, const double* cnorm, int lmax_g,
-                      double* yc, bool accumulate, hipStream_t s, const int* lwtab) {
-    dim3 grid((lmax_max + 1 + 255) / 256, lmax_max + 1);
+                      double* yc, bool accumulate, hipStream_t s, const int* lwtab, int m0, int m1) {
+    if (m1 < 0 || m1 > lmax_max + 1) m1 = lmax_max + 1;     // columns m0 <= m < m1 (default: all)
+    if (m1 <= m0) return;
+    dim3 grid((lmax_max + 1 + 255) / 256, m1 - m0);
     hipLaunchKernelGGL(k_band_post, grid, dim3(256), 0, s, comps, ncomp, part, pms, pcs, nchunk, nbm, bm_stokes, w,
-                       cnorm, lmax_g, lmax_max, yc, accumulate ? 1 : 0, lwtab);
+                       cnorm, lmax_g, lmax_max, yc, accumulate ? 1 : 0, lwtab, m0);
 }
 
 __global__ void k_band_prep2(const CompDev* __restrict__ comps, int ncomp, const double* __restrict__ sx,

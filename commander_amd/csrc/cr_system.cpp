@@ -10,6 +10,7 @@ CrSystem::CrSystem(int device) {
     CMDR_HIP_CHECK(hipSetDevice(device));
     CMDR_HIP_CHECK(hipStreamCreate(&stream_));
     CMDR_HIP_CHECK(hipStreamCreate(&stream_ring_));
+    CMDR_HIP_CHECK(hipStreamCreate(&stream_comm_));
     if (const char* e = std::getenv("CMDR_PIPELINE")) pipeline_ = std::atoi(e) != 0;
 }
 
@@ -20,6 +21,9 @@ CrSystem::~CrSystem() {
         for (hipEvent_t e : G.ev_ring) (void)hipEventDestroy(e);
     }
     if (stream_ring_) (void)hipStreamDestroy(stream_ring_);
+    if (stream_comm_) (void)hipStreamDestroy(stream_comm_);
+    if (ev_half_) (void)hipEventDestroy(ev_half_);
+    if (ev_comm_) (void)hipEventDestroy(ev_comm_);
     if (stream_) (void)hipStreamDestroy(stream_);
 }
 
@@ -793,9 +797,64 @@ void CrSystem::reduce(double* v, int64_t n) {
     allreduce_(allreduce_user_, v, n);
 }
 
+// Sum over ranks of the rows m0 <= m < m1 of every diffuse block of a stacked vector, stream-ordered on `st` (native RCCL
+// or the stream callback; one group call for all blocks).
+void CrSystem::reduce_rows(double* v, int m0, int m1, hipStream_t st) {
+    struct Rng { int64_t off, n; };
+    std::vector<Rng> rs;
+    for (const Comp& C : comps_) {
+        const int lm = C.d.lmax;
+        const int a = std::min(m0, lm + 1), b = std::min(m1, lm + 1);
+        if (b <= a) continue;
+        const int64_t i0 = a > lm ? C.d.nalm : d_packed_index(lm, a, a), i1 = b > lm ? C.d.nalm : d_packed_index(lm, b, b);
+        for (int j = 0; j < C.d.nmaps; ++j) rs.push_back({C.d.pos + (int64_t)j * C.d.nalm + i0, i1 - i0});
+    }
+    if (rs.empty()) return;
+    if (rccl_.ready()) {
+        if (rs.size() > 1) RcclComm::group_start();
+        for (const Rng& r : rs) rccl_.allreduce_sum(v + r.off, r.n, reinterpret_cast<void*>(st));
+        if (rs.size() > 1) RcclComm::group_end();
+        return;
+    }
+    for (const Rng& r : rs) allreduce_s_(allreduce_s_user_, v + r.off, r.n, reinterpret_cast<void*>(st));
+}
+
 // ------------------------------------------------------------------------------------------------- matvec
 void CrSystem::adjoint_groups_to_yc(bool from_maps) {
     const int ncomp = (int)comps_.size();
+    // Several ranks, stream-ordered collective, one unpolarised plan without mixing operators (the benchmark's layout):
+    // the adjoint runs as two launches over m < m_split | m >= m_split (equal work), and the sum over ranks of the first
+    // half's rows goes out on a second stream while the second half computes -- no host synchronisation, same sums in the
+    // same order as the one-piece form (bit-equal results).  CMDR_OVERLAP=0 keeps one launch + one all-reduce.
+    const bool overlap_env = [] { const char* e = std::getenv("CMDR_OVERLAP"); return !e || std::atoi(e) != 0; }();
+    if (overlap_env && (rccl_.ready() || allreduce_s_) && !band_sharded_ && groups_.size() == 1 && groups_[0].npol == 0 &&
+        groups_[0].mix.empty() && !groups_[0].ring_pending && compacts_.empty() && !group_has_compact(groups_[0])) {
+        Group& G = groups_[0];
+        ShtPlan& P = *G.plan;
+        const int ms = P.m_split();
+        if (!ev_half_) {
+            CMDR_HIP_CHECK(hipEventCreateWithFlags(&ev_half_, hipEventDisableTiming));
+            CMDR_HIP_CHECK(hipEventCreateWithFlags(&ev_comm_, hipEventDisableTiming));
+        }
+        span_begin(2);
+        for (int half = 0; half < 2; ++half) {
+            P.adjoint_half_to_partials(G.nT, half, stream_);
+            launch_band_post(comps_dev_.get(), ncomp, lmax_max_, P.partials(), P.part_map_stride(), P.leg().tri_elems(),
+                             P.leg().nchunk, G.nT, G.bm_stokes_dev.get(), G.w.get(), P.leg().cnorm.get(), G.lmax, yc_.get(),
+                             false, stream_, P.leg().lw_chunk.get(), half == 0 ? 0 : ms, half == 0 ? ms : -1);
+            if (half == 0) {
+                CMDR_HIP_CHECK(hipEventRecord(ev_half_, stream_));
+                CMDR_HIP_CHECK(hipStreamWaitEvent(stream_comm_, ev_half_, 0));
+                reduce_rows(yc_.get(), 0, ms, stream_comm_);
+                CMDR_HIP_CHECK(hipEventRecord(ev_comm_, stream_comm_));
+            } else {
+                reduce_rows(yc_.get(), ms, lmax_max_ + 1, stream_);
+                CMDR_HIP_CHECK(hipStreamWaitEvent(stream_, ev_comm_, 0));
+            }
+        }
+        span_end();
+        return;
+    }
     for (int g = 0; g < (int)groups_.size(); ++g) {
         Group& G = groups_[g];
         ShtPlan& P = *G.plan;
@@ -1812,7 +1871,55 @@ SolveResult CrSystem::solve(const double* b, double* x, int crit, double tol, in
         launch_sqrtS(comps_dev_.get(), ncomp, lmax_max_, smat_.get(), 0, d_.get(), nullptr, sx_.get(), false, stream_);
         sx_ready = true;
     }
+    auto fused_iter = [&](int it) {                                                     // one iteration, :253-272
+        matmulA_impl(d_.get(), nullptr, sx_ready, false);                               // :253, up to the reduced yc_
+        launch_cg_q(comps_dev_.get(), ncomp, lmax_max_, smat_.get(), yc_.get(), d_.get(), q_.get(), p_dq, stream_);
+        launch_cg_xr_precond(comps_dev_.get(), ncomp, lmax_max_, P_.get(), nmaps_pre_, p_dq, p_rs[(it - 1) & 1],
+                             p_rs[it & 1], x, r_.get(), d_.get(), q_.get(), s_.get(), scal, stream_);   // :254-269
+        launch_cg_d_sqrtS(comps_dev_.get(), ncomp, lmax_max_, smat_.get(), p_rs[(it - 1) & 1], p_rs[it & 1], d_.get(),
+                          s_.get(), sx_.get(), scal, stream_);                          // :270-272 + head of the next A d
+        sx_ready = true;
+    };
     int i = 1;
+#if !defined(CMDR_EMUL)
+    // fixed_iter: no host decision inside the loop, and two consecutive iterations form a fixed launch sequence (the r.s
+    // partial buffers alternate by parity) -> iterations 3.. are replays of ONE captured hipGraph of two iterations.  The
+    // kernels of small problems (BASELINE configs[1], ring-sharded ranks) are shorter than the host's launch path; the
+    // graph removes that path from the loop.  Not with a collective in the matvec (host callbacks cannot be captured,
+    // RCCL inside a capture is left for when it can be tested with more than one rank), not while profiling (the event
+    // spans are host objects).  CMDR_CG_GRAPH=0 disables; any capture error falls back to eager launches.
+    const bool graph_env = [] { const char* e = std::getenv("CMDR_CG_GRAPH"); return !e || std::atoi(e) != 0; }();
+    if (graph_env && fused && fixed_iter && !profile_ && !allreduce_ && !allreduce_s_ && !rccl_.ready() && maxiter >= 6) {
+        fused_iter(1);                       // eager: lazily sized workspaces, kernel attributes, sx_ready
+        fused_iter(2);
+        R.niter = 2;
+        i = 3;
+        hipGraph_t graph = nullptr;
+        hipGraphExec_t exec = nullptr;
+        bool captured = false;
+        if (hipStreamBeginCapture(stream_, hipStreamCaptureModeThreadLocal) == hipSuccess) {
+            bool ok = true;
+            try {
+                fused_iter(3);
+                fused_iter(4);
+            } catch (...) {
+                ok = false;
+            }
+            const hipError_t rc = hipStreamEndCapture(stream_, &graph);
+            if (ok && rc == hipSuccess && graph && hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0) == hipSuccess)
+                captured = true;
+        }
+        (void)hipGetLastError();             // a refused capture leaves a sticky error code behind
+        if (captured) {
+            for (; i + 1 <= maxiter; i += 2) {
+                CMDR_HIP_CHECK(hipGraphLaunch(exec, stream_));
+                R.niter = i + 1;
+            }
+        }
+        if (exec) (void)hipGraphExecDestroy(exec);
+        if (graph) (void)hipGraphDestroy(graph);
+    }
+#endif
     for (; i <= maxiter; ++i) {                                                         // :230
         if (i % check_freq == 0 && !fixed_iter) {                                       // :236-247
             fetch();
@@ -1826,13 +1933,7 @@ SolveResult CrSystem::solve(const double* b, double* x, int crit, double tol, in
             if (val < lim && (i >= miniter || h[0] <= 1e-30 * h[3])) break;
         }
         if (fused) {
-            matmulA_impl(d_.get(), nullptr, sx_ready, false);                           // :253, up to the reduced yc_
-            launch_cg_q(comps_dev_.get(), ncomp, lmax_max_, smat_.get(), yc_.get(), d_.get(), q_.get(), p_dq, stream_);
-            launch_cg_xr_precond(comps_dev_.get(), ncomp, lmax_max_, P_.get(), nmaps_pre_, p_dq, p_rs[(i - 1) & 1],
-                                 p_rs[i & 1], x, r_.get(), d_.get(), q_.get(), s_.get(), scal, stream_);   // :254-269
-            launch_cg_d_sqrtS(comps_dev_.get(), ncomp, lmax_max_, smat_.get(), p_rs[(i - 1) & 1], p_rs[i & 1], d_.get(),
-                              s_.get(), sx_.get(), scal, stream_);                      // :270-272 + head of the next A d
-            sx_ready = true;
+            fused_iter(i);
             R.niter = i;
             continue;
         }

@@ -254,6 +254,9 @@ class CrSystem {
     double prof_ms_[kProfKinds] = {0, 0, 0, 0, 0, 0, 0, 0};
     long long prof_n_[kProfKinds] = {0, 0, 0, 0, 0, 0, 0, 0};
     void reduce(double* v, int64_t n);         // over all ranks
+    void reduce_rows(double* v, int m0, int m1, hipStream_t st);   // rows m0 <= m < m1 of every diffuse block, on stream st
+    hipStream_t stream_comm_ = nullptr;        // the first half's all-reduce runs here beside the second half's adjoint
+    hipEvent_t ev_half_ = nullptr, ev_comm_ = nullptr;
     void reduce_rings(double* v, int64_t n);   // over the ranks holding the same bands (== reduce without band sharding)
 
     hipStream_t stream_ = nullptr;

@@ -63,7 +63,7 @@ void launch_band_prep(const CompDev* comps, int ncomp, const double* sx, const d
                       const double* extra = nullptr);
 void launch_band_post(const CompDev* comps, int ncomp, int lmax_max, const double* part, int64_t pms, int64_t pcs,
                       int nchunk, int nbm, const int* bm_stokes, const double* w, const double* cnorm, int lmax_g,
-                      double* yc, bool accumulate, hipStream_t s, const int* lwtab = nullptr);
+                      double* yc, bool accumulate, hipStream_t s, const int* lwtab = nullptr, int m0 = 0, int m1 = -1);
 void launch_band_prep2(const CompDev* comps, int ncomp, const double* sx, const double* w, int nT, double* st, int npol,
                        const double* cnorm2, int lmax_g, hipStream_t s, const double* extra = nullptr);
 void launch_band_post2(const CompDev* comps, int ncomp, int lmax_max, const double* part2, int64_t pps, int64_t pcs,

@@ -203,6 +203,20 @@ void LegendreTables::build(int lmax_, const std::vector<double>& x_, const std::
     std::stable_sort(tasks.begin(), tasks.end(), [](const WaveTask& a, const WaveTask& b) { return a.lw < b.lw; });
     while (tasks.size() % 4) { WaveTask t; t.m = 0; t.chunk = -1; t.lw = lmax + 1; t.lAend = lmax + 1; tasks.push_back(t); }
     group = 4;
+    {   // two halves of equal work by m (work of a task ~ its l range)
+        double tot = 0.0, acc = 0.0;
+        std::vector<double> wm(nm, 0.0);
+        for (const WaveTask& t : tasks) if (t.chunk >= 0) { wm[t.m] += (double)std::max(0, lmax + 1 - t.lw); tot += (double)std::max(0, lmax + 1 - t.lw); }
+        m_split = nm;
+        for (int m = 0; m < nm; ++m) { acc += wm[m]; if (acc >= 0.5 * tot) { m_split = m + 1; break; } }
+        tasks_split.clear();
+        for (int half = 0; half < 2; ++half) {
+            for (const WaveTask& t : tasks)          // `tasks` is already sorted longest first
+                if (t.chunk >= 0 && (half == 0 ? t.m < m_split : t.m >= m_split)) tasks_split.push_back(t);
+            while (tasks_split.size() % 4) { WaveTask t; t.m = 0; t.chunk = -1; t.lw = lmax + 1; t.lAend = lmax + 1; tasks_split.push_back(t); }
+            if (half == 0) nsplit_lo = (int)tasks_split.size();
+        }
+    }
     if (std::getenv("CMDR_DEBUG_PLAN")) {
         double slots = 0, slotsA = 0, steps = 0;
         for (const WaveTask& t : tasks) if (t.chunk >= 0) { slots += (double)(lmax - t.lw + 1) * kWave * R; slotsA += (double)(std::min(t.lAend, lmax + 1) - t.lw) * kWave * R; }

@@ -36,6 +36,10 @@ struct LegendreTables {
     // adjoint kernel: R pairs per lane, one task per wavefront, 4 per workgroup, longest first
     std::vector<WaveTask> tasks;
     std::vector<int> lw_chunk;           // [(lmax+1) * nchunk] first l the adjoint writes for (m, chunk); lmax+2: nothing
+    // the same adjoint tasks as two lists, m < m_split | m >= m_split (each longest first, padded to a multiple of 4),
+    // of about equal work: the first half's output can be summed over the ranks while the second half computes
+    std::vector<WaveTask> tasks_split;
+    int m_split = 0, nsplit_lo = 0;      // tasks_split[0 .. nsplit_lo) = the m < m_split part
     int group = 4;
     bool synth_wg = false;               // tasks_s grouped: tasks_s[4i .. 4i+3] = 4 chunks of one m (chunk = -1: none)
     // synthesis kernel: Rs pairs per lane, same layout (its own list so R and Rs can be tuned independently)

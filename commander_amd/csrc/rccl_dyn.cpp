@@ -30,6 +30,8 @@ struct Api {
     int (*CommUserRank)(void*, int*) = nullptr;
     int (*AllReduce)(const void*, void*, size_t, int, int, void*, void*) = nullptr;
     const char* (*GetErrorString)(int) = nullptr;
+    int (*GroupStart)() = nullptr;
+    int (*GroupEnd)() = nullptr;
     std::string err;
 };
 
@@ -66,6 +68,8 @@ Api& api() {
         A.CommUserRank = (decltype(A.CommUserRank))sym("ncclCommUserRank");
         A.AllReduce = (decltype(A.AllReduce))sym("ncclAllReduce");
         A.GetErrorString = (decltype(A.GetErrorString))sym("ncclGetErrorString");
+        A.GroupStart = (decltype(A.GroupStart))sym("ncclGroupStart");
+        A.GroupEnd = (decltype(A.GroupEnd))sym("ncclGroupEnd");
     });
     if (!A.err.empty()) throw Error("RCCL unavailable: " + A.err);
     return A;
@@ -79,6 +83,9 @@ void check(int rc, const char* what) {
 }
 
 }  // namespace
+
+void RcclComm::group_start() { check(api().GroupStart(), "ncclGroupStart"); }
+void RcclComm::group_end() { check(api().GroupEnd(), "ncclGroupEnd"); }
 
 int RcclComm::version() {
     int v = 0;

@@ -25,6 +25,8 @@ class RcclComm {
     int rank() const;                                                    // ncclCommUserRank
     void allreduce_sum(double* dev, int64_t n, void* hip_stream) const;  // in place, enqueued on hip_stream
     static int version();                                                // ncclGetVersion
+    static void group_start();                                           // ncclGroupStart / ncclGroupEnd: several
+    static void group_end();                                             // all-reduces of one stream as one operation
   private:
     void* comm_ = nullptr;
 };

@@ -21,6 +21,10 @@ void LegendreDev::upload(const LegendreTables& T) {
     cnorm.upload(T.cnorm);
     tasks.upload(T.tasks);
     lw_chunk.upload(T.lw_chunk);
+    tasks_split.upload(T.tasks_split);
+    m_split = T.m_split;
+    nsplit_lo = T.nsplit_lo;
+    nsplit = (int)T.tasks_split.size();
 }
 
 LegArgs LegendreDev::args() const {
@@ -204,6 +208,13 @@ void ShtPlan::adjoint_range(int k0, int n, hipStream_t s) {
 void ShtPlan::adjoint_to_partials(int nmaps, bool square, hipStream_t s, const std::function<void(int)>& between) {
     launch_leg_adj(leg_.args(), leg_.tasks.get(), leg_.ntasks, ph_.get(), leg_.ph_elems(), part_.get(),
                    part_map_stride(), leg_.tri_elems(), nmaps, square, s, between);
+}
+
+void ShtPlan::adjoint_half_to_partials(int nmaps, int half, hipStream_t s) {
+    const WaveTask* t = leg_.tasks_split.get() + (half == 0 ? 0 : leg_.nsplit_lo);
+    const int n = half == 0 ? leg_.nsplit_lo : leg_.nsplit - leg_.nsplit_lo;
+    launch_leg_adj(leg_.args(), t, n, ph_.get(), leg_.ph_elems(), part_.get(), part_map_stride(), leg_.tri_elems(), nmaps,
+                   false, s, nullptr);
 }
 
 void ShtPlan::alm2map(const double* d_alm, int64_t alm_stride, double* d_map, int64_t map_stride, int nmaps,

@@ -22,7 +22,8 @@ class LegendreDev {  // device mirror of LegendreTables
     bool uniform_start = false;
     DevBuf<double> x, seedc, seedp, alpha, cnorm;
     DevBuf<int> ls, lw_chunk;
-    DevBuf<WaveTask> tasks, tasks_s;
+    DevBuf<WaveTask> tasks, tasks_s, tasks_split;
+    int m_split = 0, nsplit_lo = 0, nsplit = 0;
     int64_t ph_elems() const { return (int64_t)(lmax + 1) * npair_pad * 4; }       // doubles per map
     int64_t tri_elems() const { return 2 * ntrip(lmax); }                          // doubles per map
 };
@@ -101,6 +102,9 @@ class ShtPlan {
     void synth_range(int k0, int n, int nbs, hipStream_t s);
     void rings_fused_range(int k0, int n, const double* const* d_mul, hipStream_t s);
     void adjoint_range(int k0, int n, hipStream_t s);
+    // the scalar adjoint of the columns m < m_split() (half 0) or m >= m_split() (half 1) only
+    void adjoint_half_to_partials(int nmaps, int half, hipStream_t s);
+    int m_split() const { return leg_.m_split; }
     const LegendreDev& leg() const { return leg_; }
 
   private:

@@ -300,8 +300,9 @@ void launch_pinv_prior(const CompDev* comps, int ncomp, int, const double* Q, in
 }
 void launch_band_post(const CompDev* comps, int ncomp, int lmax_max, const double* part, int64_t pms, int64_t pcs,
                       int nchunk, int nbm, const int* bm_stokes, const double* w, const double* cnorm, int lmax_g,
-                      double* yc, bool accumulate, hipStream_t, const int* lwtab) {
-    for (int m = 0; m <= lmax_max; ++m)
+                      double* yc, bool accumulate, hipStream_t, const int* lwtab, int m0, int m1) {
+    if (m1 < 0 || m1 > lmax_max + 1) m1 = lmax_max + 1;
+    for (int m = m0; m < m1; ++m)
         for (int l = m; l <= lmax_max; ++l)
             band_post_elem(comps, ncomp, part, pms, pcs, nchunk, nbm, bm_stokes, w, cnorm, lmax_g, yc, accumulate ? 1 : 0, m, l,
                            m <= lmax_g ? lwtab : nullptr);

@@ -183,6 +183,30 @@ def test_spin2_adjoint_kernel_forms_gpu(nband, monkeypatch):
     assert np.array_equal(ctx.cr_matmulA(x), got_def)                                  # deterministic
 
 
+@pytest.mark.parametrize("cfg,kw", [("cfg2", dict(nside=64, lmax=128)), ("cfg2", dict(nside=32, lmax=64, pol=True)),
+                                    ("cfg5", dict(nside=32, lmax=64, comp_lmax=[64, 48, 64, 40, 40]))])
+def test_fixed_iter_graph_replay_equals_eager_launches_gpu(cfg, kw, monkeypatch):
+    """fixed_iter solves replay iterations 3.. as one captured hipGraph of two PCG iterations (cr_system.cpp); the result
+    must be the eager loop's bit for bit -- even and odd iteration counts, T / T,Q,U / varying mixing -- and the oracle's."""
+    from commander_amd import synth
+    from commander_amd.cr import build_context
+    spec = synth.make_problem(cfg, **kw)
+    ctx = build_context(spec)
+    ctx.initPrecond(); ctx.update_precond()
+    resid, xi, eta = synth.draw_inputs(spec)
+    b = ctx.cr_computeRHS("sample", resid, xi, eta)
+    for nit in (11, 12):
+        monkeypatch.setenv("CMDR_CG_GRAPH", "0")
+        x0, n0, _, res0 = ctx.solve_cr_eqn_by_CG(b, "fixed_iter", 1e-8, 5, nit, 1)
+        monkeypatch.setenv("CMDR_CG_GRAPH", "1")
+        x1, n1, _, res1 = ctx.solve_cr_eqn_by_CG(b, "fixed_iter", 1e-8, 5, nit, 1)
+        assert n0 == n1 == nit and np.array_equal(x0, x1) and res0 == res1
+    S = oracle_system(spec)
+    S.init_precond_diag(); S.update_precond_diag()
+    xo, no, _ = S.solve(b, "fixed_iter", 1e-8, 5, 12, 1)
+    assert rel(x1, xo) < 1e-8
+
+
 def test_varying_mixing_and_pseudoinv_gpu():
     """BASELINE.json configs[4] shape at reduced size (Nside=32, lmax=64): five diffuse components, synchrotron and
     dust with spatially varying spectral indices (Y . F . YtW branch of evalDiffuseBand / projectDiffuseBand,

@@ -60,6 +60,12 @@ def _worker(rank, world, port, out_dir, mode):
     ctx.update_precond()
     x = np.random.default_rng(5).standard_normal(ctx.ncr)
     y = ctx.cr_matmulA(x)
+    if mode == "stream":
+        # the stream-ordered collective takes the two-half form (adjoint + row-range sums of m < m_split | m >= m_split,
+        # the first half's sum on the second stream): same sums in the same order as one launch + one all-reduce
+        os.environ["CMDR_OVERLAP"] = "0"
+        assert np.array_equal(ctx.cr_matmulA(x), y)
+        del os.environ["CMDR_OVERLAP"]
     resid, xi, eta = synth.draw_inputs(spec)
     b = ctx.cr_computeRHS("sample", resid, xi, eta)
     sol, n, stat, res = ctx.solve_cr_eqn_by_CG(b, "fixed_iter", 1e-8, 5, 12, 1)
