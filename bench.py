@@ -383,11 +383,13 @@ def other_config(cfg, preconds=("diagonal",), pol=None, sht=None, label=None):
         t_pre = time.perf_counter() - t_pre
         step()
         L.cmdr_device_synchronize()
-        L.cmdr_profile_enable(ctx._h, 1)
         t0 = time.perf_counter()
-        niter, stat, res = step()
+        niter, stat, res = step()            # the timed sample: no event spans (fixed_iter solves replay a hipGraph)
         L.cmdr_device_synchronize()
         dt = time.perf_counter() - t0
+        L.cmdr_profile_enable(ctx._h, 1)     # one more sample for the per-kernel breakdown
+        step()
+        L.cmdr_device_synchronize()
         ms = (ctypes.c_double * 8)()
         cnt = (ctypes.c_longlong * 8)()
         L.cmdr_profile_read_ext(ctx._h, 8, ms, cnt)

@@ -54,7 +54,8 @@ got = results(ctx)
 for a, b in zip(got, ref):
     assert np.array_equal(a, b), float(np.abs(a - b).max())
 if mode == "torch-stream":
-    assert calls and max(calls) == ctx.ncr
+    # the sums over ranks go out as row ranges of the stacked vector (two halves, the first on the second stream) or whole
+    assert calls and max(calls) <= ctx.ncr and sum(calls) >= ctx.ncr, (len(calls), max(calls), ctx.ncr)
     ctx.close()
     dist.destroy_process_group()
 print("RCCL_WORKER_OK", mode, flush=True)
