@@ -137,6 +137,10 @@ class CRContext:
         """Band x ring-set hybrid: communicator of the ranks holding the same bands (ncclCommSplit); collective."""
         check(self.L.cmdr_ctx_rccl_split_rings(self._h, int(band_group), int(ring_index), int(ring_replicas)), self.L)
 
+    def set_vector_slicing(self, rank, nranks):
+        """m-sliced CG vectors inside ``solve_cr_eqn_by_CG`` (include/cmdr_hip.h: cmdr_ctx_set_vector_slicing)."""
+        check(self.L.cmdr_ctx_set_vector_slicing(self._h, int(rank), int(nranks)), self.L)
+
     def drop_rccl(self):
         """Destroy the native communicators; the callback forms apply again."""
         check(self.L.cmdr_ctx_drop_rccl(self._h), self.L)

@@ -283,6 +283,12 @@ int cmdr_ctx_rccl_split_rings(cmdr_ctx* ctx, int band_group, int ring_index, int
         ctx->sys->rccl_split_rings(band_group, ring_index, ring_replicas);
     });
 }
+int cmdr_ctx_set_vector_slicing(cmdr_ctx* ctx, int rank, int nranks) {
+    return guarded([&] {
+        CMDR_REQUIRE(ctx, "ctx is NULL");
+        ctx->sys->set_vector_slicing(rank, nranks);
+    });
+}
 int cmdr_ctx_drop_rccl(cmdr_ctx* ctx) {
     return guarded([&] {
         CMDR_REQUIRE(ctx, "ctx is NULL");

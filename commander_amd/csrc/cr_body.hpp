@@ -416,12 +416,17 @@ CMDR_HD double cg_sqrtS1(const CompDev& C, const double* __restrict__ smat, int 
     s += smat[C.smat_off + l] * v;
     return s;
 }
+// ilo <= index < ihi: the slice of the stacked vector this rank owns (m-sliced CG vectors; default: everything).  One
+// component with one map: S^1/2 and M^-1 are scalars per l, so the (re, im) slots of an (l, m) are independent and a
+// slice may be any contiguous index range.
 CMDR_HD double cg_q_elem1(const CompDev& C, const double* __restrict__ smat, const double* __restrict__ yc,
-                          const double* __restrict__ d, double* __restrict__ q, int m, int l) {
+                          const double* __restrict__ d, double* __restrict__ q, int m, int l,
+                          int64_t ilo = 0, int64_t ihi = INT64_MAX) {
     const int64_t i0 = C.pos + d_packed_index(C.lmax, l, m);
     const bool addon = C.active && C.lmax_cl >= 0;
     double acc = 0.0;
     for (int sl = 0; sl < (m > 0 ? 2 : 1); ++sl) {
+        if (i0 + sl < ilo || i0 + sl >= ihi) continue;
         const double dv = d[i0 + sl];
         const double o = cg_sqrtS1(C, smat, l, yc[i0 + sl]) + (addon ? dv : 0.0);
         q[i0 + sl] = o;
@@ -431,12 +436,14 @@ CMDR_HD double cg_q_elem1(const CompDev& C, const double* __restrict__ smat, con
 }
 CMDR_HD double cg_xr_elem1(const CompDev& C, const double* __restrict__ P, int lmax_pre, double alpha,
                            double* __restrict__ x, double* __restrict__ r, const double* __restrict__ d,
-                           const double* __restrict__ q, double* __restrict__ s, int m, int l) {
+                           const double* __restrict__ q, double* __restrict__ s, int m, int l,
+                           int64_t ilo = 0, int64_t ihi = INT64_MAX) {
     const int64_t i0 = C.pos + d_packed_index(C.lmax, l, m);
     const double p = P[d_moff(lmax_pre, m) + (l - m)];
     double acc = 0.0;
     for (int sl = 0; sl < (m > 0 ? 2 : 1); ++sl) {
         const int64_t i = i0 + sl;
+        if (i < ilo || i >= ihi) continue;
         x[i] += alpha * d[i];
         double rn = r[i];
         rn -= alpha * q[i];
@@ -449,9 +456,11 @@ CMDR_HD double cg_xr_elem1(const CompDev& C, const double* __restrict__ P, int l
     return acc;
 }
 CMDR_HD void cg_d_elem1(const CompDev& C, const double* __restrict__ smat, double beta, double* __restrict__ d,
-                        const double* __restrict__ s, double* __restrict__ sx, int m, int l) {
+                        const double* __restrict__ s, double* __restrict__ sx, int m, int l,
+                        int64_t ilo = 0, int64_t ihi = INT64_MAX) {
     const int64_t i0 = C.pos + d_packed_index(C.lmax, l, m);
     for (int sl = 0; sl < (m > 0 ? 2 : 1); ++sl) {
+        if (i0 + sl < ilo || i0 + sl >= ihi) continue;
         const double dn = s[i0 + sl] + beta * d[i0 + sl];
         d[i0 + sl] = dn;
         sx[i0 + sl] = cg_sqrtS1(C, smat, l, dn);

@@ -292,11 +292,11 @@ __device__ inline void cg_stride(int lmax, F f) {
 __global__ void __launch_bounds__(256) k_cg_q(const CompDev* __restrict__ comps, int ncomp, int lmax,
                                               const double* __restrict__ smat, const double* __restrict__ yc,
                                               const double* __restrict__ d, double* __restrict__ q,
-                                              double* __restrict__ p_dq) {
+                                              double* __restrict__ p_dq, int64_t ilo, int64_t ihi) {
     double acc = 0.0;
     if (cg_single(comps, ncomp)) {
         const CompDev C = comps[0];
-        cg_stride(lmax, [&](int m, int l) { acc += cg_q_elem1(C, smat, yc, d, q, m, l); });
+        cg_stride(lmax, [&](int m, int l) { acc += cg_q_elem1(C, smat, yc, d, q, m, l, ilo, ihi); });
     } else {
         cg_stride(lmax, [&](int m, int l) { acc += cg_q_elem(comps, ncomp, smat, yc, d, q, m, l); });
     }
@@ -309,14 +309,14 @@ __global__ void __launch_bounds__(256) k_cg_xr_precond(const CompDev* __restrict
                                                        const double* __restrict__ p_rs_old, double* __restrict__ p_rs,
                                                        double* __restrict__ x, double* r, const double* __restrict__ d,
                                                        const double* __restrict__ q, double* s,
-                                                       double* __restrict__ scal) {
+                                                       double* __restrict__ scal, int64_t ilo, int64_t ihi) {
     const double dq = fold_partials(p_dq);
     const double alpha = fold_partials(p_rs_old) / dq;                                  // comm_cr_mod.f90:254
     if (blockIdx.x == 0 && threadIdx.x == 0) scal[2] = dq;
     double acc = 0.0;
     if (cg_single(comps, ncomp) && nmaps_pre == 1) {
         const CompDev C = comps[0];
-        cg_stride(lmax, [&](int m, int l) { acc += cg_xr_elem1(C, P, lmax, alpha, x, r, d, q, s, m, l); });
+        cg_stride(lmax, [&](int m, int l) { acc += cg_xr_elem1(C, P, lmax, alpha, x, r, d, q, s, m, l, ilo, ihi); });
     } else {
         cg_stride(lmax, [&](int m, int l) { acc += cg_xr_elem(comps, ncomp, P, lmax, nmaps_pre, alpha, x, r, d, q, s, m, l); });
     }
@@ -328,13 +328,13 @@ __global__ void __launch_bounds__(256) k_cg_d_sqrtS(const CompDev* __restrict__ 
                                                     const double* __restrict__ p_rs_old,
                                                     const double* __restrict__ p_rs, double* d,
                                                     const double* __restrict__ s, double* __restrict__ sx,
-                                                    double* __restrict__ scal) {
+                                                    double* __restrict__ scal, int64_t ilo, int64_t ihi) {
     const double dold = fold_partials(p_rs_old), dnew = fold_partials(p_rs);
     const double beta = dnew / dold;                                                    // :270-271
     if (blockIdx.x == 0 && threadIdx.x == 0) { scal[0] = dnew; scal[1] = dold; }
     if (cg_single(comps, ncomp)) {
         const CompDev C = comps[0];
-        cg_stride(lmax, [&](int m, int l) { cg_d_elem1(C, smat, beta, d, s, sx, m, l); });
+        cg_stride(lmax, [&](int m, int l) { cg_d_elem1(C, smat, beta, d, s, sx, m, l, ilo, ihi); });
     } else {
         cg_stride(lmax, [&](int m, int l) { cg_d_elem(comps, ncomp, smat, beta, d, s, sx, m, l); });
     }
@@ -348,19 +348,20 @@ void launch_cg_seed(const double* scal, int slot, double* p, hipStream_t s) {
     hipLaunchKernelGGL(k_cg_seed, dim3(kDotBlocks / 256), dim3(256), 0, s, scal, slot, p);
 }
 void launch_cg_q(const CompDev* comps, int ncomp, int lmax, const double* smat, const double* yc, const double* d,
-                 double* q, double* p_dq, hipStream_t s) {
-    hipLaunchKernelGGL(k_cg_q, dim3(kDotBlocks), dim3(256), 0, s, comps, ncomp, lmax, smat, yc, d, q, p_dq);
+                 double* q, double* p_dq, hipStream_t s, int64_t ilo, int64_t ihi) {
+    hipLaunchKernelGGL(k_cg_q, dim3(kDotBlocks), dim3(256), 0, s, comps, ncomp, lmax, smat, yc, d, q, p_dq, ilo, ihi);
 }
 void launch_cg_xr_precond(const CompDev* comps, int ncomp, int lmax, const double* P, int nmaps_pre, const double* p_dq,
                           const double* p_rs_old, double* p_rs, double* x, double* r, const double* d, const double* q,
-                          double* sv, double* scal, hipStream_t s) {
+                          double* sv, double* scal, hipStream_t s, int64_t ilo, int64_t ihi) {
     hipLaunchKernelGGL(k_cg_xr_precond, dim3(kDotBlocks), dim3(256), 0, s, comps, ncomp, lmax, P, nmaps_pre, p_dq,
-                       p_rs_old, p_rs, x, r, d, q, sv, scal);
+                       p_rs_old, p_rs, x, r, d, q, sv, scal, ilo, ihi);
 }
 void launch_cg_d_sqrtS(const CompDev* comps, int ncomp, int lmax, const double* smat, const double* p_rs_old,
-                       const double* p_rs, double* d, const double* sv, double* sx, double* scal, hipStream_t s) {
+                       const double* p_rs, double* d, const double* sv, double* sx, double* scal, hipStream_t s,
+                       int64_t ilo, int64_t ihi) {
     hipLaunchKernelGGL(k_cg_d_sqrtS, dim3(kDotBlocks), dim3(256), 0, s, comps, ncomp, lmax, smat, p_rs_old, p_rs, d, sv, sx,
-                       scal);
+                       scal, ilo, ihi);
 }
 
 // x += alpha d ; r -= alpha q ; alpha = scal[num] / scal[den]   (comm_cr_mod.f90:254-261)

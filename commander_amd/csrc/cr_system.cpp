@@ -797,6 +797,32 @@ void CrSystem::reduce(double* v, int64_t n) {
     allreduce_(allreduce_user_, v, n);
 }
 
+void CrSystem::set_vector_slicing(int rank, int nranks) {
+    CMDR_REQUIRE(nranks <= 1 || (rank >= 0 && rank < nranks), "bad rank / nranks");
+    slice_rank_ = rank;
+    slice_n_ = nranks > 1 ? nranks : 0;
+    // test hook: a communicator of ONE rank still goes through ncclReduceScatter / ncclAllGather (tests/test_rccl_gpu.py)
+    if (nranks == 1 && std::getenv("CMDR_SLICE_FORCE")) slice_n_ = 1;
+}
+
+// Reduce-scatter / all-gather of a padded stacked vector (slice_n_ chunks of slice_count() doubles), in place, on the
+// library stream.  Native RCCL: ncclReduceScatter / ncclAllGather.  Callback drivers (MPI, the gloo tests) only have an
+// all-reduce: the same result through it (reduce-scatter = all-reduce; all-gather = all-reduce of the vector with the
+// chunks of the other ranks zeroed) -- correct, without the traffic saving.
+void CrSystem::slice_reduce_scatter(double* v) {
+    const int64_t c = slice_count();
+    if (rccl_.ready()) { rccl_.reduce_scatter_sum(v, c, reinterpret_cast<void*>(stream_)); return; }
+    reduce(v, c * slice_n_);
+}
+void CrSystem::slice_all_gather(double* v) {
+    const int64_t c = slice_count();
+    if (rccl_.ready()) { rccl_.all_gather(v, c, reinterpret_cast<void*>(stream_)); return; }
+    if (slice_rank_ > 0) CMDR_HIP_CHECK(hipMemsetAsync(v, 0, sizeof(double) * c * slice_rank_, stream_));
+    if (slice_rank_ + 1 < slice_n_)
+        CMDR_HIP_CHECK(hipMemsetAsync(v + c * (slice_rank_ + 1), 0, sizeof(double) * c * (slice_n_ - slice_rank_ - 1), stream_));
+    reduce(v, c * slice_n_);
+}
+
 // Sum over ranks of the rows m0 <= m < m1 of every diffuse block of a stacked vector, stream-ordered on `st` (native RCCL
 // or the stream callback; one group call for all blocks).
 void CrSystem::reduce_rows(double* v, int m0, int m1, hipStream_t st) {
@@ -827,6 +853,18 @@ void CrSystem::adjoint_groups_to_yc(bool from_maps) {
     // half's rows goes out on a second stream while the second half computes -- no host synchronisation, same sums in the
     // same order as the one-piece form (bit-equal results).  CMDR_OVERLAP=0 keeps one launch + one all-reduce.
     const bool overlap_env = [] { const char* e = std::getenv("CMDR_OVERLAP"); return !e || std::atoi(e) != 0; }();
+    if (slice_active_) {   // sliced PCG loop (one unpolarised plan): every rank needs only its chunk of the sum
+        Group& G = groups_[0];
+        ShtPlan& P = *G.plan;
+        span_begin(2);
+        P.adjoint_to_partials(G.nT, false, stream_, nullptr);
+        span_end();
+        launch_band_post(comps_dev_.get(), ncomp, lmax_max_, P.partials(), P.part_map_stride(), P.leg().tri_elems(),
+                         P.leg().nchunk, G.nT, G.bm_stokes_dev.get(), G.w.get(), P.leg().cnorm.get(), G.lmax, yc_.get(), false,
+                         stream_, P.leg().lw_chunk.get());
+        slice_reduce_scatter(yc_.get());
+        return;
+    }
     if (overlap_env && (rccl_.ready() || allreduce_s_) && !band_sharded_ && groups_.size() == 1 && groups_[0].npol == 0 &&
         groups_[0].mix.empty() && !groups_[0].ring_pending && compacts_.empty() && !group_has_compact(groups_[0])) {
         Group& G = groups_[0];
@@ -1871,7 +1909,42 @@ SolveResult CrSystem::solve(const double* b, double* x, int crit, double tol, in
         launch_sqrtS(comps_dev_.get(), ncomp, lmax_max_, smat_.get(), 0, d_.get(), nullptr, sx_.get(), false, stream_);
         sx_ready = true;
     }
+    // m-sliced vectors (set_vector_slicing): this rank's index range of the stacked vector
+    const bool sliced = fused && slice_n_ >= 1 && !by_chisq && (rccl_.ready() || allreduce_s_ || allreduce_) &&
+                        !band_sharded_ && ncomp == 1 && comps_[0].d.nmaps == 1 && nmaps_pre_ == 1 && groups_.size() == 1 &&
+                        groups_[0].npol == 0 && groups_[0].mix.empty() && !pipeline_;
+    const int64_t sc = sliced ? slice_count() : 0;
+    const int64_t ilo = sliced ? sc * slice_rank_ : 0, ihi = sliced ? std::min<int64_t>(n, sc * (slice_rank_ + 1)) : INT64_MAX;
+    if (sliced) {
+        const size_t pad = (size_t)(sc * slice_n_);
+        if (yc_.size() < pad || sx_.size() < pad || q_.size() < pad) {
+            sync();
+            // keep what the loop reads from the old buffers: S^1/2 d in sx_ (written just above)
+            DevBuf<double> nsx(pad);
+            CMDR_HIP_CHECK(hipMemcpy(nsx.get(), sx_.get(), sizeof(double) * n, hipMemcpyDeviceToDevice));
+            sx_ = std::move(nsx);
+            yc_.alloc(pad);
+            q_.alloc(pad);
+        }
+        CMDR_HIP_CHECK(hipMemsetAsync(yc_.get() + n, 0, sizeof(double) * (pad - n), stream_));
+        CMDR_HIP_CHECK(hipMemsetAsync(sx_.get() + n, 0, sizeof(double) * (pad - n), stream_));
+    }
     auto fused_iter = [&](int it) {                                                     // one iteration, :253-272
+        if (sliced) {
+            slice_active_ = true;
+            try { matmulA_impl(d_.get(), nullptr, sx_ready, false); } catch (...) { slice_active_ = false; throw; }
+            slice_active_ = false;                                                      // yc_[ilo, ihi) = this rank's sums
+            launch_cg_q(comps_dev_.get(), ncomp, lmax_max_, smat_.get(), yc_.get(), d_.get(), q_.get(), p_dq, stream_, ilo, ihi);
+            reduce(p_dq, npart);                                                        // d.q: block partials over the ranks
+            launch_cg_xr_precond(comps_dev_.get(), ncomp, lmax_max_, P_.get(), nmaps_pre_, p_dq, p_rs[(it - 1) & 1],
+                                 p_rs[it & 1], x, r_.get(), d_.get(), q_.get(), s_.get(), scal, stream_, ilo, ihi);
+            reduce(p_rs[it & 1], npart);                                                // r.s
+            launch_cg_d_sqrtS(comps_dev_.get(), ncomp, lmax_max_, smat_.get(), p_rs[(it - 1) & 1], p_rs[it & 1], d_.get(),
+                              s_.get(), sx_.get(), scal, stream_, ilo, ihi);
+            slice_all_gather(sx_.get());                                                // S^1/2 d for the next synthesis
+            sx_ready = true;
+            return;
+        }
         matmulA_impl(d_.get(), nullptr, sx_ready, false);                               // :253, up to the reduced yc_
         launch_cg_q(comps_dev_.get(), ncomp, lmax_max_, smat_.get(), yc_.get(), d_.get(), q_.get(), p_dq, stream_);
         launch_cg_xr_precond(comps_dev_.get(), ncomp, lmax_max_, P_.get(), nmaps_pre_, p_dq, p_rs[(it - 1) & 1],
@@ -1944,6 +2017,13 @@ SolveResult CrSystem::solve(const double* b, double* x, int crit, double tol, in
         launch_dot(r_.get(), s_.get(), n, dot_partial_.get(), scal, 0, true, stream_);  // :269-270
         launch_cg_d(d_.get(), s_.get(), n, scal, 0, 1, stream_);                        // :271-272
         R.niter = i;
+    }
+    if (sliced) {   // every rank holds its own index range of x: gather the rest (q_ is free now and padded)
+        CMDR_HIP_CHECK(hipMemcpyAsync(q_.get() + ilo, x + ilo, sizeof(double) * (ihi - ilo), hipMemcpyDeviceToDevice, stream_));
+        if (ihi < sc * (slice_rank_ + 1))
+            CMDR_HIP_CHECK(hipMemsetAsync(q_.get() + ihi, 0, sizeof(double) * (sc * (slice_rank_ + 1) - ihi), stream_));
+        slice_all_gather(q_.get());
+        CMDR_HIP_CHECK(hipMemcpyAsync(x, q_.get(), sizeof(double) * n, hipMemcpyDeviceToDevice, stream_));
     }
     // x <- S^1/2 x  (:350-389)
     launch_sqrtS(comps_dev_.get(), ncomp, lmax_max_, smat_.get(), 0, x, nullptr, tmp_.get(), true, stream_);

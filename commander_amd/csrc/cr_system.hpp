@@ -95,6 +95,13 @@ class CrSystem {
     void rccl_split_rings(int band_group, int ring_index, int ring_replicas);
     int rccl_size() const { return rccl_.ready() ? rccl_.size() : 0; }
     void drop_rccl();
+    // m-sliced CG vectors (ownership comm_map_mod.f90:228-261, mpi_dot_product comm_utils.f90:599-614):
+    // inside a fused fixed/residual PCG loop rank `rank` of `nranks` keeps only the index range
+    // [rank c, (rank + 1) c), c = ceil(ncr / nranks), of x, r, d, q, s: the matvec output is reduce-scattered instead of
+    // all-reduced, the three vector kernels run on the slice, S^1/2 d is all-gathered for the next synthesis, and each dot
+    // product sums its block partials over the ranks (8 KB).  One diffuse component with one map under the diagonal
+    // preconditioner (the (re, im) slots are then independent); anything else keeps replicated vectors.  nranks <= 1: off.
+    void set_vector_slicing(int rank, int nranks);
 
     int64_t ncr() const { return ncr_; }
     int nband() const { return (int)bands_.size(); }
@@ -255,6 +262,11 @@ class CrSystem {
     long long prof_n_[kProfKinds] = {0, 0, 0, 0, 0, 0, 0, 0};
     void reduce(double* v, int64_t n);         // over all ranks
     void reduce_rows(double* v, int m0, int m1, hipStream_t st);   // rows m0 <= m < m1 of every diffuse block, on stream st
+    int slice_rank_ = 0, slice_n_ = 0;         // set_vector_slicing
+    bool slice_active_ = false;                // inside a sliced PCG loop: adjoint_groups_to_yc reduce-scatters yc_
+    int64_t slice_count() const { return (ncr_ + slice_n_ - 1) / slice_n_; }
+    void slice_reduce_scatter(double* v);      // padded buffers of slice_n_ * slice_count() doubles, in place
+    void slice_all_gather(double* v);
     hipStream_t stream_comm_ = nullptr;        // the first half's all-reduce runs here beside the second half's adjoint
     hipEvent_t ev_half_ = nullptr, ev_comm_ = nullptr;
     void reduce_rings(double* v, int64_t n);   // over the ranks holding the same bands (== reduce without band sharding)

@@ -86,12 +86,13 @@ void launch_dot(const double* a, const double* b, int64_t n, double* partial, do
 // fused PCG vector kernels (diagonal preconditioner, diffuse components only): p_* = dot_partial_count() partial sums
 void launch_cg_seed(const double* scal, int slot, double* p, hipStream_t s);
 void launch_cg_q(const CompDev* comps, int ncomp, int lmax, const double* smat, const double* yc, const double* d,
-                 double* q, double* p_dq, hipStream_t s);
+                 double* q, double* p_dq, hipStream_t s, int64_t ilo = 0, int64_t ihi = INT64_MAX);
 void launch_cg_xr_precond(const CompDev* comps, int ncomp, int lmax, const double* P, int nmaps_pre, const double* p_dq,
                           const double* p_rs_old, double* p_rs, double* x, double* r, const double* d, const double* q,
-                          double* sv, double* scal, hipStream_t s);
+                          double* sv, double* scal, hipStream_t s, int64_t ilo = 0, int64_t ihi = INT64_MAX);
 void launch_cg_d_sqrtS(const CompDev* comps, int ncomp, int lmax, const double* smat, const double* p_rs_old,
-                       const double* p_rs, double* d, const double* sv, double* sx, double* scal, hipStream_t s);
+                       const double* p_rs, double* d, const double* sv, double* sx, double* scal, hipStream_t s,
+                       int64_t ilo = 0, int64_t ihi = INT64_MAX);
 void launch_cg_xr(double* x, double* r, const double* d, const double* q, int64_t n, const double* scal, int num,
                   int den, hipStream_t s);
 void launch_cg_d(double* d, const double* sv, int64_t n, const double* scal, int num, int den, hipStream_t s);

@@ -30,6 +30,8 @@ struct Api {
     int (*CommUserRank)(void*, int*) = nullptr;
     int (*AllReduce)(const void*, void*, size_t, int, int, void*, void*) = nullptr;
     const char* (*GetErrorString)(int) = nullptr;
+    int (*ReduceScatter)(const void*, void*, size_t, int, int, void*, void*) = nullptr;
+    int (*AllGather)(const void*, void*, size_t, int, void*, void*) = nullptr;
     int (*GroupStart)() = nullptr;
     int (*GroupEnd)() = nullptr;
     std::string err;
@@ -68,6 +70,8 @@ Api& api() {
         A.CommUserRank = (decltype(A.CommUserRank))sym("ncclCommUserRank");
         A.AllReduce = (decltype(A.AllReduce))sym("ncclAllReduce");
         A.GetErrorString = (decltype(A.GetErrorString))sym("ncclGetErrorString");
+        A.ReduceScatter = (decltype(A.ReduceScatter))sym("ncclReduceScatter");
+        A.AllGather = (decltype(A.AllGather))sym("ncclAllGather");
         A.GroupStart = (decltype(A.GroupStart))sym("ncclGroupStart");
         A.GroupEnd = (decltype(A.GroupEnd))sym("ncclGroupEnd");
     });
@@ -137,6 +141,19 @@ int RcclComm::rank() const {
 void RcclComm::allreduce_sum(double* dev, int64_t n, void* hip_stream) const {
     CMDR_REQUIRE(comm_, "no communicator");
     check(api().AllReduce(dev, dev, (size_t)n, /*ncclFloat64*/ 8, /*ncclSum*/ 0, comm_, hip_stream), "ncclAllReduce");
+}
+
+void RcclComm::reduce_scatter_sum(double* dev, int64_t count, void* hip_stream) const {
+    CMDR_REQUIRE(comm_, "no communicator");
+    const int r = rank();     // in-place form: recvbuff = sendbuff + rank * recvcount
+    check(api().ReduceScatter(dev, dev + (int64_t)r * count, (size_t)count, /*ncclFloat64*/ 8, /*ncclSum*/ 0, comm_, hip_stream),
+          "ncclReduceScatter");
+}
+
+void RcclComm::all_gather(double* dev, int64_t count, void* hip_stream) const {
+    CMDR_REQUIRE(comm_, "no communicator");
+    const int r = rank();     // in-place form: sendbuff = recvbuff + rank * sendcount
+    check(api().AllGather(dev + (int64_t)r * count, dev, (size_t)count, /*ncclFloat64*/ 8, comm_, hip_stream), "ncclAllGather");
 }
 
 }  // namespace cmdr

@@ -24,6 +24,10 @@ class RcclComm {
     int size() const;                                                    // ncclCommCount, read back from the library
     int rank() const;                                                    // ncclCommUserRank
     void allreduce_sum(double* dev, int64_t n, void* hip_stream) const;  // in place, enqueued on hip_stream
+    // in place on a buffer of size() * count doubles: rank r ends up with the sum of everybody's chunk r at offset r * count
+    void reduce_scatter_sum(double* dev, int64_t count, void* hip_stream) const;
+    // in place: everybody's chunk (at offset rank * count) is distributed to all
+    void all_gather(double* dev, int64_t count, void* hip_stream) const;
     static int version();                                                // ncclGetVersion
     static void group_start();                                           // ncclGroupStart / ncclGroupEnd: several
     static void group_end();                                             // all-reduces of one stream as one operation

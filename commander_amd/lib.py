@@ -66,6 +66,7 @@ def _sig(L):
     L.cmdr_ctx_init_rccl.argtypes = [c_vp, ctypes.c_char_p, c_int, c_int]
     L.cmdr_ctx_rccl_split_rings.argtypes = [c_vp, c_int, c_int, c_int]
     L.cmdr_ctx_drop_rccl.argtypes = [c_vp]
+    L.cmdr_ctx_set_vector_slicing.argtypes = [c_vp, c_int, c_int]
     L.cmdr_ctx_rccl_size.argtypes = [c_vp]
     L.cmdr_ctx_rccl_size.restype = c_int
     L.cmdr_band_add.argtypes = [c_vp, c_int, c_int, c_int, dp, dp, c_dbl, dp, dp]

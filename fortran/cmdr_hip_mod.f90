@@ -135,6 +135,14 @@ module cmdr_hip_mod
        integer(c_int)        :: ierr
      end function cmdr_ctx_rccl_split_rings
 
+     ! m-sliced CG vectors inside cmdr_solve (rank of nranks keeps its range of x, r, d, q, s; reduce-scatter + all-gather)
+     function cmdr_ctx_set_vector_slicing(ctx, rank, nranks) bind(c, name='cmdr_ctx_set_vector_slicing') result(ierr)
+       import :: c_ptr, c_int
+       type(c_ptr),    value :: ctx
+       integer(c_int), value :: rank, nranks
+       integer(c_int)        :: ierr
+     end function cmdr_ctx_set_vector_slicing
+
      function cmdr_ctx_drop_rccl(ctx) bind(c, name='cmdr_ctx_drop_rccl') result(ierr)
        import :: c_ptr, c_int
        type(c_ptr), value :: ctx

@@ -125,6 +125,15 @@ int cmdr_rccl_version(void);
 int cmdr_ctx_init_rccl(cmdr_ctx* ctx, const char* id128, int rank, int nranks);
 int cmdr_ctx_rccl_split_rings(cmdr_ctx* ctx, int band_group, int ring_index, int ring_replicas);
 int cmdr_ctx_drop_rccl(cmdr_ctx* ctx);
+/* m-sliced CG vectors (optional; the reference's ownership of a_lm, comm_map_mod.f90:228-261, and its mpi_dot_product,
+ * comm_utils.f90:599-614): inside cmdr_solve rank `rank` of `nranks` keeps only its contiguous range of x, r, d, q, s.  The
+ * matvec output is reduce-scattered instead of all-reduced (ncclReduceScatter with the native communicator), the three
+ * fused vector kernels run on the slice, S^1/2 d is all-gathered for the next synthesis (ncclAllGather) and every dot
+ * product sums its 8 KB of block partials over the ranks.  Same wire volume as the all-reduce, 1/nranks of the vector work.
+ * Applies to one diffuse component with one map under the diagonal preconditioner (S^1/2 and M^-1 are then scalars per l,
+ * any index range is a valid slice); other systems keep replicated vectors.  With the all-reduce callbacks the two
+ * collectives are formed from all-reduces (correct, no traffic saving).  nranks <= 1 switches it off. */
+int cmdr_ctx_set_vector_slicing(cmdr_ctx* ctx, int rank, int nranks);
 int cmdr_ctx_rccl_size(cmdr_ctx* ctx);
 int cmdr_ctx_set_only_pol(cmdr_ctx* ctx, int only_pol);
 /* on != 0: reproduce cr_matmulA's re-use of pmap%alm across the components of a band literally

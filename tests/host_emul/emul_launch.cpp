@@ -372,33 +372,34 @@ static void put_partial(double* p, double v) {
 }
 void launch_cg_seed(const double* scal, int slot, double* p, hipStream_t) { put_partial(p, scal[slot]); }
 void launch_cg_q(const CompDev* comps, int ncomp, int lmax, const double* smat, const double* yc, const double* d,
-                 double* q, double* p_dq, hipStream_t) {
+                 double* q, double* p_dq, hipStream_t, int64_t ilo, int64_t ihi) {
     double acc = 0.0;
     for (int m = 0; m <= lmax; ++m)
         for (int l = m; l <= lmax; ++l)
-            acc += cg_single(comps, ncomp) ? cg_q_elem1(comps[0], smat, yc, d, q, m, l) : cg_q_elem(comps, ncomp, smat, yc, d, q, m, l);
+            acc += cg_single(comps, ncomp) ? cg_q_elem1(comps[0], smat, yc, d, q, m, l, ilo, ihi) : cg_q_elem(comps, ncomp, smat, yc, d, q, m, l);
     put_partial(p_dq, acc);
 }
 void launch_cg_xr_precond(const CompDev* comps, int ncomp, int lmax, const double* P, int nmaps_pre, const double* p_dq,
                           const double* p_rs_old, double* p_rs, double* x, double* r, const double* d, const double* q,
-                          double* sv, double* scal, hipStream_t) {
+                          double* sv, double* scal, hipStream_t, int64_t ilo, int64_t ihi) {
     const double dq = fold_partials(p_dq), alpha = fold_partials(p_rs_old) / dq;
     scal[2] = dq;
     double acc = 0.0;
     for (int m = 0; m <= lmax; ++m)
         for (int l = m; l <= lmax; ++l)
-            acc += cg_single(comps, ncomp) && nmaps_pre == 1 ? cg_xr_elem1(comps[0], P, lmax, alpha, x, r, d, q, sv, m, l)
+            acc += cg_single(comps, ncomp) && nmaps_pre == 1 ? cg_xr_elem1(comps[0], P, lmax, alpha, x, r, d, q, sv, m, l, ilo, ihi)
                                                              : cg_xr_elem(comps, ncomp, P, lmax, nmaps_pre, alpha, x, r, d, q, sv, m, l);
     put_partial(p_rs, acc);
 }
 void launch_cg_d_sqrtS(const CompDev* comps, int ncomp, int lmax, const double* smat, const double* p_rs_old,
-                       const double* p_rs, double* d, const double* sv, double* sx, double* scal, hipStream_t) {
+                       const double* p_rs, double* d, const double* sv, double* sx, double* scal, hipStream_t, int64_t ilo,
+                       int64_t ihi) {
     const double dold = fold_partials(p_rs_old), dnew = fold_partials(p_rs);
     scal[0] = dnew;
     scal[1] = dold;
     for (int m = 0; m <= lmax; ++m)
         for (int l = m; l <= lmax; ++l) {
-            if (cg_single(comps, ncomp)) cg_d_elem1(comps[0], smat, dnew / dold, d, sv, sx, m, l);
+            if (cg_single(comps, ncomp)) cg_d_elem1(comps[0], smat, dnew / dold, d, sv, sx, m, l, ilo, ihi);
             else cg_d_elem(comps, ncomp, smat, dnew / dold, d, sv, sx, m, l);
         }
 }

@@ -30,12 +30,21 @@ def results(ctx):
 
 ref = results(build_context(spec))
 ctx = build_context(spec)
-if mode in ("native", "native-after-torch", "split"):
+if mode == "sliced":       # one scalar component (the benchmark's shape): sliced CG vectors through ncclReduceScatter / ncclAllGather
+    spec = synth.make_problem("cfg3", nside=64, lmax=128)
+    resid, xi, eta = synth.draw_inputs(spec)
+    x = np.random.default_rng(3).standard_normal(129 * 129)
+    ref = results(build_context(spec))
+    ctx = build_context(spec)
+    os.environ["CMDR_SLICE_FORCE"] = "1"
+if mode in ("native", "native-after-torch", "split", "sliced"):
     assert ctx.L.cmdr_rccl_version() >= 20000, ctx.L.cmdr_last_error()
     ctx.init_rccl(ctx.rccl_unique_id(), 0, 1)
     assert ctx.rccl_size() == 1
     if mode == "split":
         ctx.rccl_split_rings(0, 0, 1)      # band group 0, ring set 0 of 1: the hybrid bookkeeping with trivial groups
+    if mode == "sliced":
+        ctx.set_vector_slicing(0, 1)
 elif mode == "torch-stream":
     from bench import CudaView
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT="29577")

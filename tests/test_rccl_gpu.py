@@ -20,7 +20,7 @@ from helpers import ROOT
 pytestmark = pytest.mark.gpu
 
 
-@pytest.mark.parametrize("mode", ["native", "native-after-torch", "split", "torch-stream"])
+@pytest.mark.parametrize("mode", ["native", "native-after-torch", "split", "torch-stream", "sliced"])
 def test_rccl_one_rank_bit_equal(mode):
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
     for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK"):
