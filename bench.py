@@ -577,6 +577,12 @@ def main():
             else:
                 ctx.set_allreduce_stream(allreduce)
             rccl_world = dist.get_world_size() if not one_gpu else 0
+    # m-sliced CG vectors (reduce-scatter + all-gather instead of the all-reduce, 1 / N of the vector kernels): opt-in.  At
+    # the benchmark's size the two extra 8 KB sums per iteration and the loss of the two-half overlap are estimated to cost
+    # what the replicated vector kernels cost; it pays for larger ncr / more ranks.
+    sliced = world > 1 and lay["band_parts"] == 1 and os.environ.get("CMDR_BENCH_SLICE") == "1"
+    if sliced:
+        ctx.set_vector_slicing(rank, world)
     ctx.initPrecond()
     ctx.update_precond()
     resid, xi, eta = synth.draw_inputs(spec)
@@ -689,7 +695,8 @@ def main():
         if world > 1:
             par = ("%d band groups x %d ring sets (band x ring-set hybrid)" % (lay["band_parts"], lay["ring_parts"])
                    if lay["band_parts"] > 1 else "ring-pair sharding x%d" % world)
-            par += ", replicated a_lm, 1 all-reduce(ncr) per matvec"
+            par += (", m-sliced CG vectors: reduce-scatter(ncr) + all-gather(ncr) + two 8 KB all-reduces per iteration" if sliced
+                    else ", replicated a_lm, the all-reduce(ncr) of a matvec in two halves, the first beside the second half's adjoint")
         out = {
             "metric": "cg_solves_per_sec", "value": args.steps / dt, "unit": "solves/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
