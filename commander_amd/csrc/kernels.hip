@@ -1444,6 +1444,251 @@ __global__ void __launch_bounds__(128) k_leg2_adj_dx(Leg2Args A, const WaveTask*
     }
 }
 
+// ---- the DPP form, software-pipelined: the recursion that fills the NEXT tile is interleaved, instruction by instruction,
+// with the DPP FMAs that consume the CURRENT one (two tiles per wave, ping-pong: tile 0 always carries the + chain, tile 1
+// the - chain).  k_leg2_adj_dx runs [recursion -> fence -> 16 x FMA block -> fence] twice per 32 l with nothing else in
+// flight, and its recursion phase is a dependent chain that also pushes 8 B per lane and l through the LDS store path;
+// here the chain's latency and the store path hide behind the accumulation of the other chain.  One wave per SIMD (66 KB
+// of LDS per workgroup), so everything has to come from the wave's own instruction stream -- and nothing in the loop may
+// wait for a scalar load (SMEM returns out of order: every wait on it is lgkmcnt(0), which also drains the LDS queue).
+// Hence the sign-alternated recursion: with nu_l = s_k mu_l, k = l - lw, s = (+, +, -, -, ...),
+//     nu_{l+1} = nu_{l-1} + (-1)^k (alpha_{l+1} x +- beta_{l+1}) nu_l,
+// the new value ACCUMULATES into the register of nu_{l-1}, which is dead afterwards, so a step is one multiply (x nu_l)
+// and two v_fmac_f64_dpp whose row-broadcast operand is the pre-signed coefficient (Leg2Args::abs_) held by lane l of
+// every 16-lane row: one coalesced vector load per 16 l (vmcnt: counted, in order) instead of 32 scalar loads.  The tile
+// carries nu; s_k = (-1)^row for both parities of a 32-l group, applied once when the column is stored.
+// tile of the pipelined kernel: 32 rows x 64 ring pairs, the 16 even-(l - l0) rows first, then the 16 odd ones (the two
+// values a lane reads per FMA block, and the two a lane stores per recursion stage, are then 16 rows = 8.4 KB apart: the
+// compiler cannot fuse them into ds_read2_b64 / ds_write2_b64, which cost 8 / 13 LDS cycles against 2 x 2 / 2 x 6 for the
+// single forms, MI355X_MICROARCH.md); pitch 66 doubles: (2 x 66) mod 64 = 4 banks per row -> the 32 lanes of a
+// ds_read_b64 group (16 rows x 2 pairs) hit distinct banks
+constexpr int kPxPitch = 66;
+template <int Q, bool NEG>
+__device__ __forceinline__ void fmac_row_bcast_n(double& acc, double g, double a) {
+    if (NEG) asm("v_fmac_f64_dpp %0, %1, -%2 row_newbcast:%3 row_mask:0xf bank_mask:0xf" : "+v"(acc) : "v"(g), "v"(a), "n"(Q));
+    else     asm("v_fmac_f64_dpp %0, %1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf" : "+v"(acc) : "v"(g), "v"(a), "n"(Q));
+}
+// recursion steps j = J0, J0 + 1 (J0 even) of one chain: on entry cur = nu_{l0 + J0}, prev = nu_{l0 + J0 - 1}; ca / cb hold
+// (alphaS, betaS)_{l0 + 1 + 16 h + (lane & 15)} for h = J0 / 16
+template <bool INJECT, bool MINUS, int J0>
+__device__ __forceinline__ void px_recur2(int l0, double x, double& cur, double& prev, int ls, int lw,
+                                          const double* __restrict__ sd, double ca, double cb, double* __restrict__ trow) {
+    if (INJECT) {
+        if (ls == l0 + J0) {          // seeds mu_ls, mu_{ls-1} -> nu: s_k with k = ls - lw, s_{k-1}
+            const int k = (ls - lw) & 3;
+            const double sc = (k & 2) ? -1.0 : 1.0, sp = ((k + 3) & 2) ? -1.0 : 1.0;
+            cur = sc * sd[MINUS ? 2 : 0];
+            prev = sp * sd[MINUS ? 3 : 1];
+        }
+    }
+    trow[(J0 >> 1) * kPxPitch] = cur;                         // even l - l0: rows 0..15
+    {
+        const double xc = x * cur;
+        fmac_row_bcast_n<J0 & 15, false>(prev, ca, xc);
+        fmac_row_bcast_n<J0 & 15, MINUS>(prev, cb, cur);       // prev = nu_{l0 + J0 + 1}
+    }
+    if (INJECT) {
+        if (ls == l0 + J0 + 1) {
+            const int k = (ls - lw) & 3;
+            const double sc = (k & 2) ? -1.0 : 1.0, sp = ((k + 3) & 2) ? -1.0 : 1.0;
+            prev = sc * sd[MINUS ? 2 : 0];
+            cur = sp * sd[MINUS ? 3 : 1];
+        }
+    }
+    trow[(16 + (J0 >> 1)) * kPxPitch] = prev;                  // odd l - l0: rows 16..31
+    {
+        const double xc = x * prev;
+        fmac_row_bcast_n<(J0 + 1) & 15, false>(cur, ca, xc);
+        fmac_row_bcast_n<(J0 + 1) & 15, MINUS>(cur, cb, prev);  // cur = nu_{l0 + J0 + 2}; roles are back
+    }
+}
+
+// One wave = one (m, 128 ring pairs) task: its two 64-pair blocks take turns in the pipeline -- (b0, +) (b0, -) (b1, +)
+// (b1, -) per 32-l group, each phase's FMA blocks beside the recursion of the next phase -- and both accumulate into the
+// same registers, so there is no second wave to wait for and nothing to hand over through LDS.
+template <int NP>
+__global__ void __launch_bounds__(64) k_leg2_adj_px(Leg2Args A, const WaveTask* __restrict__ tasks, int ntasks,
+                                                    const double* __restrict__ ph, int64_t ph_stride, int kq0,
+                                                    double* __restrict__ part, int64_t part_pol_stride,
+                                                    int64_t part_chunk_stride) {
+    __shared__ __attribute__((aligned(16))) double tile[2][kMxL * kPxPitch];      // ping-pong
+    const int lane = threadIdx.x;
+    if ((int)blockIdx.x >= ntasks) return;
+    const WaveTask T = tasks[blockIdx.x];
+    if (T.chunk < 0) return;
+    const int m = __builtin_amdgcn_readfirstlane(T.m);
+    const int chunk = __builtin_amdgcn_readfirstlane(T.chunk);
+    const int lw = __builtin_amdgcn_readfirstlane(T.lw);
+    const int lmax = A.lmax;
+    const int kq = lane >> 4, row = lane & 15;
+    const int par0 = (lw + m) & 1;
+    double x0, x1, pc0 = 0.0, pp0 = 0.0, mc0 = 0.0, mp0 = 0.0, pc1 = 0.0, pp1 = 0.0, mc1 = 0.0, mp1 = 0.0;
+    const double *sd0, *sd1;
+    int ls0, ls1, lhi;
+    double B0[NP][2][2][4], B1[NP][2][2][4];
+    {
+        int hi = -1;
+        auto setup = [&](int b, double& x, int& ls, const double*& sd, double (&B)[NP][2][2][4]) {
+            const int pb = chunk * 128 + b * 64;
+            const int p = pb + lane;
+            const int64_t idx = (int64_t)m * A.npair_pad + p;
+            x = A.x[p];
+            ls = A.ls[idx];
+            sd = A.seed + idx * 4;
+            int v = ls == 0x3fffffff ? -1 : ls;
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) v = max(v, __shfl_xor(v, o));
+            hi = max(hi, __builtin_amdgcn_readfirstlane(v));
+            const int64_t o = d_phidx(lmax + 1, pb + 4 * row + kq, m);
+#pragma unroll
+            for (int ip = 0; ip < NP; ++ip) {
+                const double* q = ph + (int64_t)(kq0 + 2 * ip) * ph_stride + o;
+                const double* u = q + ph_stride;
+                const double qpr = q[0] + q[2], qpi = q[1] + q[3], qmr = q[0] - q[2], qmi = q[1] - q[3];
+                const double upr = u[0] + u[2], upi = u[1] + u[3], umr = u[0] - u[2], umi = u[1] - u[3];
+                const double w0[4] = {qpr, qpi, upr, upi}, xx0[4] = {-umi, umr, qmi, -qmr};
+                const double w1[4] = {qmr, qmi, umr, umi}, xx1[4] = {-upi, upr, qpi, -qpr};
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    const double we = par0 ? w1[c] : w0[c], xe = par0 ? xx1[c] : xx0[c];
+                    const double wo = par0 ? w0[c] : w1[c], xo = par0 ? xx0[c] : xx1[c];
+                    B[ip][0][0][c] = we + xe; B[ip][1][0][c] = we - xe;
+                    B[ip][0][1][c] = wo + xo; B[ip][1][1][c] = wo - xo;
+                }
+            }
+        };
+        setup(0, x0, ls0, sd0, B0);
+        setup(1, x1, ls1, sd1, B1);
+        lhi = hi;
+    }
+    const int64_t mo = d_moffp(lmax, m);
+    // (alphaS, betaS)_{l}: this lane's entry of a 16-l block that starts at l = lb + 1 is ab[2 lb]
+    const double* __restrict__ ab = A.abs_ + 2 * (mo - m) + 2 * (1 + row);
+    const int cidx = ((kq & 1) << 1) | (kq >> 1);
+    double* __restrict__ outp = part + chunk * part_chunk_stride + 4 * (mo - m) + cidx;
+    const double osgn = (row & 1) ? -1.0 : 1.0;          // nu -> mu for the rows this lane stores (both parities)
+    double* __restrict__ T0 = tile[0];
+    double* __restrict__ T1 = tile[1];
+    const int arow = row * kPxPitch + kq;
+#define CMDR_WAVE_SYNC()                                                                                   \
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");                                                 \
+    __builtin_amdgcn_wave_barrier();                                                                       \
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    // the tile reads of FMA block q + 3 are issued before block q is consumed (LDS is in order and the compiler keeps the
+    // program order of the reads against the recursion's stores, which it cannot prove disjoint)
+#define CMDR_PX_RD(q, TT, E, O) { E = TT[arow + 4 * (q)]; O = TT[arow + 16 * kPxPitch + 4 * (q)]; }
+#define CMDR_PX_FMA(q, BB, S, E, O)                                                                        \
+    {                                                                                                      \
+        _Pragma("unroll") for (int ip = 0; ip < NP; ++ip)                                                  \
+        _Pragma("unroll") for (int c = 0; c < 4; ++c) {                                                    \
+            fmac_row_bcast<(q)>(ae_[ip][c], BB[ip][S][0][c], E);                                           \
+            fmac_row_bcast<(q)>(ao_[ip][c], BB[ip][S][1][c], O);                                           \
+        }                                                                                                  \
+    }
+    // one pipeline stage: FMA block q (operands E, O read three stages ago; B set BB, sign S) on tile TT beside recursion
+    // steps 2q, 2q + 1 of the next phase (block state XN / CUR / PREV / LSN / SDN, sign MN, group start LN) into TN
+#define CMDR_PX_STAGE(q, BB, S, TT, INJ, MN, LN, XN, CUR, PREV, LSN, SDN, TN, CA, CB, E, O, EN, ON)         \
+    if ((q) + 3 < 16) CMDR_PX_RD(((q) + 3) & 15, TT, EN, ON)                                               \
+    CMDR_PX_FMA(q, BB, S, E, O)                                                                            \
+    px_recur2<INJ, MN, 2 * (q)>(LN, XN, CUR, PREV, LSN, lw, SDN, CA[(q) >> 3], CB[(q) >> 3], TN + lane);
+#define CMDR_PX_PHASE(BB, S, TT, INJ, MN, LN, XN, CUR, PREV, LSN, SDN, TN, CA, CB)                          \
+    {                                                                                                      \
+        double e0, o0, e1, o1, e2, o2, e3, o3;                                                             \
+        CMDR_PX_RD(0, TT, e0, o0) CMDR_PX_RD(1, TT, e1, o1) CMDR_PX_RD(2, TT, e2, o2)                      \
+        CMDR_PX_STAGE(0, BB, S, TT, INJ, MN, LN, XN, CUR, PREV, LSN, SDN, TN, CA, CB, e0, o0, e3, o3)       \
+        CMDR_PX_STAGE(1, BB, S, TT, INJ, MN, LN, XN, CUR, PREV, LSN, SDN, TN, CA, CB, e1, o1, e0, o0)       \
+        CMDR_PX_STAGE(2, BB, S, TT, INJ, MN, LN, XN, CUR, PREV, LSN, SDN, TN, CA, CB, e2, o2, e1, o1)       \
+        CMDR_PX_STAGE(3, BB, S, TT, INJ, MN, LN, XN, CUR, PREV, LSN, SDN, TN, CA, CB, e3, o3, e2, o2)       \
+        CMDR_PX_STAGE(4, BB, S, TT, INJ, MN, LN, XN, CUR, PREV, LSN, SDN, TN, CA, CB, e0, o0, e3, o3)       \
+        CMDR_PX_STAGE(5, BB, S, TT, INJ, MN, LN, XN, CUR, PREV, LSN, SDN, TN, CA, CB, e1, o1, e0, o0)       \
+        CMDR_PX_STAGE(6, BB, S, TT, INJ, MN, LN, XN, CUR, PREV, LSN, SDN, TN, CA, CB, e2, o2, e1, o1)       \
+        CMDR_PX_STAGE(7, BB, S, TT, INJ, MN, LN, XN, CUR, PREV, LSN, SDN, TN, CA, CB, e3, o3, e2, o2)       \
+        CMDR_PX_STAGE(8, BB, S, TT, INJ, MN, LN, XN, CUR, PREV, LSN, SDN, TN, CA, CB, e0, o0, e3, o3)       \
+        CMDR_PX_STAGE(9, BB, S, TT, INJ, MN, LN, XN, CUR, PREV, LSN, SDN, TN, CA, CB, e1, o1, e0, o0)       \
+        CMDR_PX_STAGE(10, BB, S, TT, INJ, MN, LN, XN, CUR, PREV, LSN, SDN, TN, CA, CB, e2, o2, e1, o1)      \
+        CMDR_PX_STAGE(11, BB, S, TT, INJ, MN, LN, XN, CUR, PREV, LSN, SDN, TN, CA, CB, e3, o3, e2, o2)      \
+        CMDR_PX_STAGE(12, BB, S, TT, INJ, MN, LN, XN, CUR, PREV, LSN, SDN, TN, CA, CB, e0, o0, e3, o3)      \
+        CMDR_PX_STAGE(13, BB, S, TT, INJ, MN, LN, XN, CUR, PREV, LSN, SDN, TN, CA, CB, e1, o1, e0, o0)      \
+        CMDR_PX_STAGE(14, BB, S, TT, INJ, MN, LN, XN, CUR, PREV, LSN, SDN, TN, CA, CB, e2, o2, e1, o1)      \
+        CMDR_PX_STAGE(15, BB, S, TT, INJ, MN, LN, XN, CUR, PREV, LSN, SDN, TN, CA, CB, e3, o3, e2, o2)      \
+    }
+    auto load_ab = [&](int lb, double (&Ca)[2], double (&Cb)[2]) {
+        // rows beyond the table's end (lb + 32 may pass lmax + 1 by up to 32 + 31) read the 64 entries of slack
+        const double2 v0 = *reinterpret_cast<const double2*>(ab + 2 * lb);
+        const double2 v1 = *reinterpret_cast<const double2*>(ab + 2 * (lb + 16));
+        Ca[0] = v0.x; Cb[0] = v0.y;
+        Ca[1] = v1.x; Cb[1] = v1.y;
+    };
+    double Ca[2], Cb[2], Na[2], Nb[2];
+    // prologue: the + chain of block 0 for the first group, un-pipelined
+    load_ab(lw, Ca, Cb);
+    {
+#define CMDR_PX_PRO(q, INJ) px_recur2<INJ, false, 2 * (q)>(lw, x0, pc0, pp0, ls0, lw, sd0, Ca[(q) >> 3], Cb[(q) >> 3], T0 + lane);
+        if (lw <= lhi) { CMDR_PX_PRO(0, true) CMDR_PX_PRO(1, true) CMDR_PX_PRO(2, true) CMDR_PX_PRO(3, true) CMDR_PX_PRO(4, true)
+                         CMDR_PX_PRO(5, true) CMDR_PX_PRO(6, true) CMDR_PX_PRO(7, true) CMDR_PX_PRO(8, true) CMDR_PX_PRO(9, true)
+                         CMDR_PX_PRO(10, true) CMDR_PX_PRO(11, true) CMDR_PX_PRO(12, true) CMDR_PX_PRO(13, true)
+                         CMDR_PX_PRO(14, true) CMDR_PX_PRO(15, true) }
+        else           { CMDR_PX_PRO(0, false) CMDR_PX_PRO(1, false) CMDR_PX_PRO(2, false) CMDR_PX_PRO(3, false) CMDR_PX_PRO(4, false)
+                         CMDR_PX_PRO(5, false) CMDR_PX_PRO(6, false) CMDR_PX_PRO(7, false) CMDR_PX_PRO(8, false) CMDR_PX_PRO(9, false)
+                         CMDR_PX_PRO(10, false) CMDR_PX_PRO(11, false) CMDR_PX_PRO(12, false) CMDR_PX_PRO(13, false)
+                         CMDR_PX_PRO(14, false) CMDR_PX_PRO(15, false) }
+#undef CMDR_PX_PRO
+        CMDR_WAVE_SYNC()
+    }
+    for (int l0 = lw; l0 <= lmax; l0 += kMxL) {
+        double ae_[NP][4], ao_[NP][4];
+#pragma unroll
+        for (int ip = 0; ip < NP; ++ip)
+#pragma unroll
+            for (int c = 0; c < 4; ++c) ae_[ip][c] = ao_[ip][c] = 0.0;
+        const bool inj = l0 <= lhi, injn = l0 + kMxL <= lhi;
+        load_ab(l0 + kMxL, Na, Nb);                    // the next group's coefficients: in flight during this group
+        // (b0, +) on tile 0 | the - chain of block 0 -> tile 1
+        if (inj) { CMDR_PX_PHASE(B0, 0, T0, true, true, l0, x0, mc0, mp0, ls0, sd0, T1, Ca, Cb) }
+        else     { CMDR_PX_PHASE(B0, 0, T0, false, true, l0, x0, mc0, mp0, ls0, sd0, T1, Ca, Cb) }
+        CMDR_WAVE_SYNC()
+        // (b0, -) on tile 1 | the + chain of block 1 -> tile 0
+        if (inj) { CMDR_PX_PHASE(B0, 1, T1, true, false, l0, x1, pc1, pp1, ls1, sd1, T0, Ca, Cb) }
+        else     { CMDR_PX_PHASE(B0, 1, T1, false, false, l0, x1, pc1, pp1, ls1, sd1, T0, Ca, Cb) }
+        CMDR_WAVE_SYNC()
+        // (b1, +) on tile 0 | the - chain of block 1 -> tile 1
+        if (inj) { CMDR_PX_PHASE(B1, 0, T0, true, true, l0, x1, mc1, mp1, ls1, sd1, T1, Ca, Cb) }
+        else     { CMDR_PX_PHASE(B1, 0, T0, false, true, l0, x1, mc1, mp1, ls1, sd1, T1, Ca, Cb) }
+        CMDR_WAVE_SYNC()
+        // (b1, -) on tile 1 | the + chain of block 0 for the NEXT group -> tile 0 (harmless beyond lmax: the tables carry
+        // slack and nothing of that group is stored)
+        if (injn) { CMDR_PX_PHASE(B1, 1, T1, true, false, l0 + kMxL, x0, pc0, pp0, ls0, sd0, T0, Na, Nb) }
+        else      { CMDR_PX_PHASE(B1, 1, T1, false, false, l0 + kMxL, x0, pc0, pp0, ls0, sd0, T0, Na, Nb) }
+        CMDR_WAVE_SYNC()
+        Ca[0] = Na[0]; Ca[1] = Na[1]; Cb[0] = Nb[0]; Cb[1] = Nb[1];
+        // fold the four pair lanes (kq) of every row; te / to hold, in 16-lane row kq, component {0, 2, 1, 3}[kq] of the
+        // even / odd l rows
+#pragma unroll
+        for (int ip = 0; ip < NP; ++ip) {
+            double a0 = ae_[ip][0], a1 = ae_[ip][1], a2 = ae_[ip][2], a3 = ae_[ip][3];
+            swap_halves(a0, a1);
+            swap_halves(a2, a3);
+            double s01 = a0 + a1, s23 = a2 + a3;
+            swap_rows(s01, s23);
+            const double te = s01 + s23;
+            a0 = ao_[ip][0]; a1 = ao_[ip][1]; a2 = ao_[ip][2]; a3 = ao_[ip][3];
+            swap_halves(a0, a1);
+            swap_halves(a2, a3);
+            s01 = a0 + a1; s23 = a2 + a3;
+            swap_rows(s01, s23);
+            const double to = s01 + s23;
+            const int l = l0 + 2 * row;
+            if (l <= lmax) outp[(int64_t)ip * part_pol_stride + 4 * l] = osgn * te;
+            if (l + 1 <= lmax) outp[(int64_t)ip * part_pol_stride + 4 * (l + 1)] = osgn * to;
+        }
+    }
+#undef CMDR_PX_PHASE
+#undef CMDR_PX_STAGE
+#undef CMDR_PX_FMA
+#undef CMDR_PX_RD
+#undef CMDR_WAVE_SYNC
+}
+
 // CMDR_LEG2_NP_S=1 / CMDR_LEG2_NP_A=1 switch the two-pairs-per-wave synthesis / adjoint off
 static bool leg2_pairs2(bool adjoint) {
     static int v[2] = {-1, -1};
@@ -1487,7 +1732,22 @@ void launch_leg2_adj(const Leg2Args& A, const WaveTask* tasks, int ntasks, const
     // Nside 2048 / lmax 4000, one pair, 23.0 ms against 19.7 ms for k_leg2_adj -- two tile round trips per 32 l (mu+ and
     // mu-: the LDS store path, ~85 B/clk/CU, carries 16 B per (ring pair, l)) at two waves per SIMD cost more than the
     // wave-wide reductions they replace
-    const bool dx_on = [] { const char* e = std::getenv("CMDR_ADJ2_DX"); return e && std::atoi(e) != 0; }();
+    // CMDR_ADJ2_DX: 0 (default) the VALU kernels, 1 k_leg2_adj_dx, 2 its software-pipelined single-wave form k_leg2_adj_px.
+    // Measured at Nside 2048 / lmax 4000, one pair: 19.9 ms (VALU), 23.0 ms (dx), 22.1 ms (px: 30.7 ms as first written,
+    // 24.7 ms without fused ds_read2 / ds_write2 and with reads three blocks ahead, 22.1 ms as one wave per task without
+    // workgroup barriers).  At one wave per SIMD the VALU is busy 44 % and the LDS array 57 % of the time, one after the
+    // other rather than beside each other; the transposed forms stay opt-in.
+    const int dx_mode = [] { const char* e = std::getenv("CMDR_ADJ2_DX"); return e ? std::atoi(e) : 0; }();
+    const bool dx_on = dx_mode == 1;
+    if (dx_mode == 2 && A.R == 2 && npol - ip0 >= 1 && npol - ip0 <= 2) {
+        if (npol - ip0 == 2)
+            hipLaunchKernelGGL((k_leg2_adj_px<2>), dim3(ntasks), dim3(64), 0, s, A, tasks, ntasks, ph, ph_stride, kq0 + 2 * ip0,
+                               part + ip0 * part_pol_stride, part_pol_stride, part_chunk_stride);
+        else
+            hipLaunchKernelGGL((k_leg2_adj_px<1>), dim3(ntasks), dim3(64), 0, s, A, tasks, ntasks, ph, ph_stride, kq0 + 2 * ip0,
+                               part + ip0 * part_pol_stride, part_pol_stride, part_chunk_stride);
+        return;
+    }
     if (dx_on && A.R == 2 && npol - ip0 >= 1 && npol - ip0 <= 2) {
         if (npol - ip0 == 2)
             hipLaunchKernelGGL((k_leg2_adj_dx<1, 2>), dim3(ntasks), dim3(128), 0, s, A, tasks, ntasks, ph, ph_stride, kq0 + 2 * ip0,

@@ -271,6 +271,8 @@ struct Leg2Args {
     const double* seed;    // [(lmax+1) * npair_pad * 4]
     const double* alpha;   // [ntrip]
     const double* beta;    // [ntrip]
+    const double* abs_;    // [2 ntrip] (alpha, beta)_l times (-1)^(l - 1 - l0), interleaved: the sign-alternated form of the
+                           // recursion used by k_leg2_adj_px (nu_{l+1} = nu_{l-1} + (alphaS x +- betaS) nu_l, no subtraction)
 };
 
 template <int R>

@@ -62,6 +62,18 @@ void Legendre2Dev::upload(const Legendre2Tables& T) {
     beta.upload(T.beta);
     cnorm.upload(T.cnorm);
     tasks.upload(T.tasks);
+    // (alpha, beta)_l (-1)^(l - 1 - l0), interleaved (Leg2Args::abs_)
+    std::vector<double> ab(2 * T.alpha.size(), 0.0);
+    for (int m = 0; m <= T.lmax; ++m) {
+        const int l0 = std::max(m, 2);
+        const int64_t mo = moffp(T.lmax, m) - m;
+        for (int l = l0 + 1; l <= T.lmax + 1; ++l) {
+            const double sg = ((l - 1 - l0) & 1) ? -1.0 : 1.0;
+            ab[2 * (mo + l)] = sg * T.alpha[mo + l];
+            ab[2 * (mo + l) + 1] = sg * T.beta[mo + l];
+        }
+    }
+    abs_.upload(ab);
 }
 
 ShtPlan::ShtPlan(int nside, int lmax, const std::vector<int>& rings, const double* wring, int max_maps, bool pol)
@@ -259,6 +271,7 @@ Leg2Args ShtPlan_leg2_args(const Legendre2Dev& L, const double* x) {
     A.seed = L.seed.get();
     A.alpha = L.alpha.get();
     A.beta = L.beta.get();
+    A.abs_ = L.abs_.get();
     return A;
 }
 

@@ -156,8 +156,9 @@ def test_polarised_cr_path_gpu():
 def test_spin2_adjoint_kernel_forms_gpu(nband, monkeypatch):
     """Polarised bands: three and more (Q,U) pairs per plan take the matrix-unit spin-2 adjoint (k_leg2_adj_mx, four
     pairs per launch: 9 = 4 + 4 + 1, 3 = one launch with an empty column group, 6 = 4 + 2), one or two (left over) pairs
-    the VALU kernels of rounds 1-2 or, with CMDR_ADJ2_DX=1, the DPP form of the matrix-unit task (k_leg2_adj_dx: correct but
-    slower for one pair, off by default); CMDR_ADJ2_MX=0 sends everything to the VALU kernels.  All forms against the
+    the VALU kernels of rounds 1-2 or, with CMDR_ADJ2_DX=1 / 2, the DPP form of the matrix-unit task (k_leg2_adj_dx) / its
+    software-pipelined single-wave form with the sign-alternated recursion (k_leg2_adj_px) -- both correct but slower for
+    one pair, off by default; CMDR_ADJ2_MX=0 sends everything to the VALU kernels.  All forms against the
     oracle, aniso noise (every (m, m') block of Yt N^-1 Y is populated), and against each other."""
     from commander_amd import synth
     from commander_amd.cr import build_context
@@ -169,6 +170,9 @@ def test_spin2_adjoint_kernel_forms_gpu(nband, monkeypatch):
     x = np.random.default_rng(100 + nband).standard_normal(ctx.ncr)
     want = S.matmulA(x)
     got_def = ctx.cr_matmulA(x)
+    monkeypatch.setenv("CMDR_ADJ2_DX", "2")
+    got_px = ctx.cr_matmulA(x)                                                         # matrix unit + pipelined DPP form
+    assert rel(got_px, want) < 1e-11
     monkeypatch.setenv("CMDR_ADJ2_DX", "1")
     got_mx = ctx.cr_matmulA(x)                                                         # matrix unit + DPP form
     monkeypatch.setenv("CMDR_ADJ2_MX", "0")
@@ -177,7 +181,7 @@ def test_spin2_adjoint_kernel_forms_gpu(nband, monkeypatch):
     assert rel(got_def, want) < 1e-11 and rel(got_mx, want) < 1e-11 and rel(got_valu, want) < 1e-11
     assert rel(got_mx, got_valu) < 1e-12 and not np.array_equal(got_mx, got_valu)     # different kernels did run
     if nband != 3:                                                                     # 3 pairs = one matrix-unit launch
-        assert not np.array_equal(got_mx, got_def)                                     # the DPP form took the left-over pairs
+        assert not np.array_equal(got_mx, got_def) and not np.array_equal(got_px, got_def)   # the DPP forms took the left-over pairs
     monkeypatch.delenv("CMDR_ADJ2_MX")
     monkeypatch.delenv("CMDR_ADJ2_DX")
     assert np.array_equal(ctx.cr_matmulA(x), got_def)                                  # deterministic
