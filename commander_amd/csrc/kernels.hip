@@ -93,8 +93,10 @@ __global__ void __launch_bounds__(256, 3) k_leg_synth_wg(LegArgs A, const WaveTa
                                                       double* __restrict__ ph, int64_t ph_stride, PrepDev P) {
     // doubles per l: NB x (re, im) [, alpha_{l+1}, pad: LDS form only].  DPP form: lane j of a 16-lane row reads tile row j
     // with ds_read_b128, so the row stride decides the banking: 16 B, 48 B and 80 B strides are conflict-free, 32 B (NB = 2)
-    // is 2-way and 64 B (NB = 4) 4-way (7.4e7 conflict cycles per launch, profiles/r02_pmc_sq_summary.txt) -> one pad slot
-    constexpr int ROW = DPPC ? ((NB == 2 || NB == 4) ? 2 * NB + 2 : 2 * NB) : 2 * NB + 2;
+    // is 2-way and 64 B (NB = 4) 4-way (7.4e7 conflict cycles per launch, profiles/r02_pmc_sq_summary.txt).  NB = 2 takes a
+    // pad slot; NB = 4 does NOT: 80-byte rows make the tile 320 doubles, i.e. two staging loads per thread instead of one,
+    // and the launch 1.37 instead of 1.23 ms (measured, round 3) -- the conflicts are cheaper than the second load
+    constexpr int ROW = DPPC ? (NB == 2 ? 2 * NB + 2 : 2 * NB) : 2 * NB + 2;
     constexpr int NE = kTileL * ROW;                    // doubles per tile
     constexpr int NLD = (NE + 255) / 256;               // global loads per thread and tile
     __shared__ __attribute__((aligned(16))) double tile[2][NE];
