@@ -187,7 +187,8 @@ CMDR_HD void band_prep2_elem(const CompDev* __restrict__ comps, int ncomp, const
 CMDR_HD void band_post2_elem(const CompDev* __restrict__ comps, int ncomp, const double* __restrict__ part2,
                              int64_t part_pol_stride, int64_t part_chunk_stride, int nchunk, int npol,
                              const double* __restrict__ w /* [nbm][ncomp][lmax_g+1] */, int nT,
-                             const double* __restrict__ cnorm2, int lmax_g, double* __restrict__ yc, int m, int l) {
+                             const double* __restrict__ cnorm2, int lmax_g, double* __restrict__ yc, int m, int l,
+                             const int* __restrict__ lwtab = nullptr) {
     // one thread = one (l, m): the chunk partials of a polarisation pair are read once and feed every component
     if (l > lmax_g || l < 2) return;
     constexpr int kMaxComp = 8;
@@ -205,8 +206,10 @@ CMDR_HD void band_post2_elem(const CompDev* __restrict__ comps, int ncomp, const
     for (int ip = 0; ip < npol; ++ip) {
         const double* p = part2 + ip * part_pol_stride + 4 * t;
         double a[4] = {0.0, 0.0, 0.0, 0.0};
-        for (int ch = 0; ch < nchunk; ++ch)
+        for (int ch = 0; ch < nchunk; ++ch) {
+            if (lwtab && l < lwtab[m * nchunk + ch]) continue;     // never written: structurally zero
             for (int k = 0; k < 4; ++k) a[k] += p[ch * part_chunk_stride + k];
+        }
         for (int c = 0; c < ncomp; ++c) {
             if (!use[c]) continue;
             const double we = w[((int64_t)(nT + 2 * ip) * ncomp + c) * (lmax_g + 1) + l];

@@ -89,17 +89,18 @@ void launch_band_prep2(const CompDev* comps, int ncomp, const double* sx, const 
 }
 __global__ void k_band_post2(const CompDev* __restrict__ comps, int ncomp, const double* __restrict__ part2,
                              int64_t pps, int64_t pcs, int nchunk, int npol, const double* __restrict__ w, int nT,
-                             const double* __restrict__ cnorm2, int lmax_g, double* __restrict__ yc) {
+                             const double* __restrict__ cnorm2, int lmax_g, double* __restrict__ yc,
+                             const int* __restrict__ lwtab) {
     const int m = blockIdx.y, l = m + blockIdx.x * 256 + threadIdx.x;
     if (l > lmax_g) return;
-    band_post2_elem(comps, ncomp, part2, pps, pcs, nchunk, npol, w, nT, cnorm2, lmax_g, yc, m, l);
+    band_post2_elem(comps, ncomp, part2, pps, pcs, nchunk, npol, w, nT, cnorm2, lmax_g, yc, m, l, lwtab);
 }
 void launch_band_post2(const CompDev* comps, int ncomp, int /*lmax_max*/, const double* part2, int64_t pps, int64_t pcs,
                        int nchunk, int npol, const double* w, int nT, const double* cnorm2, int lmax_g, double* yc,
-                       hipStream_t s) {
+                       hipStream_t s, const int* lwtab) {
     dim3 grid((lmax_g + 1 + 255) / 256, lmax_g + 1);
     hipLaunchKernelGGL(k_band_post2, grid, dim3(256), 0, s, comps, ncomp, part2, pps, pcs, nchunk, npol, w, nT, cnorm2,
-                       lmax_g, yc);
+                       lmax_g, yc, lwtab);
 }
 
 __global__ void k_alm_copy(const double* __restrict__ src, int lmax_s, double* __restrict__ dst, int lmax_d,

@@ -603,7 +603,7 @@ void CrSystem::mix_adjoint(Group& G, bool rhs) {
     if (G.npol)
         launch_part2_to_alm(P.partials2(), P.part2_pol_stride(), P.leg2().tri4(), P.leg2().nchunk,
                             G.U.get() + (int64_t)G.nT * na, G.U.get() + (int64_t)(G.nT + 1) * na, 2 * na,
-                            P.leg2().cnorm.get(), G.lmax, G.npol, stream_);
+                            P.leg2().cnorm.get(), G.lmax, G.npol, stream_, P.leg2().lw_chunk.get());
     reduce_rings(G.U.get(), (int64_t)G.nbm * na);
     for (MixBatch& B : G.mix) {
         const int nT = (int)B.T.size(), nP = (int)B.P.size();
@@ -923,7 +923,7 @@ void CrSystem::adjoint_groups_to_yc(bool from_maps) {
         if (G.npol)
             launch_band_post2(comps_dev_.get(), ncomp, lmax_max_, P.partials2(), P.part2_pol_stride(), P.leg2().tri4(),
                               P.leg2().nchunk, G.npol, G.w.get(), G.nT, P.leg2().cnorm.get(), G.lmax, yc_.get(),
-                              stream_);
+                              stream_, P.leg2().lw_chunk.get());
         if (!G.mix.empty()) mix_adjoint(G, from_maps);
     }
     reduce(yc_.get(), ncr_);
@@ -1819,7 +1819,7 @@ void CrSystem::apply_pseudoinv(const double* x, double* y) {
         if (G.npol)
             launch_band_post2(comps_dev_.get(), ncomp, lmax_max_, P.partials2(), P.part2_pol_stride(), P.leg2().tri4(),
                               P.leg2().nchunk, G.npol, G.w_pout.get(), G.nT, P.leg2().cnorm.get(), G.lmax, yc_.get(),
-                              stream_);
+                              stream_, P.leg2().lw_chunk.get());
     }
     reduce(yc_.get(), ncr_);
     launch_pinv_prior(comps_dev_.get(), ncomp, lmax_max_, Qprior_.get(), lmax_pre_, nmaps_pre_, x, yc_.get(), y,

@@ -1066,6 +1066,91 @@ __global__ void __launch_bounds__(256) k_leg2_synth_np2(Leg2Args A, const WaveTa
     }
 }
 
+// ---- NP polarisation pairs per wave at R ring pairs per lane (round 3; the np2 kernel above is <2, 2>): with three or
+// four pairs sharing the two recursions and W, X the work per pair and step falls from 11 to 10 / 9.5 VALU operations;
+// one ring pair per lane keeps the 16 NP R accumulators within the register budget of three waves per SIMD.
+template <int R, int NP>
+__global__ void __launch_bounds__(256) k_leg2_synth_npx(Leg2Args A, const WaveTask* __restrict__ tasks, int ntasks,
+                                                        const double* __restrict__ st, int npol, int ip0,
+                                                        double* __restrict__ ph, int64_t ph_stride, int kq, int split) {
+    // split = A.R / R: a task of the plan's list (64 A.R ring pairs) is shared by `split` waves of 64 R pairs each
+    const int wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int t = (blockIdx.x / split) * 4 + wid;
+    if (t >= ntasks) return;
+    const WaveTask T = tasks[t];
+    if (T.chunk < 0) return;
+    const int m = __builtin_amdgcn_readfirstlane(T.m);
+    const int chunk = __builtin_amdgcn_readfirstlane(T.chunk) * split + (int)(blockIdx.x % split);
+    const int lw = __builtin_amdgcn_readfirstlane(T.lw), lAend = __builtin_amdgcn_readfirstlane(T.lAend);
+    const int lane = threadIdx.x & 63;
+    const int lmax = A.lmax;
+    const int64_t mo = d_moffp(lmax, m);
+    const double* __restrict__ al = A.alpha + (mo - m);
+    const double* __restrict__ be = A.beta + (mo - m);
+    const double* __restrict__ as = st + 4 * ((int64_t)npol * (mo - m) + ip0);
+    const int64_t ls4 = 4 * (int64_t)npol;
+    Leg2State<R> S;
+    leg2_load_state<R>(A, m, chunk, lane, S);
+    double ar[R][NP][4], ai[R][NP][4];
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+#pragma unroll
+        for (int p = 0; p < NP; ++p)
+#pragma unroll
+            for (int k = 0; k < 4; ++k) ar[r][p][k] = ai[r][p][k] = 0.0;
+        if (S.ls[r] == lw) { S.pc[r] = S.sd(r, 0); S.pp[r] = S.sd(r, 1); S.mc[r] = S.sd(r, 2); S.mp[r] = S.sd(r, 3); }
+    }
+    for (int l = lw; l <= lmax; l += 2) {
+        const double* __restrict__ c0 = as + ls4 * l;
+        const double* __restrict__ c1 = c0 + ls4;
+        const double al1 = al[l + 1], be1 = be[l + 1], al2 = al[l + 2], be2 = be[l + 2];
+        const bool inj = l < lAend;
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            double W = S.pc[r] + S.mc[r], X = S.pc[r] - S.mc[r];
+#pragma unroll
+            for (int p = 0; p < NP; ++p) {
+                const double e0r = c0[4 * p], e0i = c0[4 * p + 1], b0r = c0[4 * p + 2], b0i = c0[4 * p + 3];
+                ar[r][p][0] += e0r * W;  ai[r][p][0] += e0i * W;
+                ar[r][p][1] -= b0i * X;  ai[r][p][1] += b0r * X;
+                ar[r][p][2] += b0r * W;  ai[r][p][2] += b0i * W;
+                ar[r][p][3] += e0i * X;  ai[r][p][3] -= e0r * X;
+            }
+            if (inj) leg2_advance<R, true>(S, r, l, al1, be1); else leg2_advance<R, false>(S, r, l, al1, be1);
+            W = S.pc[r] + S.mc[r];
+            X = S.pc[r] - S.mc[r];
+#pragma unroll
+            for (int p = 0; p < NP; ++p) {
+                const double e1r = c1[4 * p], e1i = c1[4 * p + 1], b1r = c1[4 * p + 2], b1i = c1[4 * p + 3];
+                ar[r][p][1] += e1r * W;  ai[r][p][1] += e1i * W;
+                ar[r][p][0] -= b1i * X;  ai[r][p][0] += b1r * X;
+                ar[r][p][3] += b1r * W;  ai[r][p][3] += b1i * W;
+                ar[r][p][2] += e1i * X;  ai[r][p][2] -= e1r * X;
+            }
+            if (inj) leg2_advance<R, true>(S, r, l + 1, al2, be2); else leg2_advance<R, false>(S, r, l + 1, al2, be2);
+        }
+    }
+    const int l0 = m > 2 ? m : 2;
+    const bool swap = ((l0 + m) & 1) != 0;
+    const int base = chunk * 64 * R + lane;
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        const int pr = base + r * 64;
+#pragma unroll
+        for (int p = 0; p < NP; ++p)
+#pragma unroll
+            for (int q = 0; q < 2; ++q) {
+                const double kr = swap ? ar[r][p][2 * q + 1] : ar[r][p][2 * q], ki = swap ? ai[r][p][2 * q + 1] : ai[r][p][2 * q];
+                const double fr = swap ? ar[r][p][2 * q] : ar[r][p][2 * q + 1], fi = swap ? ai[r][p][2 * q] : ai[r][p][2 * q + 1];
+                double* o = ph + (kq + 2 * p + q) * ph_stride + d_phidx(A.lmax + 1, pr, m);
+                o[0] = kr + fr;
+                o[1] = ki + fi;
+                o[2] = kr - fr;
+                o[3] = ki - fi;
+            }
+    }
+}
+
 template <int R>
 __global__ void __launch_bounds__(256) k_leg2_adj_np2(Leg2Args A, const WaveTask* __restrict__ tasks, int ntasks,
                                                       const double* __restrict__ ph, int64_t ph_stride, int kq,
@@ -1704,7 +1789,21 @@ static bool leg2_pairs2(bool adjoint) {
 void launch_leg2_synth(const Leg2Args& A, const WaveTask* tasks, int ntasks, const double* st, int npol, double* ph,
                        int64_t ph_stride, int kq0, hipStream_t s) {
     if (ntasks == 0) return;
-    for (int ip = 0; ip < npol; ++ip) {
+    // three and more pairs: four (three) per wave at one ring pair per lane (k_leg2_synth_npx<1, NP>; CMDR_SYNTH2_NP=0: off)
+    const bool npx_on = [] { const char* e = std::getenv("CMDR_SYNTH2_NP"); return !e || std::atoi(e) != 0; }();   // per call (test hook)
+    int ip0 = 0;
+    if (npx_on && A.R == 2) {
+        while (npol - ip0 >= 3) {
+            const int left = npol - ip0;
+            const int nb = (left == 3 || left == 6 || left == 5) ? 3 : 4;      // 5 = 3 + 2, 6 = 3 + 3, 7 = 4 + 3, 9 = 4 + 3 + 2 ...
+            if (nb == 4)
+                hipLaunchKernelGGL((k_leg2_synth_npx<1, 4>), dim3((ntasks / 4) * 2), dim3(256), 0, s, A, tasks, ntasks, st, npol, ip0, ph, ph_stride, kq0 + 2 * ip0, 2);
+            else
+                hipLaunchKernelGGL((k_leg2_synth_npx<1, 3>), dim3((ntasks / 4) * 2), dim3(256), 0, s, A, tasks, ntasks, st, npol, ip0, ph, ph_stride, kq0 + 2 * ip0, 2);
+            ip0 += nb;
+        }
+    }
+    for (int ip = ip0; ip < npol; ++ip) {
         if (A.R == 2 && ip + 1 < npol && leg2_pairs2(false)) {
             hipLaunchKernelGGL(k_leg2_synth_np2<2>, dim3(ntasks / 4), dim3(256), 0, s, A, tasks, ntasks, st, npol, ip, ph, ph_stride, kq0 + 2 * ip);
             ++ip;
@@ -1784,17 +1883,17 @@ void launch_alm2_to_stream(const double* aE, const double* aB, int64_t pol_strid
 }
 __global__ void k_part2_to_alm(const double* __restrict__ part, int64_t part_pol_stride, int64_t pcs, int nchunk,
                                double* __restrict__ aE, double* __restrict__ aB, int64_t pol_stride,
-                               const double* __restrict__ cnorm, int lmax) {
+                               const double* __restrict__ cnorm, int lmax, const int* __restrict__ lwtab) {
     const int m = blockIdx.y, l = m + blockIdx.x * 256 + threadIdx.x;
     if (l > lmax) return;
     part2_to_alm_elem(part + blockIdx.z * part_pol_stride, pcs, nchunk, aE + blockIdx.z * pol_stride,
-                      aB + blockIdx.z * pol_stride, cnorm, lmax, m, l);
+                      aB + blockIdx.z * pol_stride, cnorm, lmax, m, l, lwtab);
 }
 void launch_part2_to_alm(const double* part, int64_t part_pol_stride, int64_t pcs, int nchunk, double* aE, double* aB,
-                         int64_t pol_stride, const double* cnorm, int lmax, int npol, hipStream_t s) {
+                         int64_t pol_stride, const double* cnorm, int lmax, int npol, hipStream_t s, const int* lwtab) {
     dim3 grid((lmax + 1 + 255) / 256, lmax + 1, npol);
     hipLaunchKernelGGL(k_part2_to_alm, grid, dim3(256), 0, s, part, part_pol_stride, pcs, nchunk, aE, aB, pol_stride,
-                       cnorm, lmax);
+                       cnorm, lmax, lwtab);
 }
 
 // ===================================================================================== ring stage

@@ -52,7 +52,7 @@ void launch_leg2_adj(const Leg2Args& A, const WaveTask* tasks, int ntasks, const
 void launch_alm2_to_stream(const double* aE, const double* aB, int64_t pol_stride, double* st, int npol,
                            const double* cnorm, int lmax, hipStream_t s);
 void launch_part2_to_alm(const double* part, int64_t part_pol_stride, int64_t pcs, int nchunk, double* aE, double* aB,
-                         int64_t pol_stride, const double* cnorm, int lmax, int npol, hipStream_t s);
+                         int64_t pol_stride, const double* cnorm, int lmax, int npol, hipStream_t s, const int* lwtab = nullptr);
 
 // ---- CR solver streams (cr_kernels.hip)
 void launch_sqrtS(const CompDev* comps, int ncomp, int lmax_max, const double* smat, int kind, const double* in,
@@ -68,7 +68,7 @@ void launch_band_prep2(const CompDev* comps, int ncomp, const double* sx, const 
                        const double* cnorm2, int lmax_g, hipStream_t s, const double* extra = nullptr);
 void launch_band_post2(const CompDev* comps, int ncomp, int lmax_max, const double* part2, int64_t pps, int64_t pcs,
                        int nchunk, int npol, const double* w, int nT, const double* cnorm2, int lmax_g, double* yc,
-                       hipStream_t s);
+                       hipStream_t s, const int* lwtab = nullptr);
 void launch_precond_diag(const CompDev* comps, int ncomp, const double* P, int lmax_pre, int nmaps_pre,
                          const double* in, double* out, hipStream_t s);
 void launch_alm_copy_batch(const AlmCopyDesc* d, int n, hipStream_t s);   // columns with distinct destinations

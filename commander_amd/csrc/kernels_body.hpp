@@ -459,13 +459,15 @@ CMDR_HD void alm2_to_stream_elem(const double* __restrict__ aE, const double* __
 //   E = -cnorm kappa'_m / 2 * sum_chunks part ; kappa' = sqrt2 for m > 0 ; l < 2 -> 0
 CMDR_HD void part2_to_alm_elem(const double* __restrict__ p, int64_t part_chunk_stride, int nchunk,
                                double* __restrict__ aE, double* __restrict__ aB, const double* __restrict__ cnorm,
-                               int lmax, int m, int l) {
+                               int lmax, int m, int l, const int* __restrict__ lwtab = nullptr) {
     const int64_t t = d_moffp(lmax, m) + (l - m);
     double s[4] = {0.0, 0.0, 0.0, 0.0};
     if (l >= 2)
-        for (int c = 0; c < nchunk; ++c)
+        for (int c = 0; c < nchunk; ++c) {
+            if (lwtab && l < lwtab[m * nchunk + c]) continue;     // never written: structurally zero
 #pragma unroll
             for (int k = 0; k < 4; ++k) s[k] += p[c * part_chunk_stride + 4 * t + k];
+        }
     const double f = -0.5 * cnorm[t] * (m == 0 ? 1.0 : 1.41421356237309504880);
     const int64_t i = d_packed_index(lmax, l, m);
     aE[i] = s[0] * f;

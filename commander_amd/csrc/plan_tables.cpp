@@ -449,6 +449,8 @@ void Legendre2Tables::build(int lmax_, const std::vector<double>& x, const std::
             tasks.push_back(t);
         }
     }
+    lw_chunk.assign((size_t)nm * nchunk, lmax + 2);     // partial-column entries below it are never written (stay zero)
+    for (const WaveTask& t : tasks) lw_chunk[(size_t)t.m * nchunk + t.chunk] = t.lw;
     std::stable_sort(tasks.begin(), tasks.end(), [](const WaveTask& a, const WaveTask& b) { return a.lw < b.lw; });
     while (tasks.size() % 4) { WaveTask t; t.m = 0; t.chunk = -1; t.lw = lmax + 1; t.lAend = lmax + 1; tasks.push_back(t); }
 }

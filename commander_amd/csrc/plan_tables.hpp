@@ -61,6 +61,7 @@ struct Legendre2Tables {
     std::vector<double> seed;            // [(lmax+1) * npair_pad * 4]: mu+_ls, mu+_{ls-1}, mu-_ls, mu-_{ls-1}
     std::vector<WaveTask> tasks;         // R pairs per lane, 4 tasks per workgroup, longest first
     bool uniform_start = false;          // every 64-pair lane block switches on at one l == max(m, 2) (mod 32)
+    std::vector<int> lw_chunk;           // [(lmax+1) * nchunk] first l the adjoint writes for (m, chunk); lmax+2: nothing
     void build(int lmax, const std::vector<double>& x, const std::vector<double>& sth, int npair_pad, int R,
                int nthreads = 0, const std::vector<int>* mlim_in = nullptr /*[npair]; default mlim_spin2*/);
 };

@@ -74,6 +74,7 @@ void Legendre2Dev::upload(const Legendre2Tables& T) {
         }
     }
     abs_.upload(ab);
+    lw_chunk.upload(T.lw_chunk);
 }
 
 ShtPlan::ShtPlan(int nside, int lmax, const std::vector<int>& rings, const double* wring, int max_maps, bool pol)
@@ -302,7 +303,7 @@ void ShtPlan::map2alm_spin2(const double* d_Q, const double* d_U, double* d_E, d
     rings(1, const_cast<double*>(d_Q), d_U - d_Q, nullptr, weighted, 2, s);
     adjoint2_to_partials(1, 0, s);
     launch_part2_to_alm(part2_.get(), part2_pol_stride(), leg2_.tri4(), leg2_.nchunk, d_E, d_B, 0, leg2_.cnorm.get(),
-                        T_.lmax, 1, s);
+                        T_.lmax, 1, s, leg2_.lw_chunk.get());
 }
 
 // share_in : every scalar column has the same input (d_in holds it once) and every (Q,U) pair the same (E,B) input
@@ -359,7 +360,7 @@ void ShtPlan::sandwich(const double* d_in, double* d_out, const double* const* d
         }
         adjoint2_to_partials(nPout, nT, s);
         launch_part2_to_alm(part2_.get(), part2_pol_stride(), leg2_.tri4(), leg2_.nchunk, d_out + nTout * na,
-                            d_out + (nTout + 1) * na, 2 * na, leg2_.cnorm.get(), T_.lmax, nPout, s);
+                            d_out + (nTout + 1) * na, 2 * na, leg2_.cnorm.get(), T_.lmax, nPout, s, leg2_.lw_chunk.get());
     }
 }
 

@@ -33,7 +33,7 @@ class Legendre2Dev {  // device mirror of Legendre2Tables
     void upload(const Legendre2Tables& T);
     int lmax = -1, npair_pad = 0, R = 2, nchunk = 0, ntasks = 0;
     DevBuf<double> x, seed, alpha, beta, cnorm, abs_;
-    DevBuf<int> ls;
+    DevBuf<int> ls, lw_chunk;
     DevBuf<WaveTask> tasks;
     int64_t tri4() const { return 4 * ntrip(lmax); }   // doubles per polarisation pair (stream / one partial chunk)
 };

@@ -196,12 +196,12 @@ void launch_alm2_to_stream(const double* aE, const double* aB, int64_t pol_strid
                 alm2_to_stream_elem(aE + ip * pol_stride, aB + ip * pol_stride, st, npol, ip, cnorm, lmax, m, l);
 }
 void launch_part2_to_alm(const double* part, int64_t part_pol_stride, int64_t pcs, int nchunk, double* aE, double* aB,
-                         int64_t pol_stride, const double* cnorm, int lmax, int npol, hipStream_t) {
+                         int64_t pol_stride, const double* cnorm, int lmax, int npol, hipStream_t, const int* lwtab) {
     for (int ip = 0; ip < npol; ++ip)
         for (int m = 0; m <= lmax; ++m)
             for (int l = m; l <= lmax; ++l)
                 part2_to_alm_elem(part + ip * part_pol_stride, pcs, nchunk, aE + ip * pol_stride, aB + ip * pol_stride,
-                                  cnorm, lmax, m, l);
+                                  cnorm, lmax, m, l, lwtab);
 }
 
 void launch_ring(int mode, const RingDev* rings, const int* cls, int ncls, int log2M, double* ph,
@@ -319,10 +319,11 @@ void launch_band_prep2(const CompDev* comps, int ncomp, const double* sx, const 
                                 extra ? extra + (nT + 2 * ip + 1) * na : nullptr);
 }
 void launch_band_post2(const CompDev* comps, int ncomp, int, const double* part2, int64_t pps, int64_t pcs, int nchunk,
-                       int npol, const double* w, int nT, const double* cnorm2, int lmax_g, double* yc, hipStream_t) {
+                       int npol, const double* w, int nT, const double* cnorm2, int lmax_g, double* yc, hipStream_t,
+                       const int* lwtab) {
     for (int m = 0; m <= lmax_g; ++m)
         for (int l = m; l <= lmax_g; ++l)
-            band_post2_elem(comps, ncomp, part2, pps, pcs, nchunk, npol, w, nT, cnorm2, lmax_g, yc, m, l);
+            band_post2_elem(comps, ncomp, part2, pps, pcs, nchunk, npol, w, nT, cnorm2, lmax_g, yc, m, l, lwtab);
 }
 void launch_precond_diag(const CompDev* comps, int ncomp, const double* P, int lmax_pre, int nmaps_pre,
                          const double* in, double* out, hipStream_t) {

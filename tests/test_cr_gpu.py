@@ -170,6 +170,11 @@ def test_spin2_adjoint_kernel_forms_gpu(nband, monkeypatch):
     x = np.random.default_rng(100 + nband).standard_normal(ctx.ncr)
     want = S.matmulA(x)
     got_def = ctx.cr_matmulA(x)
+    # synthesis: three and more pairs go four / three at a time through k_leg2_synth_npx; CMDR_SYNTH2_NP=0: the np2 kernels
+    monkeypatch.setenv("CMDR_SYNTH2_NP", "0")
+    got_s0 = ctx.cr_matmulA(x)
+    monkeypatch.delenv("CMDR_SYNTH2_NP")
+    assert np.array_equal(got_s0, got_def)     # the same operations in the same order per ring pair: bit-identical
     monkeypatch.setenv("CMDR_ADJ2_DX", "2")
     got_px = ctx.cr_matmulA(x)                                                         # matrix unit + pipelined DPP form
     assert rel(got_px, want) < 1e-11
