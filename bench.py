@@ -286,7 +286,7 @@ def executed_flops(nT, npol, steps0, steps2, env=os.environ):
       scalar synthesis (k_leg_synth_wg, batches of <= 5 maps sharing one recursion): 3 + 4 nb
       scalar adjoint: matrix unit (6..9 maps: 3 + 32 on 16 MFMA columns, + 4 for a ninth map on the VALU),
                       DPP form (3..5 maps: 3 + 4 nb), VALU form (1..2 maps: 3 + 4 nb + the wave-wide reduction, not counted)
-      spin-2 synthesis: 8 (two chains) + 2 (W, X) + 16 per (Q,U) pair; two pairs share the chains
+      spin-2 synthesis: 8 (two chains) + 2 (W, X) + 16 per (Q,U) pair; four / three / two pairs share the chains
       spin-2 adjoint:   matrix unit (3..4 pairs per launch): 8 + 64 (two A operands x 16 columns);
                         VALU: 8 + 2 + 16 per pair (two pairs share the chains), reduction not counted"""
     f = {"synth0": 0.0, "adj_mx": 0.0, "adj_valu": 0.0, "synth2": 0.0, "adj2": 0.0, "adj2_kernel": None}
@@ -306,11 +306,19 @@ def executed_flops(nT, npol, steps0, steps2, env=os.environ):
             f["adj_valu"] += (3.0 + 4.0 * nb) * steps0
     if npol:
         p = npol
+        f["synth2_launches"] = 0
+        while p >= 3 and env.get("CMDR_SYNTH2_NP", "1") != "0":      # k_leg2_synth_npx: 4 / 3 pairs share the chains
+            nb = 3 if p in (3, 5, 6) else 4
+            f["synth2"] += (10.0 + 16.0 * nb) * steps2
+            f["synth2_launches"] += 1
+            p -= nb
         while p >= 2:
             f["synth2"] += (10.0 + 32.0) * steps2
+            f["synth2_launches"] += 1
             p -= 2
         if p:
             f["synth2"] += 26.0 * steps2
+            f["synth2_launches"] += 1
         mx2 = int(env.get("CMDR_ADJ2_MX", "3"))
         p = npol
         names = []
@@ -341,9 +349,9 @@ def kernel_lines(ms, cnt, nT, npol, steps0, steps2):
     name = {"synth0": "k_leg_synth_wg (scalar Legendre synthesis, all batches of one matvec)",
             "adj_mx": "k_leg_adj_mx (scalar Legendre adjoint on the matrix unit)",
             "adj_valu": "k_leg_adj_dx / k_leg_adj (scalar Legendre adjoint, DPP / VALU form)",
-            "synth2": "k_leg2_synth[_np2] (spin-2 Legendre synthesis, all (Q,U) pairs of one matvec)",
+            "synth2": "k_leg2_synth[_np2|_npx] (spin-2 Legendre synthesis, all (Q,U) pairs of one matvec)",
             "adj2": "%s (spin-2 Legendre adjoint, all (Q,U) pairs of one matvec)" % (f["adj2_kernel"] or "k_leg2_adj")}
-    nl = {"synth0": len(_batches(nT, 5)) if nT else 0, "adj_mx": 1, "adj_valu": 1, "synth2": (npol + 1) // 2,
+    nl = {"synth0": len(_batches(nT, 5)) if nT else 0, "adj_mx": 1, "adj_valu": 1, "synth2": max(1, f.get("synth2_launches", 1)),
           "adj2": max(1, f.get("adj2_launches", 1))}
     out = {}
     for k in t:

@@ -789,6 +789,305 @@ __global__ void __launch_bounds__(128) k_leg_adj_dx(LegArgs A, const WaveTask* _
     }
 }
 
+// ---- Synthesis on the matrix unit, small tile (round 3) ------------------------------------------------------------
+// v_mfma_f64_4x4x4_4b_f64 -- four independent 4x4x4 blocks per instruction -- sustains 72 TFLOP/s on this part where the
+// 16x16x4 tile sustains 49 and a loop of fp64 VALU FMAs 65 (tools/microbench/fp64_mfma_4x4.hip; one shared datapath).
+// Operand layout, found by experiment (tools/microbench/mfma_4x4_layout.hip):  lane = x + 4 b + 16 y,
+//     A_b[i][k]: x = i, y = k      B_b[k][j]: x = j, y = k      D_b[i][j]: x = j, y = i      (b = block; CBSZ/ABID: no effect)
+// The synthesis F(pair, col) = sum_l mu_l(pair) a_l(col) maps onto it with block = 4 ring pairs, i = pair of the block,
+// k = 4 values of l of one parity, j = 4 columns (two maps x (re, im)): the 16 lanes of a row (lane & 15) are 16 ring
+// pairs in A and D, every output belongs to one lane (no partial sums), and the coefficients -- the same for every
+// block -- are read from the workgroup's LDS tile with a broadcast address.  Per (ring pair, l): 2 fp64 operations of
+// recursion + 8 flop per column group, all maps of a batch on ONE recursion (nine maps: five groups, where
+// k_leg_synth_wg runs 5 + 4 maps on two); one wave = one 64-pair block (the accumulators of all l stay in 8 NCG
+// registers), a workgroup = the four blocks of two adjacent tasks of one m.
+//   * mu goes from the recursion (lane = ring pair) to the A operand (lane = (pair of 16, l of 4)) through a
+//     wave-private LDS image of 16 l x 64 pairs, two of them: while the 16 NCG MFMAs of one image are issued, the 16
+//     recursion steps that fill the other are slotted between them (one step per NCG MFMAs), so neither the dependent
+//     FMA chain nor the LDS round trip is ever waited for.  Pitch 66 doubles and operand rows {r, r + 8, r + 2, r + 10}:
+//     the two half-waves of a ds_read_b64 touch 32 different banks.
+//   * the recursion runs in the sign-alternated form nu_l = s_l mu_l, s = (+, +, -, -) from l = m on:
+//     nu_{l+1} = nu_{l-1} + (-1)^(l-m) alpha_{l+1} (x nu_l) is ONE multiply and ONE v_fmac_f64_dpp into the register
+//     that held nu_{l-1}, with the 16 alphas of an image in one VGPR (lane j of every row: one vector load per image,
+//     requested an image ahead) and the step's alpha delivered by the DPP row broadcast -- no scalar loads, whose waits
+//     would stall the MFMA stream.  The signs s_l are folded into the coefficient tile when it is staged.
+//   * the l grid of the images is anchored at m, so the order of every sum depends on (m, pair) alone.
+struct PrepTermM4 { long long sxo; int wo, lmaxc; };
+constexpr int kM4H = 16;        // l per mu image
+constexpr int kM4Pitch = 66;    // doubles per image row
+template <int NCG>
+constexpr int m4_lds_bytes() {
+    return (int)sizeof(double) * (4 * 2 * kM4H * kM4Pitch + 2 * kTileL * (4 * NCG + 1)) + (int)sizeof(PrepTermM4) * 2 * NCG * 8;
+}
+
+// One image: MF -- the 16 NCG MFMAs on image `ard` and coefficient rows `brd`; REC -- the 16 recursion steps of the NEXT
+// image (l = l0n .. l0n + 15) into `twr`, step S behind the MFMAs of (operand group S / 4, pair group S % 4).
+template <int NCG, bool MF, bool REC, bool INJ, int ROW, int S>
+__device__ __forceinline__ void m4_image(const double* __restrict__ ard, const double* __restrict__ brd,
+                                         double (&acc)[4][NCG][2], double (&Ac)[4], double (&Bc)[NCG], double (&An)[4],
+                                         double (&Bn)[NCG], double* __restrict__ twr, int l0n, double x, double& na,
+                                         double& nb, double scn, double spn, int ls, double cv) {
+    if constexpr (S < 16) {
+        constexpr int g = S >> 2, q = S & 3;
+        if (MF && q == 0 && g < 3) {          // operands of group g + 1: requested before the MFMAs of group g are issued
+            constexpr int r1 = 4 * ((g + 1) >> 1) + ((g + 1) & 1);
+#pragma unroll
+            for (int c = 0; c < NCG; ++c) Bn[c] = brd[r1 * ROW + 4 * c];
+#pragma unroll
+            for (int qq = 0; qq < 4; ++qq) An[qq] = ard[r1 * kM4Pitch + 16 * qq];
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        if (MF) {
+#pragma unroll
+            for (int c = 0; c < NCG; ++c)
+                acc[q][c][g & 1] = __builtin_amdgcn_mfma_f64_4x4x4f64(Ac[q], Bc[c], acc[q][c][g & 1], 0, 0, 0);
+        }
+        if (REC) {
+            double& cur = (S & 1) ? nb : na;
+            double& prev = (S & 1) ? na : nb;
+            if (INJ) if (ls == l0n + S) { cur = scn; prev = spn; }
+            twr[S * kM4Pitch] = cur;
+            const double xm = x * cur;
+            fmac_row_bcast<S>(prev, cv, xm);      // prev <- nu_{l+1}
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        if (MF && q == 3 && g < 3) {
+#pragma unroll
+            for (int c = 0; c < NCG; ++c) Bc[c] = Bn[c];
+#pragma unroll
+            for (int qq = 0; qq < 4; ++qq) Ac[qq] = An[qq];
+        }
+        m4_image<NCG, MF, REC, INJ, ROW, S + 1>(ard, brd, acc, Ac, Bc, An, Bn, twr, l0n, x, na, nb, scn, spn, ls, cv);
+    }
+}
+
+template <int NCG, bool PREP>
+__global__ void __launch_bounds__(256, 2) k_leg_synth_m4(LegArgs A, const WaveTask* __restrict__ tasks, int ntasks,
+                                                         const double* __restrict__ ast, int nbs, int k0, int nb,
+                                                         double* __restrict__ ph, int64_t ph_stride, PrepDev P) {
+    constexpr int NS = 2 * NCG;                          // map slots (slots >= nb stay zero and are not stored)
+    constexpr int ROW = 2 * NS + 1;                      // odd: rows 8 apart fall into different banks
+    constexpr int NE = kTileL * ROW;
+    constexpr int NLD = (NE + 255) / 256;
+    static_assert(kTileL == 2 * kM4H, "two mu images per coefficient tile");
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_m4[];
+    double* const sm = reinterpret_cast<double*>(smem_m4);
+    const int wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    double* const Tw = sm + wid * (2 * kM4H * kM4Pitch);          // two images
+    double* const ctile = sm + 4 * (2 * kM4H * kM4Pitch);
+    PrepTermM4* const terms = reinterpret_cast<PrepTermM4*>(ctile + 2 * NE);
+    const int tg = blockIdx.x >> 1, half = blockIdx.x & 1;
+    const WaveTask T = tasks[tg * 4 + half * 2 + (wid >> 1)];
+    const int m = __builtin_amdgcn_readfirstlane(tasks[tg * 4].m);
+    const int lw0 = __builtin_amdgcn_readfirstlane(min(tasks[tg * 4 + half * 2].lw, tasks[tg * 4 + half * 2 + 1].lw));
+    const int chunk = __builtin_amdgcn_readfirstlane(T.chunk);
+    const int lmax = A.lmax;
+    const int64_t mo = d_moffp(lmax, m);
+    const double* __restrict__ al = A.alpha + (mo - m);
+    const double* __restrict__ as = ast + 2 * ((int64_t)nbs * (mo - m) + k0);
+    const int64_t ls2 = 2 * (int64_t)nbs;
+    const int pbase = (chunk < 0 ? 0 : chunk) * 128 + (wid & 1) * 64;
+    double x, na = 0.0, nb_ = 0.0, scn, spn;
+    int ls, lwr;
+    {
+        const int p = pbase + lane;
+        const int64_t idx = (int64_t)m * A.npair_pad + p;
+        x = A.x[p];
+        ls = chunk < 0 ? 0x3fffffff : A.ls[idx];
+        const double sc = A.seedc[idx], sp = A.seedp[idx];
+        scn = ((ls - m) & 2) ? -sc : sc;                 // seeds in the sign-alternated form
+        spn = ((ls - 1 - m) & 2) ? -sp : sp;
+        int v = ls;
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) v = min(v, __shfl_xor(v, o));
+        lwr = __builtin_amdgcn_readfirstlane(v);
+    }
+    double acc[4][NCG][2];
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+#pragma unroll
+        for (int c = 0; c < NCG; ++c) acc[q][c][0] = acc[q][c][1] = 0.0;
+    // ---- coefficient tiles: as k_leg_synth_wg (PREP: k_band_prep folded into the staging), rows with (l - m) & 2 negated
+    const int sl = m == 0 ? 1 : 2;
+    const int64_t na_ = (int64_t)(lmax + 1) * (lmax + 1);
+    const int64_t gbase = d_packed_index(lmax, 0, m);
+    if (PREP) {
+        if ((int)threadIdx.x < nb * P.ncomp) {
+            const int k = threadIdx.x / P.ncomp, c = threadIdx.x - k * P.ncomp, bm = k0 + k;
+            const CompDev C = P.comps[c];
+            const int st = P.bm_stokes[bm];
+            PrepTermM4 Tm;
+            Tm.lmaxc = st < C.nmaps ? C.lmax : -1;
+            Tm.sxo = C.pos + (int64_t)st * C.nalm + d_packed_index(C.lmax, 0, m);
+            Tm.wo = (bm * P.ncomp + c) * (lmax + 1);
+            terms[threadIdx.x] = Tm;
+        }
+        __syncthreads();
+    }
+    const bool prep1 = PREP && P.ncomp == 1 && !P.extra;
+    const double* pw[NLD];
+    const double* psx[NLD];
+    int plm[NLD], prow[NLD];
+#pragma unroll
+    for (int i = 0; i < NLD; ++i) {
+        const int e = (int)threadIdx.x + 256 * i;
+        const int row = e / ROW, col = e - row * ROW;
+        prow[i] = row;
+        pw[i] = psx[i] = nullptr;
+        plm[i] = -1;
+        if (PREP && prep1 && e < NE && col < 2 * nb) {
+            const PrepTermM4 Tm = terms[col >> 1];
+            pw[i] = P.w + Tm.wo;
+            psx[i] = P.sx + Tm.sxo + (col & 1);
+            plm[i] = ((col & 1) && m == 0) ? -1 : min(Tm.lmaxc, lmax);
+        }
+    }
+    const double* __restrict__ pcn = PREP ? P.cnorm + (mo - m) : nullptr;
+    const double kap = m == 0 ? 1.0 : 0.70710678118654752440;
+    // The loads of tile t + 1 are issued at the top of tile t and their arithmetic is done at its bottom (fetch_finish):
+    // done right behind the loads it would put a vmcnt(0) wait -- a full trip to L2 / HBM -- in front of every tile's MFMAs
+    double raw[NLD][3];
+    auto fetch = [&](int lb, double* v) {
+        if (PREP && prep1) {
+#pragma unroll
+            for (int i = 0; i < NLD; ++i) {
+                const int l = lb + prow[i];
+                raw[i][0] = raw[i][1] = raw[i][2] = 0.0;
+                if (l <= plm[i]) {
+                    raw[i][0] = pw[i][l];
+                    raw[i][1] = psx[i][sl * l];
+                    raw[i][2] = pcn[l];
+                }
+            }
+            return;
+        }
+#pragma unroll
+        for (int i = 0; i < NLD; ++i) {
+            const int e = (int)threadIdx.x + 256 * i;
+            const int row = e / ROW, col = e - row * ROW;
+            const int l = lb + row;
+            double val = 0.0;
+            if (e < NE && l <= lmax && col < 2 * nb) {
+                if (PREP) {
+                    const int k = col >> 1, part = col & 1;
+                    if (!(part && m == 0)) {
+                        double s = 0.0;
+                        if (P.extra) s = P.extra[(int64_t)(k0 + k) * na_ + gbase + sl * l + part];
+                        for (int c = 0; c < P.ncomp; ++c) {
+                            const PrepTermM4 Tm = terms[k * P.ncomp + c];
+                            if (l > Tm.lmaxc) continue;
+                            const double wc = P.w[Tm.wo + l];
+                            const double t = P.sx[Tm.sxo + sl * l + part];
+                            if (wc != 0.0) s += wc * t;
+                        }
+                        val = s * (P.cnorm[mo - m + l] * kap);
+                    }
+                } else {
+                    val = as[ls2 * l + col];
+                }
+            }
+            v[i] = (row & 2) ? -val : val;                // s_l of the sign-alternated recursion (lb == m mod 32)
+        }
+    };
+    auto fetch_finish = [&](double* v) {
+        if (PREP && prep1) {
+#pragma unroll
+            for (int i = 0; i < NLD; ++i) {
+                double a = 0.0;
+                if (raw[i][0] != 0.0) a += raw[i][0] * raw[i][1];
+                a *= raw[i][2] * kap;
+                v[i] = (prow[i] & 2) ? -a : a;
+            }
+        }
+    };
+    // operand addressing: k = lane >> 4 picks the row offset {0, 8, 2, 10}; A reads pair (lane & 15) of a 16-pair
+    // group, B column (lane & 3) of a column group
+    const int kk = lane >> 4, roff = (kk & 1) * 8 + (kk >> 1) * 2;
+    const int aoff = roff * kM4Pitch + (lane & 15);
+    const int boff = roff * ROW + (lane & 3);
+    // the 16 signed alphas of the image that starts at l0: lane j of every row holds (-1)^j alpha_{l0 + j + 1}
+    auto load_al = [&](int l0) {
+        return al[min(l0 + 1 + (lane & 15), lmax + 2)];     // (behind lmax: values nobody uses, reads inside the table)
+    };
+    auto signed_al = [&](double a) { return (lane & 1) ? -a : a; };
+    const int lb0 = lw0 - ((lw0 - m) & (kTileL - 1));
+    const int ntile = lb0 > lmax ? 0 : (lmax - lb0) / kTileL + 1;
+    double pre[NLD];
+    if (ntile > 0) { fetch(lb0, pre); fetch_finish(pre); }
+    bool primed = false;                                  // wave-uniform: image 0 of the current tile is filled
+    double cv[2] = {0.0, 0.0}, cvr[2] = {0.0, 0.0};   // signed alphas beside image 0 / 1 of this tile; raw loads for the next
+    double Ac[4], Bc[NCG], An[4], Bn[NCG];
+    for (int t = 0; t < ntile; ++t) {
+        double* cur = ctile + (t & 1) * NE;
+#pragma unroll
+        for (int i = 0; i < NLD; ++i) {
+            const int e = (int)threadIdx.x + 256 * i;
+            if (e < NE) cur[e] = pre[i];
+        }
+        __syncthreads();                                  // tile t visible; tile t-1 (same buffer as t+1) fully consumed
+        const int lb = lb0 + t * kTileL;
+        const bool active = chunk >= 0 && lb + kTileL > lwr;   // some pair of this block has started (wave-uniform)
+        // the alphas of the two recursions that run beside the NEXT tile's images: requested first, so that waiting for
+        // them at the bottom of this tile does not wait for the coefficient loads behind them
+        if (active) { cvr[0] = load_al(lb + kTileL + kM4H); cvr[1] = load_al(lb + 2 * kTileL); }
+        if (t + 1 < ntile) fetch(lb + kTileL, pre);       // in flight while this tile is consumed
+        if (!active) {
+            if (t + 1 < ntile) fetch_finish(pre);
+            continue;
+        }
+        if (!primed) {                                    // first image of this wave: recursion alone
+            const double c0 = signed_al(load_al(lb));
+            m4_image<NCG, false, true, true, ROW, 0>(nullptr, nullptr, acc, Ac, Bc, An, Bn, Tw + lane, lb, x, na, nb_, scn, spn, ls, c0);
+            cv[0] = signed_al(load_al(lb + kM4H));
+            cv[1] = signed_al(load_al(lb + kTileL));
+            primed = true;
+        }
+        // the two images of the tile: MFMAs on image h, the recursion of the next image (the other buffer) beside them.
+        // Behind the last tile that recursion runs on into rows nobody reads (one code path: a second instantiation
+        // of the image body costs the register allocator its grip on the 8 NCG accumulators)
+#pragma unroll 1
+        for (int h = 0; h < 2; ++h) {
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            const double* ard = Tw + h * (kM4H * kM4Pitch) + aoff;
+            const double* brd = cur + h * (kM4H * ROW) + boff;
+            const int l0n = lb + (h + 1) * kM4H;
+#pragma unroll
+            for (int c = 0; c < NCG; ++c) Bc[c] = brd[4 * c];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) Ac[q] = ard[16 * q];
+#ifndef CMDR_M4_DBG
+#define CMDR_M4_DBG 0      // timing experiments (separate builds): 1 no recursion beside the MFMAs, 2 no MFMAs
+#endif
+            m4_image<NCG, CMDR_M4_DBG != 2, CMDR_M4_DBG != 1, true, ROW, 0>(ard, brd, acc, Ac, Bc, An, Bn, Tw + (1 - h) * (kM4H * kM4Pitch) + lane, l0n, x,
+                                                    na, nb_, scn, spn, ls, h == 0 ? cv[0] : cv[1]);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        cv[0] = signed_al(cvr[0]);
+        cv[1] = signed_al(cvr[1]);
+        __builtin_amdgcn_sched_barrier(0);
+        if (t + 1 < ntile) fetch_finish(pre);
+    }
+    if (chunk < 0) return;
+    // D_b[i][j]: lane = j + 4 b + 16 i holds pair 16 q + 4 b + i, column j of group c
+    const int j = lane & 3, slot0 = j >> 1, reim = j & 1;
+    const int pl = pbase + 4 * ((lane >> 2) & 3) + (lane >> 4);
+#pragma unroll
+    for (int c = 0; c < NCG; ++c) {
+        const int slot = 2 * c + slot0;
+        if (slot >= nb) continue;
+        double* __restrict__ o0 = ph + (int64_t)(k0 + slot) * ph_stride + reim;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            double* o = o0 + d_phidx(lmax + 1, pl + 16 * q, m);
+            o[0] = acc[q][c][0] + acc[q][c][1];
+            o[2] = acc[q][c][0] - acc[q][c][1];
+        }
+    }
+}
+
 // maps sharing one recursion per wave (register budget).  Tuning knobs: CMDR_LEG_NB caps both kernels,
 // CMDR_LEG_NB_S / CMDR_LEG_NB_A set the synthesis / adjoint value (up to the compiled maximum).
 static int leg_batch(int R, bool adjoint, bool wg = false) {
@@ -847,6 +1146,43 @@ void launch_leg_synth(const LegArgs& A, const WaveTask* tasks, int ntasks, const
                       int64_t ph_stride, int nmaps, hipStream_t s, int nbs, const PrepDev* prep) {
     if (ntasks == 0 || nmaps == 0) return;
     if (nbs < 0) nbs = nmaps;
+    // CMDR_SYNTH_M4=n: batches of n maps and more through the small-tile matrix-unit kernel, up to ten maps on one
+    // recursion.  OFF by default (0): measured 3.3-3.9 ms against 2.7 ms for nine maps at Nside 1024 / lmax 2000 -- the
+    // 512 B a wave stores per l for the transposition meet the 85 B/clk of the CU's LDS store path, and the recursion's
+    // VALU instructions do not hide behind the same wave's MFMAs (tried list).  Read per call (test hook).
+    const int m4_min = [] { const char* e = std::getenv("CMDR_SYNTH_M4"); return e ? std::atoi(e) : 0; }();
+    if (A.wg && A.R == 2 && m4_min > 0 && nmaps >= m4_min) {
+        for_batches(nmaps, 10, [&](int nb, int k0, int rep) {
+            for (int ir = 0; ir < rep; ++ir, k0 += nb) {
+#define CMDR_M4(NCG)                                                                                                    \
+    do {                                                                                                                \
+        static bool attr_set = false;                                                                                   \
+        if (!attr_set) {                                                                                                \
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_leg_synth_m4<NCG, true>),                        \
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, m4_lds_bytes<NCG>());                 \
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_leg_synth_m4<NCG, false>),                       \
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, m4_lds_bytes<NCG>());                 \
+            attr_set = true;                                                                                            \
+        }                                                                                                               \
+        if (prep)                                                                                                       \
+            hipLaunchKernelGGL((k_leg_synth_m4<NCG, true>), dim3((ntasks / 4) * 2), dim3(256), m4_lds_bytes<NCG>(), s,  \
+                               A, tasks, ntasks, ast, nbs, k0, nb, ph, ph_stride, *prep);                               \
+        else                                                                                                            \
+            hipLaunchKernelGGL((k_leg_synth_m4<NCG, false>), dim3((ntasks / 4) * 2), dim3(256), m4_lds_bytes<NCG>(), s, \
+                               A, tasks, ntasks, ast, nbs, k0, nb, ph, ph_stride, PrepDev{});                           \
+    } while (0)
+                switch ((nb + 1) / 2) {
+                    case 1: CMDR_M4(1); break;
+                    case 2: CMDR_M4(2); break;
+                    case 3: CMDR_M4(3); break;
+                    case 4: CMDR_M4(4); break;
+                    default: CMDR_M4(5); break;
+                }
+#undef CMDR_M4
+            }
+        });
+        return;
+    }
     for_batches(nmaps, A.wg ? std::min(leg_batch(A.R, false, true), 5) : leg_batch(A.R, false), [&](int nb, int k0, int rep) {
 #define CMDR_S(RR, NN) case NN: synth_RN<RR, NN>(A, tasks, ntasks, ast, nbs, k0, rep, ph, ph_stride, s, prep); break;
         if (A.R == 1) {

@@ -449,11 +449,14 @@ def test_fused_pcg_updates_equal_the_general_sequence_gpu(cfg, pol, monkeypatch)
 
 
 @pytest.mark.parametrize("env", [{}, {"CMDR_SYNTH_DPP": "0"}, {"CMDR_SYNTH_PREP": "0"},
-                                 {"CMDR_SYNTH_DPP": "0", "CMDR_SYNTH_PREP": "0"}, {"CMDR_ADJ_X9": "0"}, {"CMDR_ADJ_DX": "0"}])
+                                 {"CMDR_SYNTH_DPP": "0", "CMDR_SYNTH_PREP": "0"}, {"CMDR_ADJ_X9": "0"}, {"CMDR_ADJ_DX": "0"},
+                                 {"CMDR_SYNTH_M4": "3"}, {"CMDR_SYNTH_M4": "3", "CMDR_SYNTH_PREP": "0"},
+                                 {"CMDR_SYNTH_M4": "3", "CMDR_UNIFORM_START": "0"}])
 def test_kernel_form_switches_agree_with_the_oracle(env, monkeypatch):
     """The A/B switches of the Legendre kernels (synthesis through LDS broadcasts instead of DPP, coefficients from the
-    stream instead of the staging, ninth map in its own launch, small batches through the VALU adjoint) select code
-    paths that stay compiled in: each must give the oracle's matvec, on 9 bands (matrix unit) and on 4 (DPP / VALU form)."""
+    stream instead of the staging, ninth map in its own launch, small batches through the VALU adjoint, synthesis on the
+    small matrix-unit tile) select code paths that stay compiled in: each must give the oracle's matvec, on 9 bands
+    (matrix unit) and on 4 (DPP / VALU form)."""
     from commander_amd import synth
     from commander_amd.cr import build_context
     for k, v in env.items():
