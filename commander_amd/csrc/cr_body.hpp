@@ -120,9 +120,12 @@ CMDR_HD void band_post_elem(const CompDev* __restrict__ comps, int ncomp, const 
             }
             if (!any) continue;
             const double* p = part + b * part_map_stride + 2 * t;
-            double s2[2];     // rows a chunk's task never writes are structurally zero and left out (lwtab)
-            chunk_sum<2>(p, part_chunk_stride, nchunk, lwtab ? lwtab + m * nchunk : nullptr, l, s2);
-            const double sr = s2[0], si = s2[1];
+            double sr = 0.0, si = 0.0;
+            for (int ch = 0; ch < nchunk; ++ch) {
+                if (lwtab && l < lwtab[m * nchunk + ch]) continue;   // never written by the adjoint: structurally zero
+                sr += p[ch * part_chunk_stride];
+                si += p[ch * part_chunk_stride + 1];
+            }
             for (int c = 0; c < ncomp; ++c)
                 if (wc[c] != 0.0) { re[c] += wc[c] * sr; im[c] += wc[c] * si; }
         }
@@ -202,8 +205,11 @@ CMDR_HD void band_post2_elem(const CompDev* __restrict__ comps, int ncomp, const
     if (!any) return;
     for (int ip = 0; ip < npol; ++ip) {
         const double* p = part2 + ip * part_pol_stride + 4 * t;
-        double a[4];
-        chunk_sum<4>(p, part_chunk_stride, nchunk, lwtab ? lwtab + m * nchunk : nullptr, l, a);
+        double a[4] = {0.0, 0.0, 0.0, 0.0};
+        for (int ch = 0; ch < nchunk; ++ch) {
+            if (lwtab && l < lwtab[m * nchunk + ch]) continue;     // never written: structurally zero
+            for (int k = 0; k < 4; ++k) a[k] += p[ch * part_chunk_stride + k];
+        }
         for (int c = 0; c < ncomp; ++c) {
             if (!use[c]) continue;
             const double we = w[((int64_t)(nT + 2 * ip) * ncomp + c) * (lmax_g + 1) + l];

@@ -455,32 +455,6 @@ CMDR_HD void alm2_to_stream_elem(const double* __restrict__ aE, const double* __
     o[0] = v[0]; o[1] = v[1]; o[2] = v[2]; o[3] = v[3];
 }
 
-// Sum over the chunk partials of one (l, m) entry (NV doubles per entry; p -> the entry in chunk 0), chunks in the fixed
-// order 0, 1, ..., the chunks whose task never writes row l (lw = lwtab + m * nchunk) left out.  The loads of eight
-// chunks are issued together before the first add: the kernels that finish the adjoint are pure streams over the
-// partial columns and one thread's chain of load -> add -> load is what bounded them.
-template <int NV>
-CMDR_HD void chunk_sum(const double* __restrict__ p, int64_t part_chunk_stride, int nchunk, const int* __restrict__ lw,
-                       int l, double* __restrict__ out) {
-    for (int k = 0; k < NV; ++k) out[k] = 0.0;
-    for (int c0 = 0; c0 < nchunk; c0 += 8) {
-        double v[8][NV];
-#if defined(__HIPCC__)
-#pragma unroll
-#endif
-        for (int j = 0; j < 8; ++j) {
-            const int c = c0 + j;
-            const bool on = c < nchunk && !(lw && l < lw[c]);
-            for (int k = 0; k < NV; ++k) v[j][k] = on ? p[c * part_chunk_stride + k] : 0.0;     // + 0.0: no change
-        }
-#if defined(__HIPCC__)
-#pragma unroll
-#endif
-        for (int j = 0; j < 8; ++j)
-            for (int k = 0; k < NV; ++k) out[k] += v[j][k];
-    }
-}
-
 // spin-2 adjoint partial columns (4 doubles per l: E'r, E'i, B'r, B'i) -> packed E, B:
 //   E = -cnorm kappa'_m / 2 * sum_chunks part ; kappa' = sqrt2 for m > 0 ; l < 2 -> 0
 CMDR_HD void part2_to_alm_elem(const double* __restrict__ p, int64_t part_chunk_stride, int nchunk,
@@ -488,7 +462,12 @@ CMDR_HD void part2_to_alm_elem(const double* __restrict__ p, int64_t part_chunk_
                                int lmax, int m, int l, const int* __restrict__ lwtab = nullptr) {
     const int64_t t = d_moffp(lmax, m) + (l - m);
     double s[4] = {0.0, 0.0, 0.0, 0.0};
-    if (l >= 2) chunk_sum<4>(p + 4 * t, part_chunk_stride, nchunk, lwtab ? lwtab + m * nchunk : nullptr, l, s);
+    if (l >= 2)
+        for (int c = 0; c < nchunk; ++c) {
+            if (lwtab && l < lwtab[m * nchunk + c]) continue;     // never written: structurally zero
+#pragma unroll
+            for (int k = 0; k < 4; ++k) s[k] += p[c * part_chunk_stride + 4 * t + k];
+        }
     const double f = -0.5 * cnorm[t] * (m == 0 ? 1.0 : 1.41421356237309504880);
     const int64_t i = d_packed_index(lmax, l, m);
     aE[i] = s[0] * f;
@@ -1140,9 +1119,12 @@ CMDR_HD void part_to_alm_elem(const double* __restrict__ p, int64_t part_chunk_s
                               double* __restrict__ a, const double* __restrict__ cnorm, int lmax, int m, int l,
                               const int* __restrict__ lwtab = nullptr) {
     const int64_t t = d_moffp(lmax, m) + (l - m);
-    double s[2];
-    chunk_sum<2>(p + 2 * t, part_chunk_stride, nchunk, lwtab ? lwtab + m * nchunk : nullptr, l, s);
-    const double re = s[0], im = s[1];
+    double re = 0.0, im = 0.0;
+    for (int c = 0; c < nchunk; ++c) {
+        if (lwtab && l < lwtab[m * nchunk + c]) continue;     // never written: structurally zero
+        re += p[c * part_chunk_stride + 2 * t];
+        im += p[c * part_chunk_stride + 2 * t + 1];
+    }
     const double cn = cnorm[t];
     const int64_t i = d_packed_index(lmax, l, m);
     if (m == 0) {
