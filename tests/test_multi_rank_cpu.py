@@ -153,7 +153,15 @@ def _hybrid_worker(rank, world, port, out_dir):
     resid, xi, eta = synth.draw_inputs(spec)
     b = ctx.cr_computeRHS("sample", resid, xi, eta)
     sol, n, stat, res = ctx.solve_cr_eqn_by_CG(b, "fixed_iter", 1e-8, 5, 12, 1)
-    np.savez(os.path.join(out_dir, "rank%d.npz" % rank), y=y, b=b, sol=sol, pm=pm, bands=np.array(lay["bands"]))
+    # CG_LMAX_PRECOND on top: every rank builds the dense low-l block from ITS bands on the full low-resolution sky, the
+    # sum over the band groups counts each group ring_parts times (lowl_update divides by ring_replicas_)
+    low = synth.lowres_noise(synth.make_problem("cfg2", nside=nside, lmax=lmax), 4)
+    mine = [low[bb] for bb in lay["bands"]]
+    ctx.set_lowl_precond(0, 6, [ns for ns, _ in mine], [mm for _, mm in mine])
+    ctx.update_precond()
+    pml = ctx.cr_invM(x)
+    soll = ctx.solve_cr_eqn_by_CG(b, "fixed_iter", 1e-8, 5, 12, 1)[0]
+    np.savez(os.path.join(out_dir, "rank%d.npz" % rank), y=y, b=b, sol=sol, pm=pm, pml=pml, soll=soll, bands=np.array(lay["bands"]))
     dist.barrier()
     dist.destroy_process_group()
 
@@ -180,6 +188,12 @@ def test_four_rank_band_ring_hybrid_matches_single_rank(tmp_path):
     resid, xi, eta = synth.draw_inputs(spec)
     b = ctx.cr_computeRHS("sample", resid, xi, eta)
     sol, n, stat, res = ctx.solve_cr_eqn_by_CG(b, "fixed_iter", 1e-8, 5, 12, 1)
+    low = synth.lowres_noise(spec, 4)
+    ctx.set_lowl_precond(0, 6, [ns for ns, _ in low], [mm for _, mm in low])
+    ctx.update_precond()
+    pml = ctx.cr_invM(x)
+    soll = ctx.solve_cr_eqn_by_CG(b, "fixed_iter", 1e-8, 5, 12, 1)[0]
+    assert np.count_nonzero(pml != pm) == 49                   # the (6 + 1)^2 low-l entries of the CMB went through the dense block
     seen = []
     for r in range(4):
         g = np.load(os.path.join(str(tmp_path), "rank%d.npz" % r))
@@ -188,6 +202,8 @@ def test_four_rank_band_ring_hybrid_matches_single_rank(tmp_path):
         assert rel(g["pm"], pm) < 1e-12
         assert rel(g["b"], b) < 1e-12
         assert rel(g["sol"], sol) < 1e-10
+        assert rel(g["pml"], pml) < 1e-11                      # band x ring-set bookkeeping of the low-l block (ring_replicas = 2)
+        assert rel(g["soll"], soll) < 1e-10
     assert sorted(set(seen)) == [0, 1, 2]
 
 
