@@ -648,7 +648,7 @@ def main():
         dt_refresh /= max(1, min(args.steps, 3))
     # the same step through the HOST-pointer ABI (cmdr_compute_rhs + cmdr_solve: what INTEGRATION.md's Level-1 Fortran
     # driver calls): pays the H2D of the residual / noise maps and eta and the D2H of rhs and x every sample.  Never `value`.
-    dt_host = None
+    dt_host = dt_host_pinned = None
     if not args.no_extras and world == 1 and not rehearse:
         def host_step():
             bh = ctx.cr_computeRHS("sample", resid, xi, eta)
@@ -659,6 +659,29 @@ def main():
         host_step()
         barrier()
         dt_host = time.perf_counter() - t0
+        # ... and with the driver's long-lived input arrays page-locked once (cmdr_host_register), as INTEGRATION.md
+        # recommends for data(i)%res%map and the noise draws
+        dt_host_pinned = None
+        try:
+            pinned = [np.ascontiguousarray(a, dtype=np.float64) for a in list(resid) + list(xi) + [eta]]
+            resid_p, xi_p, eta_p = pinned[:len(resid)], pinned[len(resid):len(resid) + len(xi)], pinned[-1]
+            for a in pinned:
+                ctx.host_register(a)
+            try:
+                def host_step_pinned():
+                    bh = ctx.cr_computeRHS("sample", resid_p, xi_p, eta_p)
+                    return ctx.solve_cr_eqn_by_CG(bh, "fixed_iter", 1e-8, 5, NITER, 1)
+                host_step_pinned()
+                barrier()
+                t0 = time.perf_counter()
+                host_step_pinned()
+                barrier()
+                dt_host_pinned = time.perf_counter() - t0
+            finally:
+                for a in pinned:
+                    ctx.host_unregister(a)
+        except Exception as e:   # noqa: BLE001  (reported leg only)
+            print("[bench] pinned host-ABI leg skipped: %r" % (e,), file=sys.stderr, flush=True)
     if rank == 0:
         nbm, steps_pruned = int(info[0]), int(info[2])
         nT, npol, steps2 = int(info[4]), int(info[5]), int(info[3])
@@ -719,8 +742,10 @@ def main():
             "rccl_world_size": rccl_world, "collective": collective if dist is not None else None,
             "value_with_precond_refresh": (1.0 / dt_refresh) if dt_refresh else None,
             "value_host_abi": (1.0 / dt_host) if dt_host else None,
+            "value_host_abi_pinned": (1.0 / dt_host_pinned) if dt_host and dt_host_pinned else None,
             "value_host_abi_note": "the same step through the host-pointer ABI (cmdr_compute_rhs + cmdr_solve: H2D of the "
-                                   "residual / noise maps and eta, D2H of rhs and x, every sample); reported, never `value`",
+                                   "residual / noise maps and eta, D2H of rhs and x, every sample); _pinned: with those input arrays page-locked "
+                                   "once through cmdr_host_register; reported, never `value`",
             "roofline": {
                 "bound": "mfma",
                 "bound_detail": "fp64 matrix unit (v_mfma_f64_16x16x4_f64) + fp64 VALU recursion; one shared datapath on "

@@ -379,6 +379,16 @@ class CRContext:
     def dev(self, n, src=None):
         return DeviceArray(self.L, n, src)
 
+    def host_register(self, a):
+        """Page-lock a long-lived, C-contiguous numpy array (cmdr_host_register): the host-pointer entry points then copy
+        from / to it by DMA.  Returns the array; ``host_unregister`` before it is freed."""
+        assert a.flags["C_CONTIGUOUS"]
+        check(self.L.cmdr_host_register(ctypes.c_void_p(a.ctypes.data), a.nbytes), self.L)
+        return a
+
+    def host_unregister(self, a):
+        check(self.L.cmdr_host_unregister(ctypes.c_void_p(a.ctypes.data)), self.L)
+
     def cr_matmulA_dev(self, x, y):
         check(self.L.cmdr_matmulA_dev(self._h, x.ptr, y.ptr), self.L)
 

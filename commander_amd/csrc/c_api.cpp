@@ -72,6 +72,18 @@ int cmdr_memcpy_h2d(void* dst, const void* src, size_t n) {
 int cmdr_memcpy_d2h(void* dst, const void* src, size_t n) {
     return guarded([&] { CMDR_HIP_CHECK(hipMemcpy(dst, src, n, hipMemcpyDeviceToHost)); });
 }
+int cmdr_host_register(void* p, size_t n) {
+    return guarded([&] {
+        CMDR_REQUIRE(p != nullptr && n > 0, "bad arguments");
+        CMDR_HIP_CHECK(hipHostRegister(p, n, hipHostRegisterDefault));
+    });
+}
+int cmdr_host_unregister(void* p) {
+    return guarded([&] {
+        CMDR_REQUIRE(p != nullptr, "NULL argument");
+        CMDR_HIP_CHECK(hipHostUnregister(p));
+    });
+}
 
 int cmdr_sht_plan_create(int nside, int lmax, int nrings, const int* rings, const double* wring, int max_maps,
                          cmdr_sht_plan** out) {

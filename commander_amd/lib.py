@@ -40,6 +40,8 @@ def _sig(L):
     L.cmdr_dev_mem_info.argtypes = [ctypes.POINTER(c_sz), ctypes.POINTER(c_sz)]
     L.cmdr_memcpy_h2d.argtypes = [c_vp, c_vp, c_sz]
     L.cmdr_memcpy_d2h.argtypes = [c_vp, c_vp, c_sz]
+    L.cmdr_host_register.argtypes = [c_vp, c_sz]
+    L.cmdr_host_unregister.argtypes = [c_vp]
     L.cmdr_sht_plan_create.argtypes = [c_int, c_int, c_int, ip, dp, c_int, ctypes.POINTER(c_vp)]
     L.cmdr_sht_plan_create_pol.argtypes = [c_int, c_int, c_int, ip, dp, c_int, ctypes.POINTER(c_vp)]
     L.cmdr_sht_execute_spin2.argtypes = [c_vp, c_int, dp, dp, dp, dp]

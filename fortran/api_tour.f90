@@ -114,7 +114,9 @@ program api_tour
   nb = int(ncr, c_size_t) * 8_c_size_t
   call cmdr_check(cmdr_dev_alloc(nb, dx), 'dev_alloc x'); call cmdr_check(cmdr_dev_alloc(nb, dy), 'dev_alloc y')
   call cmdr_check(cmdr_dev_alloc(nb, dz), 'dev_alloc z')
+  call cmdr_check(cmdr_host_register(c_loc(x), nb), 'host_register')       ! long-lived host array: copies by DMA from now on
   call cmdr_check(cmdr_memcpy_h2d(dx, c_loc(x), nb), 'h2d')
+  call cmdr_check(cmdr_host_unregister(c_loc(x)), 'host_unregister')
   call cmdr_check(cmdr_matmulA_dev(ctx, dx, dy), 'cr_matmulA_dev')
   call cmdr_check(cmdr_memcpy_d2h(c_loc(ay), dy, nb), 'd2h')
   if (maxval(abs(ay - ax)) > 0.d0) stop 'api_tour: device-pointer matvec differs from the host-pointer one'

@@ -551,6 +551,20 @@ module cmdr_hip_mod
        integer(c_int)           :: ierr
      end function cmdr_memcpy_d2h
 
+     ! page-lock a long-lived host array (c_loc(array)) so that the host-pointer entry points copy by DMA
+     function cmdr_host_register(ptr_host, nbytes) bind(c, name='cmdr_host_register') result(ierr)
+       import :: c_int, c_size_t, c_ptr
+       type(c_ptr), value       :: ptr_host
+       integer(c_size_t), value :: nbytes
+       integer(c_int)           :: ierr
+     end function cmdr_host_register
+
+     function cmdr_host_unregister(ptr_host) bind(c, name='cmdr_host_unregister') result(ierr)
+       import :: c_int, c_ptr
+       type(c_ptr), value :: ptr_host
+       integer(c_int)     :: ierr
+     end function cmdr_host_unregister
+
      ! device-pointer forms of the CR entry points: x, b stay in HBM between calls (type(c_ptr) from cmdr_dev_alloc)
      function cmdr_matmulA_dev(ctx, x_dev, y_dev) bind(c, name='cmdr_matmulA_dev') result(ierr)
        import :: c_int, c_ptr

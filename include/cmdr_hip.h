@@ -43,6 +43,12 @@ int cmdr_dev_free(void* p);
 int cmdr_dev_mem_info(size_t* free_bytes, size_t* total_bytes);
 int cmdr_memcpy_h2d(void* dst_dev, const void* src_host, size_t nbytes);
 int cmdr_memcpy_d2h(void* dst_host, const void* src_dev, size_t nbytes);
+/* Page-lock a caller-owned host buffer (hipHostRegister), so that the host-pointer entry points below copy from / to it by
+ * DMA at the link's rate instead of staging pageable memory: the band maps Commander allocates once per run
+ * (data(i)%res%map and the noise draws of cr_computeRHS, comm_cr_mod.f90:452-466) are 1.8 GB per amplitude sample at the
+ * benchmark size.  Optional; the buffer must stay allocated (and must not move) until cmdr_host_unregister. */
+int cmdr_host_register(void* ptr_host, size_t nbytes);
+int cmdr_host_unregister(void* ptr_host);
 
 /* ------------------------------------------------------------------------------------------------
  * SHT level.  Replaces sharp_make_mmajor_real_packed_alm_info + sharp_make_subset_healpix_geom_info

@@ -18,6 +18,9 @@ inline hipError_t hipFree(void* p) { std::free(p); return 0; }
 inline hipError_t hipMemcpy(void* d, const void* s, size_t n, hipMemcpyKind) { std::memmove(d, s, n); return 0; }
 inline hipError_t hipMemcpyAsync(void* d, const void* s, size_t n, hipMemcpyKind, hipStream_t) { std::memmove(d, s, n); return 0; }
 inline hipError_t hipMemsetAsync(void* d, int v, size_t n, hipStream_t) { std::memset(d, v, n); return 0; }
+constexpr unsigned hipHostRegisterDefault = 0;
+inline hipError_t hipHostRegister(void*, size_t, unsigned) { return 0; }
+inline hipError_t hipHostUnregister(void*) { return 0; }
 inline hipError_t hipStreamSynchronize(hipStream_t) { return 0; }
 inline hipError_t hipDeviceSynchronize() { return 0; }
 inline hipError_t hipGetDeviceCount(int* n) { *n = 1; return 0; }
