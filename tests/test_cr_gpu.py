@@ -468,3 +468,30 @@ def test_kernel_form_switches_agree_with_the_oracle(env, monkeypatch):
         x = np.random.default_rng(3 + nband).standard_normal(ctx.ncr)
         assert rel(ctx.cr_matmulA(x), S.matmulA(x)) < 1e-11
         ctx.close()
+
+
+def test_page_locked_caller_buffers_give_the_same_rhs_gpu():
+    """cmdr_host_register / cmdr_host_unregister: the host-pointer entry points read page-locked caller arrays (DMA) and
+    pageable ones (staged) to the same bits."""
+    from commander_amd import synth
+    from commander_amd.cr import build_context
+    spec = synth.make_problem("cfg3", nside=64, lmax=128)
+    ctx = build_context(spec)
+    ctx.initPrecond()
+    ctx.update_precond()
+    resid, xi, eta = synth.draw_inputs(spec)
+    want = ctx.cr_computeRHS("sample", resid, xi, eta)
+    arrs = [np.ascontiguousarray(a, dtype=np.float64) for a in list(resid) + list(xi) + [eta]]
+    for a in arrs:
+        ctx.host_register(a)
+    try:
+        nb = len(resid)
+        got = ctx.cr_computeRHS("sample", arrs[:nb], arrs[nb:2 * nb], arrs[-1])
+        sol = ctx.solve_cr_eqn_by_CG(ctx.host_register(got), "fixed_iter", maxiter=5)[0]
+        ctx.host_unregister(got)
+    finally:
+        for a in arrs:
+            ctx.host_unregister(a)
+    assert np.array_equal(got, want)
+    assert np.array_equal(sol, ctx.solve_cr_eqn_by_CG(want, "fixed_iter", maxiter=5)[0])
+    ctx.close()
