@@ -53,13 +53,24 @@ __device__ __forceinline__ void fmac_row_bcast(double& acc, double g, double a) 
 // One l of the synthesis for R ring pairs per lane and NB maps, coefficients through DPP row broadcasts: C[c] holds, in
 // lane j of every 16-lane row, column c of tile row lb16 + j (a~ re / im of map c / 2), so step J takes lane J of the
 // row inside the FMA; alpha_{l+1} comes through the scalar unit.  Same operations in the same order as the LDS-broadcast loop.
+// a4 / a4n: alpha of the first four steps, fetched by the previous block (its scalar load would otherwise be waited for at
+// the top of every block), and the same for the next block, requested at step 1 together with this block's own.
 template <int R, int NB, bool INJECT, int J>
 __device__ __forceinline__ void synth_steps16(const double (&C)[2 * NB], const double* __restrict__ alp /* alpha_{lb16+1+j} */,
                                               int lb16, const double (&x)[R], double (&mc)[R],
                                               double (&mp)[R], const double (&sc)[R], const double (&sp)[R],
                                               const int (&ls)[R], double (&Er)[R][NB], double (&Ei)[R][NB],
-                                              double (&Or)[R][NB], double (&Oi)[R][NB]) {
+                                              double (&Or)[R][NB], double (&Oi)[R][NB], const double (&a4)[4],
+                                              double (&a4n)[4]) {
     if constexpr (J < 16) {
+        if constexpr (J == 1) {
+            __builtin_amdgcn_sched_barrier(0);             // (... or hoist it above the waits for the tile rows)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) a4n[i] = alp[16 + i];
+            __builtin_amdgcn_sched_barrier(0);             // (the scheduler would sink the request to the block's end)
+        }
+        double alj;
+        if constexpr (J < 4) alj = a4[J]; else alj = alp[J];
 #pragma unroll
         for (int r = 0; r < R; ++r) {
             if (INJECT) if (ls[r] == lb16 + J) { mc[r] = sc[r]; mp[r] = sp[r]; }   // phase A: lanes still switch on
@@ -73,12 +84,12 @@ __device__ __forceinline__ void synth_steps16(const double (&C)[2 * NB], const d
                     fmac_row_bcast<J>(Oi[r][k], C[2 * k + 1], mc[r]);
                 }
             }
-            const double ax = alp[J] * x[r];                   // alpha_{l+1} through the scalar unit
+            const double ax = alj * x[r];                      // alpha_{l+1} through the scalar unit
             const double tt = ax * mc[r] - mp[r];
             mp[r] = mc[r];
             mc[r] = tt;
         }
-        synth_steps16<R, NB, INJECT, J + 1>(C, alp, lb16, x, mc, mp, sc, sp, ls, Er, Ei, Or, Oi);
+        synth_steps16<R, NB, INJECT, J + 1>(C, alp, lb16, x, mc, mp, sc, sp, ls, Er, Ei, Or, Oi, a4, a4n);
     }
 }
 
@@ -145,6 +156,16 @@ __global__ void __launch_bounds__(256, 3) k_leg_synth_wg(LegArgs A, const WaveTa
         }
         lwr[r] = __builtin_amdgcn_readfirstlane(v);
     }
+    // UNI: the seeds as the block's start will take them (zero in the lanes that never start), formed HERE: their first
+    // use inside the tile loop would leave the wait for these loads there, as a vmcnt(0) that also waits, tile after
+    // tile, for the tile loads issued just before it
+    double scv[R], spv[R];
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        const bool on = UNI && ls[r] == lwr[r];
+        scv[r] = on ? sc[r] : 0.0;
+        spv[r] = on ? sp[r] : 0.0;
+    }
     // PREP: per (map of this batch, component) where the component's (l = 0, m) entry sits in sx (the packed index is
     // linear in l within one m), where its weight row starts, and up to which l it contributes
     struct PrepTerm { long long sxo, wo; int lmaxc, pad; };
@@ -189,22 +210,26 @@ __global__ void __launch_bounds__(256, 3) k_leg_synth_wg(LegArgs A, const WaveTa
     const double* __restrict__ pcn = PREP ? P.cnorm + (mo - m) : nullptr;
     const double kap = m == 0 ? 1.0 : 0.70710678118654752440;
     // tile element e -> (row = l - lb, col): col < 2 NB: stream double, col == 2 NB: alpha_{l+1}
+    // prep1: the loads of a tile are issued one tile ahead and their arithmetic is done when the tile is stored
+    // (fetch_finish, at the top of the loop): done right behind the loads it puts a vmcnt(0) wait -- a trip to L2 / HBM --
+    // in front of the first 16 l of every tile
+    double raw[NLD][3];
     auto fetch = [&](int lb, double* v) {
         if (PREP && prep1) {
 #pragma unroll
             for (int i = 0; i < NLD; ++i) {
                 const int l = lb + prow[i];
-                double val = 0.0;
+                raw[i][0] = raw[i][1] = raw[i][2] = 0.0;
                 if (l <= plm[i]) {
-                    const double wc = pw[i][l], t = psx[i][sl * l];
-                    double a = 0.0;
-                    if (wc != 0.0) a += wc * t;
-                    val = a * (pcn[l] * kap);
+                    raw[i][0] = pw[i][l];
+                    raw[i][1] = psx[i][sl * l];
+                    raw[i][2] = pcn[l];
                 } else if (!DPPC && (int)threadIdx.x + 256 * i < NE && (int)threadIdx.x + 256 * i - prow[i] * ROW == 2 * NB &&
                            l <= lmax + 1) {
-                    val = al[l + 1];
+                    raw[i][0] = al[l + 1];               // alpha column of the LDS form: passes through fetch_finish
+                    raw[i][1] = 1.0;
+                    raw[i][2] = 1.0 / kap;
                 }
-                v[i] = val;
             }
             return;
         }
@@ -240,11 +265,31 @@ __global__ void __launch_bounds__(256, 3) k_leg_synth_wg(LegArgs A, const WaveTa
             v[i] = val;
         }
     };
+    auto fetch_finish = [&](double* v) {
+        if (PREP && prep1) {
+#pragma unroll
+            for (int i = 0; i < NLD; ++i) {
+                double a = 0.0;
+                if (raw[i][0] != 0.0) a += raw[i][0] * raw[i][1];
+                v[i] = a * (raw[i][2] * kap);
+            }
+        }
+    };
     double pre[NLD];
     const int ntile = (lmax - lw0) / kTileL + 1;
+    // UNI: alpha of the first four steps of the next 16-l block (synth_steps16).  The blocks a wave runs are consecutive
+    // from the first one with lb16 + 16 > lw, so the first set is fetched here and every later one by the block before
+    double a4[4];
+    {
+        const int first = lw0 + ((max(lw, lw0) - lw0) & ~15);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) a4[i] = al[min(first, lmax) + 1 + i];
+    }
     fetch(lw0, pre);
     for (int t = 0; t < ntile; ++t) {
         double* cur = tile[t & 1];
+        __builtin_amdgcn_sched_barrier(0);
+        fetch_finish(pre);
 #pragma unroll
         for (int i = 0; i < NLD; ++i) {
             const int e = (int)threadIdx.x + 256 * i;
@@ -264,14 +309,15 @@ __global__ void __launch_bounds__(256, 3) k_leg_synth_wg(LegArgs A, const WaveTa
                     if (lb16 + 16 <= lw || lb16 > lmax) continue;
 #pragma unroll
                     for (int r = 0; r < R; ++r)
-                        if (lb16 == lwr[r]) {              // wave-uniform: this block's lanes switch on here
-                            if (ls[r] == lb16) { mc[r] = sc[r]; mp[r] = sp[r]; }
-                        }
+                        if (lb16 == lwr[r]) { mc[r] = scv[r]; mp[r] = spv[r]; }   // wave-uniform: this block's lanes switch on here
                     double C[2 * NB];
                     const double* __restrict__ crow = cur + (hb + (lane & 15)) * ROW;
 #pragma unroll
                     for (int c = 0; c < 2 * NB; ++c) C[c] = crow[c];
-                    synth_steps16<R, NB, false, 0>(C, al + lb16 + 1, lb16, x, mc, mp, sc, sp, ls, Er, Ei, Or, Oi);
+                    double a4n[4];
+                    synth_steps16<R, NB, false, 0>(C, al + lb16 + 1, lb16, x, mc, mp, sc, sp, ls, Er, Ei, Or, Oi, a4, a4n);
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) a4[i] = a4n[i];
                 }
                 continue;
             }
@@ -286,7 +332,12 @@ __global__ void __launch_bounds__(256, 3) k_leg_synth_wg(LegArgs A, const WaveTa
                 const double* __restrict__ crow = cur + (hb + (lane & 15)) * ROW;
 #pragma unroll
                 for (int c = 0; c < 2 * NB; ++c) C[c] = crow[c];
-                synth_steps16<R, NB, true, 0>(C, al + lb16 + 1, lb16, x, mc, mp, sc, sp, ls, Er, Ei, Or, Oi);
+                {
+                    double b4[4], b4n[4];
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) b4[i] = al[lb16 + 1 + i];
+                    synth_steps16<R, NB, true, 0>(C, al + lb16 + 1, lb16, x, mc, mp, sc, sp, ls, Er, Ei, Or, Oi, b4, b4n);
+                }
             }
 #pragma unroll 1
             for (; hb < kTileL; hb += 16) {
@@ -296,7 +347,12 @@ __global__ void __launch_bounds__(256, 3) k_leg_synth_wg(LegArgs A, const WaveTa
                 const double* __restrict__ crow = cur + (hb + (lane & 15)) * ROW;
 #pragma unroll
                 for (int c = 0; c < 2 * NB; ++c) C[c] = crow[c];
-                synth_steps16<R, NB, false, 0>(C, al + lb16 + 1, lb16, x, mc, mp, sc, sp, ls, Er, Ei, Or, Oi);
+                {
+                    double b4[4], b4n[4];
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) b4[i] = al[lb16 + 1 + i];
+                    synth_steps16<R, NB, false, 0>(C, al + lb16 + 1, lb16, x, mc, mp, sc, sp, ls, Er, Ei, Or, Oi, b4, b4n);
+                }
             }
             continue;
         }
