@@ -32,6 +32,25 @@ __global__ void __launch_bounds__(256) k_mix4(double* out, int iters, double a, 
     out[blockIdx.x * 256 + threadIdx.x] = s;
 }
 
+// NV independent v_fmac_f64_dpp (row_newbcast operand, the synthesis kernels' accumulate) per iteration
+template <int NV>
+__global__ void __launch_bounds__(256) k_dpp(double* out, int iters, double a) {
+    double v[NV];
+#pragma unroll
+    for (int i = 0; i < NV; ++i) v[i] = threadIdx.x * 1e-3 + i;
+    double g = 1e-3 * (threadIdx.x & 15), m = a;
+    asm volatile("" : "+v"(g), "+v"(m));
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+        for (int i = 0; i < NV; ++i)
+            asm volatile("v_fmac_f64_dpp %0, %1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf" : "+v"(v[i]) : "v"(g), "v"(m), "n"(i & 15));
+    }
+    double s = 0;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) s += v[i];
+    out[blockIdx.x * 256 + threadIdx.x] = s;
+}
+
 template <int NM, bool SMALL>
 __global__ void __launch_bounds__(256) k_mf(double* out, int iters) {
     double acc1[NM];
@@ -75,6 +94,12 @@ int main() {
         double ms = timeit([&] { hipLaunchKernelGGL((k_mix4<NV, NM>), dim3(nblk), dim3(256), 0, 0, out, iters, 0.999, 1e-3); }); \
         double fv = 2.0 * NV * iters * (double)nblk * 256, fm = 2.0 * NM * 256.0 * iters * (double)nblk * 4;          \
         printf("mix NV=%2d NM=%d: %.3f ms   VALU %.1f TF  MFMA4 %.1f TF  sum %.1f TF\n", NV, NM, ms, fv / ms / 1e9, fm / ms / 1e9, (fv + fm) / ms / 1e9); \
+    }
+    {
+        double ms = timeit([&] { hipLaunchKernelGGL((k_dpp<16>), dim3(nblk), dim3(256), 0, 0, out, iters, 1e-9); });
+        printf("v_fmac_f64_dpp x16: %.3f ms  %.1f TF\n", ms, 2.0 * 16 * iters * (double)nblk * 256 / ms / 1e9);
+        ms = timeit([&] { hipLaunchKernelGGL((k_dpp<8>), dim3(nblk), dim3(256), 0, 0, out, iters, 1e-9); });
+        printf("v_fmac_f64_dpp x8:  %.3f ms  %.1f TF\n", ms, 2.0 * 8 * iters * (double)nblk * 256 / ms / 1e9);
     }
     MIX(8, 0) MIX(16, 0) MIX(0, 8) MIX(2, 8) MIX(4, 8) MIX(8, 8) MIX(16, 8)
     return 0;
