@@ -2363,6 +2363,8 @@ void launch_ring(int mode, const RingDev* rings, const int* cls, int ncls, int l
     const size_t lds = sizeof(cd) * (size_t)(lds_elems(log2M) + (use_ldstw ? ring_tw_elems(log2Mmax) : 0));
     int nthr = 512;   // measured: 512 > 256 threads per ring pair (more waves to cover LDS / global latency)
     if (const char* e = std::getenv("CMDR_RING_THREADS")) { const int v = std::atoi(e); if (v == 256 || v == 512 || v == 1024) nthr = v; }
+    if (log2M >= 13)     // the 8192-point images (one workgroup per CU): their own knob
+        if (const char* e = std::getenv("CMDR_RING_THREADS_BIG")) { const int v = std::atoi(e); if (v == 256 || v == 512 || v == 1024) nthr = v; }
     if (nthr > (1 << log2M) / 2) nthr = std::max(64, (1 << log2M) / 2);
     static int xbl = -1;                      // log2 of the pairs per block
     if (xbl < 0) { xbl = 2; if (const char* e = std::getenv("CMDR_RING_XBL")) { const int v = std::atoi(e); if (v >= 0 && v <= 10) xbl = v; } }
