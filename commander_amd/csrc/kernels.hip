@@ -476,6 +476,34 @@ __device__ inline double wave_reduce16(const double* v, double* tile, int lane) 
     return s;
 }
 
+// ---- alpha / beta of the next l group through the scalar unit, requested by hand ------------------------------------
+// The VALU adjoint kernels store a partial column entry per l group.  Behind a global store inside the loop the compiler
+// no longer proves the recursion tables unclobbered, fetches alpha_{l+1} (beta_{l+1}) with VECTOR loads and waits for
+// them a few instructions later: one trip to L2 per group of 4 / 8 l, in front of its arithmetic.  These helpers issue the
+// s_load themselves, one group ahead; the values are taken out (sload_wait) at the bottom of the group the load flew
+// behind, so what is carried around the loop is always data that has arrived.
+typedef int sgpr8 __attribute__((ext_vector_type(8)));
+typedef int sgpr16 __attribute__((ext_vector_type(16)));
+__device__ __forceinline__ sgpr8 sload_d4(const double* p) {      // p wave-uniform
+    sgpr8 r;
+    asm volatile("s_load_dwordx8 %0, %1, 0x0" : "=&s"(r) : "s"(p));
+    return r;
+}
+__device__ __forceinline__ sgpr16 sload_d8(const double* p) {
+    sgpr16 r;
+    asm volatile("s_load_dwordx16 %0, %1, 0x0" : "=&s"(r) : "s"(p));
+    return r;
+}
+// `after`: a value of the group just finished, so that the wait cannot be scheduled in front of it
+__device__ __forceinline__ void sload_wait(sgpr8& a, sgpr8& b, double& after) {
+    asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(a), "+s"(b), "+v"(after));
+}
+__device__ __forceinline__ void sload_wait(sgpr16& a, double& after) {
+    asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(a), "+v"(after));
+}
+template <class V>
+__device__ __forceinline__ double sgpr_double(const V& r, int j) { return __hiloint2double(r[2 * j + 1], r[2 * j]); }
+
 // Adjoint: each wave reduces its 64 lanes (wave_reduce16) and writes one partial column segment
 // part[map][chunk][padded triangle] (complex).  Deterministic: fixed summation order, no atomics.
 template <int R, int NB, bool SQUARE>
@@ -504,11 +532,21 @@ __global__ void __launch_bounds__(256) k_leg_adj(LegArgs A, const WaveTask* __re
     double* wl = lds[wid];
     const int id = lane >> 2;              // value this lane ends up with: l = l0 + id/2, (re, im) = id & 1
     int buf = 0;
+    double a8[kAdjL_];                     // alpha_{l0 + 1 + j} of the current group (sload_d8: see above)
+    {
+        sgpr16 a = sload_d8(al + lw + 1);
+        double dummy = 0.0;
+        sload_wait(a, dummy);
+#pragma unroll
+        for (int j = 0; j < kAdjL_; ++j) a8[j] = sgpr_double(a, j);
+    }
     for (int l0 = lw; l0 <= lmax; l0 += kAdjL_) {
+        sgpr16 an = sload_d8(al + l0 + kAdjL_ + 1);       // (table slack behind lmax: plan_tables.hpp ntrip)
         double w[kAdjL_][R];
-        if (l0 < lAend) leg_adj_mu_group<R, NB, SQUARE, true>(al, l0, S, w);
-        else            leg_adj_mu_group<R, NB, SQUARE, false>(al, l0, S, w);
+        if (l0 < lAend) leg_adj_mu_group_v<R, NB, SQUARE, true>(a8, l0, S, w);
+        else            leg_adj_mu_group_v<R, NB, SQUARE, false>(a8, l0, S, w);
         const int l = l0 + (id >> 1);
+        double last = 0.0;
 #pragma unroll
         for (int k = 0; k < NB; ++k) {
             double v[16];
@@ -516,7 +554,11 @@ __global__ void __launch_bounds__(256) k_leg_adj(LegArgs A, const WaveTask* __re
             const double s = wave_reduce16(v, wl + buf * kRedTile, lane);   // double-buffered: one barrier per use
             buf ^= 1;
             if ((lane & 3) == 0 && l <= lmax) out0[(k0 + k) * part_map_stride + 2 * l + (id & 1)] = s;
+            last = s;
         }
+        sload_wait(an, last);
+#pragma unroll
+        for (int j = 0; j < kAdjL_; ++j) a8[j] = sgpr_double(an, j);
     }
 }
 
@@ -1365,14 +1407,26 @@ __global__ void __launch_bounds__(256) k_leg2_adj(Leg2Args A, const WaveTask* __
     double* wl = lds[wid];
     const int id = lane >> 2;              // value this lane ends up with: l = l0 + id/4, component id & 3
     int buf = 0;
+    double a4[4], b4[4];                   // (alpha, beta)_{l0 + 1 + j} of the current group (sload_d4: see k_leg_adj)
+    {
+        sgpr8 a = sload_d4(al + lw + 1), b = sload_d4(be + lw + 1);
+        double dummy = 0.0;
+        sload_wait(a, b, dummy);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { a4[j] = sgpr_double(a, j); b4[j] = sgpr_double(b, j); }
+    }
     for (int l0 = lw; l0 <= lmax; l0 += 4) {
+        sgpr8 an = sload_d4(al + l0 + 5), bn = sload_d4(be + l0 + 5);
         double v[16];
-        if (l0 < lAend) leg2_adj_group<R, true>(A, al, be, l0, S, G, v);
-        else            leg2_adj_group<R, false>(A, al, be, l0, S, G, v);
-        const double sacc = wave_reduce16(v, wl + buf * kRedTile, lane);
+        if (l0 < lAend) leg2_adj_group_v<R, true>(a4, b4, l0, S, G, v);
+        else            leg2_adj_group_v<R, false>(a4, b4, l0, S, G, v);
+        double sacc = wave_reduce16(v, wl + buf * kRedTile, lane);
         buf ^= 1;
         const int l = l0 + (id >> 2);
         if ((lane & 3) == 0 && l <= lmax) out[4 * l + (id & 3)] = sacc;
+        sload_wait(an, bn, sacc);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { a4[j] = sgpr_double(an, j); b4[j] = sgpr_double(bn, j); }
     }
 }
 
@@ -1573,7 +1627,16 @@ __global__ void __launch_bounds__(256) k_leg2_adj_np2(Leg2Args A, const WaveTask
     double* wl = lds[wid];
     const int id = lane >> 2;
     int buf = 0;
+    double a4[4], b4[4];                   // (alpha, beta)_{l0g + 1 + j} of the current group (sload_d4: see k_leg_adj)
+    {
+        sgpr8 a = sload_d4(al + lw + 1), b = sload_d4(be + lw + 1);
+        double dummy = 0.0;
+        sload_wait(a, b, dummy);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { a4[j] = sgpr_double(a, j); b4[j] = sgpr_double(b, j); }
+    }
     for (int l0g = lw; l0g <= lmax; l0g += 4) {
+        sgpr8 an = sload_d4(al + l0g + 5), bn = sload_d4(be + l0g + 5);
         double v[2][16];
         const bool inj = l0g < lAend;
 #pragma unroll
@@ -1590,7 +1653,7 @@ __global__ void __launch_bounds__(256) k_leg2_adj_np2(Leg2Args A, const WaveTask
                     a0[p][2] += W * G[p].uk_r[r] + X * G[p].qf_i[r];
                     a0[p][3] += W * G[p].uk_i[r] - X * G[p].qf_r[r];
                 }
-                if (inj) leg2_advance<R, true>(S, r, l, al[l + 1], be[l + 1]); else leg2_advance<R, false>(S, r, l, al[l + 1], be[l + 1]);
+                if (inj) leg2_advance<R, true>(S, r, l, a4[j], b4[j]); else leg2_advance<R, false>(S, r, l, a4[j], b4[j]);
                 W = S.pc[r] + S.mc[r];
                 X = S.pc[r] - S.mc[r];
 #pragma unroll
@@ -1600,7 +1663,7 @@ __global__ void __launch_bounds__(256) k_leg2_adj_np2(Leg2Args A, const WaveTask
                     a1[p][2] += W * G[p].uf_r[r] + X * G[p].qk_i[r];
                     a1[p][3] += W * G[p].uf_i[r] - X * G[p].qk_r[r];
                 }
-                if (inj) leg2_advance<R, true>(S, r, l + 1, al[l + 2], be[l + 2]); else leg2_advance<R, false>(S, r, l + 1, al[l + 2], be[l + 2]);
+                if (inj) leg2_advance<R, true>(S, r, l + 1, a4[j + 1], b4[j + 1]); else leg2_advance<R, false>(S, r, l + 1, a4[j + 1], b4[j + 1]);
             }
 #pragma unroll
             for (int p = 0; p < 2; ++p)
@@ -1608,12 +1671,17 @@ __global__ void __launch_bounds__(256) k_leg2_adj_np2(Leg2Args A, const WaveTask
                 for (int k = 0; k < 4; ++k) { v[p][4 * j + k] = a0[p][k]; v[p][4 * j + 4 + k] = a1[p][k]; }
         }
         const int l = l0g + (id >> 2);
+        double last = 0.0;
 #pragma unroll
         for (int p = 0; p < 2; ++p) {
             const double sacc = wave_reduce16(v[p], wl + buf * kRedTile, lane);
             buf ^= 1;
             if ((lane & 3) == 0 && l <= lmax) out[p * part_pol_stride + 4 * l + (id & 3)] = sacc;
+            last = sacc;
         }
+        sload_wait(an, bn, last);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { a4[j] = sgpr_double(an, j); b4[j] = sgpr_double(bn, j); }
     }
 }
 

@@ -219,12 +219,13 @@ CMDR_HD void leg_adj_load(const LegArgs& A, const double* __restrict__ ph, int64
 }
 
 // Advance the recursion over l0 .. l0+7 and keep the (possibly squared) mu values: w[j][r]
+// a8[j] = alpha_{l0 + j + 1}
 template <int R, int NB, bool SQUARE, bool INJECT>
-CMDR_HD void leg_adj_mu_group(const double* __restrict__ al, int l0, AdjLane<R, NB>& S, double (*w)[R]) {
+CMDR_HD void leg_adj_mu_group_v(const double (&a8)[kAdjL_], int l0, AdjLane<R, NB>& S, double (*w)[R]) {
 #pragma unroll
     for (int j = 0; j < kAdjL_; ++j) {
         const int l = l0 + j;
-        const double al1 = al[l + 1];
+        const double al1 = a8[j];
 #pragma unroll
         for (int r = 0; r < R; ++r) {
             if (INJECT) if (S.ls[r] == l) { S.mc[r] = S.sc[r]; S.mp[r] = S.sp[r]; }
@@ -234,6 +235,13 @@ CMDR_HD void leg_adj_mu_group(const double* __restrict__ al, int l0, AdjLane<R, 
             S.mc[r] = t;
         }
     }
+}
+template <int R, int NB, bool SQUARE, bool INJECT>
+CMDR_HD void leg_adj_mu_group(const double* __restrict__ al, int l0, AdjLane<R, NB>& S, double (*w)[R]) {
+    double a8[kAdjL_];
+#pragma unroll
+    for (int j = 0; j < kAdjL_; ++j) a8[j] = al[l0 + j + 1];
+    leg_adj_mu_group_v<R, NB, SQUARE, INJECT>(a8, l0, S, w);
 }
 
 // v[2*j], v[2*j+1] = (re, im) partial sums of this lane for l = l0 + j (j < 8), map k
@@ -408,9 +416,10 @@ CMDR_HD void leg2_adj_load(const Leg2Args& A, const double* __restrict__ ph, int
 // one group of 4 l (two pairs): v[4*j + {0..3}] = partial (E'r, E'i, B'r, B'i) of this lane for l = l0g + j
 // transpose of leg2_synth_lane's accumulations:
 //   first of pair : E' += W Gq_keep - i X Gu_flip... written out per component below
+// a4[j] = alpha_{l0g + j + 1}, b4[j] = beta_{l0g + j + 1}
 template <int R, bool INJECT>
-CMDR_HD void leg2_adj_group(const Leg2Args& A, const double* __restrict__ al, const double* __restrict__ be, int l0g,
-                            Leg2State<R>& S, const Adj2G<R>& G, double* v) {
+CMDR_HD void leg2_adj_group_v(const double (&a4)[4], const double (&b4)[4], int l0g, Leg2State<R>& S, const Adj2G<R>& G,
+                              double* v) {
 #pragma unroll
     for (int j = 0; j < 4; j += 2) {
         const int l = l0g + j;
@@ -423,7 +432,7 @@ CMDR_HD void leg2_adj_group(const Leg2Args& A, const double* __restrict__ al, co
             ei += W * G.qk_i[r] + X * G.uf_r[r];
             br += W * G.uk_r[r] + X * G.qf_i[r];
             bi += W * G.uk_i[r] - X * G.qf_r[r];
-            leg2_advance<R, INJECT>(S, r, l, al[l + 1], be[l + 1]);
+            leg2_advance<R, INJECT>(S, r, l, a4[j], b4[j]);
             W = S.pc[r] + S.mc[r];
             X = S.pc[r] - S.mc[r];
             // second of pair: Qf += E' W ; Qk += i B' X ; Uf += B' W ; Uk += -i E' X
@@ -431,11 +440,19 @@ CMDR_HD void leg2_adj_group(const Leg2Args& A, const double* __restrict__ al, co
             ei2 += W * G.qf_i[r] + X * G.uk_r[r];
             br2 += W * G.uf_r[r] + X * G.qk_i[r];
             bi2 += W * G.uf_i[r] - X * G.qk_r[r];
-            leg2_advance<R, INJECT>(S, r, l + 1, al[l + 2], be[l + 2]);
+            leg2_advance<R, INJECT>(S, r, l + 1, a4[j + 1], b4[j + 1]);
         }
         v[4 * j + 0] = er;  v[4 * j + 1] = ei;  v[4 * j + 2] = br;  v[4 * j + 3] = bi;
         v[4 * j + 4] = er2; v[4 * j + 5] = ei2; v[4 * j + 6] = br2; v[4 * j + 7] = bi2;
     }
+}
+template <int R, bool INJECT>
+CMDR_HD void leg2_adj_group(const Leg2Args&, const double* __restrict__ al, const double* __restrict__ be, int l0g,
+                            Leg2State<R>& S, const Adj2G<R>& G, double* v) {
+    double a4[4], b4[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { a4[j] = al[l0g + j + 1]; b4[j] = be[l0g + j + 1]; }
+    leg2_adj_group_v<R, INJECT>(a4, b4, l0g, S, G, v);
 }
 
 // packed (E, B) a_lm -> spin-2 stream entry: E' = -E cnorm kappa_m / 2 (kappa = 1/sqrt2 for m > 0), l >= 2 only
